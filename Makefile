@@ -1,0 +1,35 @@
+# Builds lib/libhprlp.so (the drop-in boundary, reference name and place: <root>/lib/libhprlp.so,
+# reference Makefile:114-115) for gfx950 with hipcc, plus bin/solve_mps_file.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := hpr-lp-c_amd/csrc
+CXXFLAGS := -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -ffp-contract=off -Wall -Wno-unused-result -Wno-return-type-c-linkage
+HIPFLAGS := --offload-arch=$(ARCH)
+BUILD := build
+
+HIP_SRCS := $(wildcard $(CSRC)/*.hip)
+CPP_SRCS := $(wildcard $(CSRC)/*.cpp)
+OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.hip.o,$(HIP_SRCS)) $(patsubst $(CSRC)/%.cpp,$(BUILD)/%.o,$(CPP_SRCS))
+HDRS := $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
+
+all: lib/libhprlp.so bin/solve_mps_file
+
+$(BUILD)/%.hip.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(CXXFLAGS) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(BUILD)/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(CXXFLAGS) $(HIPFLAGS) -x hip -c $< -o $@
+
+lib/libhprlp.so: $(OBJS)
+	@mkdir -p lib
+	$(HIPCC) -shared -fPIC $(HIPFLAGS) -o $@ $(OBJS) -lz -ldl -Wl,--no-undefined
+
+bin/solve_mps_file: tools/solve_mps_file.cpp lib/libhprlp.so include/HPRLP.h
+	@mkdir -p bin
+	g++ -O2 -std=c++11 -Iinclude -o $@ tools/solve_mps_file.cpp -Llib -lhprlp -Wl,-rpath,'$$ORIGIN/../lib'
+
+clean:
+	rm -rf $(BUILD) lib bin
+.PHONY: all clean

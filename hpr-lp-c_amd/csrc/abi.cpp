@@ -1,0 +1,342 @@
+// abi.cpp -- extern "C" boundary: the reference's solve entry points (include/HPRLP.h) and the
+// step-level extension (include/hprlp_amd.h).  Every entry point catches exceptions.
+#include <cmath>
+#include <iomanip>
+#include <iostream>
+
+#include "hprlp_amd.h"
+#include "solver.h"
+#include "version.h"
+
+using namespace hprlp;
+
+struct hprlp_solver {
+    Solver s;
+};
+
+static HPRLP_results make_error_result(const char *status) {
+    HPRLP_results r;
+    std::memset(r.status, 0, sizeof(r.status));
+    std::strncpy(r.status, status, sizeof(r.status) - 1);
+    r.residuals = r.primal_obj = r.gap = 0.0;
+    return r;
+}
+
+static void print_banner_and_parameters(const HPRLP_parameters *p) {
+    std::cout << "\n==================================================================\n"
+              << "                 HPR-LP Solver  (MI355X / gfx950 HIP build)       \n"
+              << "     Halpern Peaceman-Rachford Linear Programming Solver          \n"
+              << "  Version: " << HPRLP_VERSION_STRING << "   backend: " << HPRLP_BACKEND_STRING << "\n"
+              << "==================================================================\n\n";
+    std::cout << "Solver Parameters:\n"
+              << "  Device:              GPU " << p->device_number << "\n"
+              << "  Max Iterations:      " << p->max_iter << "\n"
+              << "  Stopping Tolerance:  " << std::scientific << std::setprecision(1) << p->stop_tol << "\n"
+              << std::defaultfloat << "  Time Limit:          " << std::fixed << std::setprecision(1) << p->time_limit
+              << " seconds\n" << std::defaultfloat << "  Check Interval:      " << p->check_iter << " iterations\n"
+              << "  PSLP Presolve:       " << (p->use_presolve ? "Enabled" : "Disabled") << "\n"
+              << "  Scaling:  CR=" << p->use_CR_scaling << " Ruiz=" << p->use_Ruiz_scaling
+              << " Pock-Chambolle=" << p->use_Pock_Chambolle_scaling << " b/c=" << p->use_bc_scaling << "\n\n";
+}
+
+extern "C" const char *hprlp_last_error(void) { return last_error_cstr(); }
+extern "C" const char *hprlp_backend(void) { return HPRLP_BACKEND_STRING; }
+
+// reference src/HPRLP.cu:116-311
+extern "C" HPRLP_results HPRLP_main_solve(const LP_info_cpu *model, const HPRLP_parameters *param) {
+    if (!model || !param) {
+        std::cerr << "[error] Null model or parameter pointer" << std::endl;
+        return make_error_result("ERROR");
+    }
+    try {
+        print_banner_and_parameters(param);
+        Solver s;
+        s.setup(model, param);
+        std::cout << "Setup (copy and allocation) time = " << std::fixed << std::setprecision(2) << s.setup_time
+                  << " seconds" << std::endl;
+        s.scale();
+        std::cout << "Scaling time = " << std::fixed << std::setprecision(2) << s.scaling_time << " seconds" << std::endl;
+        s.lambda_max = s.power_iteration(5000, 1e-4, nullptr) * 1.01;  // src/HPRLP.cu:81-97
+        if (s.power_iters >= 5000)
+            std::cout << "Power iteration did not converge within the specified tolerance.\n";
+        std::cout << "ESTIMATING MAXIMUM EIGENVALUE time = " << std::fixed << std::setprecision(2) << s.power_time
+                  << " seconds" << std::endl << std::defaultfloat;
+        s.init_iteration_state();
+        HPRLP_results out;
+        s.solve_loop(&out);
+        s.collect_solution(&out);
+        std::cout << "\n=== Solution Summary ===\n"
+                  << "Status: " << out.status << "\nIterations: " << out.iter << "\nTime: " << out.time
+                  << " seconds\nPrimal Objective: " << std::scientific << std::setprecision(12) << out.primal_obj
+                  << "\nResidual: " << out.residuals << "\n\n" << std::defaultfloat;
+        return out;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        std::cerr << "[error] HPRLP_main_solve failed: " << e.what() << std::endl;
+        return make_error_result("ERROR");
+    }
+}
+
+// reference src/HPRLP.cu:493-524.  The embedded PSLP presolve (reference src/pslp_integration.cpp) is
+// a CPU component outside the accelerated path: use_presolve is accepted and
+// the model is solved as given.
+extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters *param) {
+    if (!model) {
+        std::cerr << "[error] Null model pointer" << std::endl;
+        return make_error_result("ERROR");
+    }
+    HPRLP_parameters dflt;
+    const HPRLP_parameters *p = param ? param : &dflt;
+    return HPRLP_main_solve(model, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// step-level extension
+// ------------------------------------------------------------------------------------------------
+#define GUARD_BEGIN try {
+#define GUARD_END(failval)                    \
+    }                                         \
+    catch (const std::exception &e) {         \
+        set_last_error(e.what());             \
+        return failval;                       \
+    }
+
+extern "C" hprlp_solver *hprlp_solver_create(const LP_info_cpu *model, const HPRLP_parameters *param) {
+    if (!model) {
+        set_last_error("null model");
+        return nullptr;
+    }
+    hprlp_solver *h = nullptr;
+    try {
+        HPRLP_parameters dflt;
+        h = new hprlp_solver();
+        h->s.verbose = false;
+        h->s.setup(model, param ? param : &dflt);
+        return h;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        delete h;
+        return nullptr;
+    }
+}
+
+extern "C" void hprlp_solver_destroy(hprlp_solver *h) {
+    try {
+        delete h;
+    } catch (...) {
+    }
+}
+
+extern "C" void hprlp_solver_set_verbose(hprlp_solver *h, int verbose) {
+    if (h) h->s.verbose = verbose != 0;
+}
+
+extern "C" int hprlp_solver_scale(hprlp_solver *h) {
+    GUARD_BEGIN
+    h->s.scale();
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" double hprlp_solver_power_iteration(hprlp_solver *h, int max_iter, double tol, int *iters_out) {
+    GUARD_BEGIN
+    return h->s.power_iteration(max_iter, tol, iters_out);
+    GUARD_END(-1.0)
+}
+
+extern "C" int hprlp_solver_init(hprlp_solver *h, double sigma, double lambda_max) {
+    GUARD_BEGIN
+    h->s.lambda_max = lambda_max;
+    if (sigma > 0) h->s.set_sigma_lambda(sigma, lambda_max, true);
+    else h->s.init_iteration_state();
+    HIP_CHECK(hipStreamSynchronize(h->s.stream));
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" int hprlp_solver_iterate(hprlp_solver *h, int normal, int then_check) {
+    GUARD_BEGIN
+    h->s.run_normal(normal);
+    if (then_check) h->s.step(true);
+    HIP_CHECK(hipStreamSynchronize(h->s.stream));
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" int hprlp_solver_residuals(hprlp_solver *h, int iter, int compute_gap, double out[8]) {
+    GUARD_BEGIN
+    Residuals r;
+    RestartState rs;
+    h->s.compute_residuals(iter, compute_gap != 0, &r, &rs);
+    out[0] = r.err_Rp; out[1] = r.err_Rd; out[2] = r.primal_obj; out[3] = r.dual_obj;
+    out[4] = r.rel_gap; out[5] = r.kkt; out[6] = rs.current_gap; out[7] = h->s.lambda_max;
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" int hprlp_solver_restart(hprlp_solver *h, const double in[6], double *sigma_out) {
+    GUARD_BEGIN
+    RestartState rs;
+    rs.flag = 1;
+    rs.first = false;
+    rs.current_gap = in[0]; rs.best_gap = in[1]; rs.best_sigma = in[2];
+    Residuals r;
+    r.err_Rd = in[3]; r.err_Rp = in[4]; r.rel_gap = in[5];
+    h->s.update_sigma_and_restart(&rs, r);
+    HIP_CHECK(hipStreamSynchronize(h->s.stream));
+    if (sigma_out) *sigma_out = h->s.sigma;
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" double hprlp_solver_weighted_norm(hprlp_solver *h) {
+    GUARD_BEGIN
+    return h->s.weighted_norm_after_restart();
+    GUARD_END(-1.0)
+}
+
+extern "C" int hprlp_solver_run(hprlp_solver *h, HPRLP_results *out, hprlp_trace_row *trace, int max_trace,
+                                int *n_trace) {
+    GUARD_BEGIN
+    static_assert(sizeof(hprlp_trace_row) == sizeof(TraceRow), "trace row layout");
+    h->s.trace = reinterpret_cast<TraceRow *>(trace);
+    h->s.trace_cap = trace ? max_trace : 0;
+    h->s.solve_loop(out);
+    h->s.collect_solution(out);
+    if (n_trace) *n_trace = h->s.trace_n;
+    h->s.trace = nullptr;
+    h->s.trace_cap = 0;
+    return 0;
+    GUARD_END(-1)
+}
+
+namespace {
+struct VecRef {
+    double *p;
+    long n;
+};
+VecRef find_vector(Solver &s, const std::string &name) {
+    if (name == "x") return {s.x.p, s.n_loc};
+    if (name == "last_x") return {s.last_x.p, s.n_loc};
+    if (name == "x_hat") return {s.x_hat, s.n_loc};
+    if (name == "x_bar") return {s.x_bar, s.n_loc};
+    if (name == "z_bar") return {s.z_bar.p, s.n_loc};
+    if (name == "x_temp") return {s.x_temp, s.n_loc};
+    if (name == "y") return {s.y, s.m_loc};
+    if (name == "last_y") return {s.last_y.p, s.m_loc};
+    if (name == "y_bar") return {s.y_bar, s.m_loc};
+    if (name == "y_obj") return {s.y_obj.p, s.m_loc};
+    if (name == "y_temp") return {s.y_temp.p, s.m_loc};
+    if (name == "AL") return {s.AL.p, s.m_loc};
+    if (name == "AU") return {s.AU.p, s.m_loc};
+    if (name == "l") return {s.l.p, s.n_loc};
+    if (name == "u") return {s.u.p, s.n_loc};
+    if (name == "c") return {s.c.p, s.n_loc};
+    if (name == "row_norm") return {s.row_norm.p, s.m_loc};
+    if (name == "col_norm") return {s.col_norm.p, s.n_loc};
+    if (name == "A_val") return {s.A.val.p, s.A.view.nnz};
+    if (name == "AT_val") return {s.AT.val.p, s.AT.view.nnz};
+    return {nullptr, -1};
+}
+}  // namespace
+
+extern "C" long hprlp_solver_get_vector(hprlp_solver *h, const char *name, double *out, long cap) {
+    GUARD_BEGIN
+    VecRef v = find_vector(h->s, name ? name : "");
+    if (v.n < 0) throw std::runtime_error(std::string("unknown vector name: ") + (name ? name : "(null)"));
+    if (cap < v.n) throw std::runtime_error("output buffer too small");
+    HIP_CHECK(hipStreamSynchronize(h->s.stream));
+    if (v.n > 0) HIP_CHECK(hipMemcpy(out, v.p, sizeof(double) * v.n, hipMemcpyDeviceToHost));
+    return v.n;
+    GUARD_END(-1)
+}
+
+extern "C" int hprlp_solver_set_vector(hprlp_solver *h, const char *name, const double *in, long len) {
+    GUARD_BEGIN
+    VecRef v = find_vector(h->s, name ? name : "");
+    if (v.n < 0) throw std::runtime_error(std::string("unknown vector name: ") + (name ? name : "(null)"));
+    if (len != v.n) throw std::runtime_error("length mismatch");
+    HIP_CHECK(hipStreamSynchronize(h->s.stream));
+    if (v.n > 0) HIP_CHECK(hipMemcpy(v.p, in, sizeof(double) * v.n, hipMemcpyHostToDevice));
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" int hprlp_solver_get_scalars(hprlp_solver *h, double out[16]) {
+    GUARD_BEGIN
+    Solver &s = h->s;
+    Ctrl ck;
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    HIP_CHECK(hipMemcpy(&ck, s.ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    const double v[16] = {s.b_scale, s.c_scale, s.norm_b, s.norm_c, s.norm_b_org, s.norm_c_org, s.sigma, s.lambda_max,
+                          s.setup_time, s.scaling_time, s.power_time, static_cast<double>(s.power_iters),
+                          static_cast<double>(ck.kx), static_cast<double>(ck.ky), 0, 0};
+    for (int i = 0; i < 16; ++i) out[i] = v[i];
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" int hprlp_solver_info(hprlp_solver *h, long out[8]) {
+    GUARD_BEGIN
+    Solver &s = h->s;
+    out[0] = s.m; out[1] = s.n; out[2] = s.A.view.nnz;
+    out[3] = s.A.view.nblk; out[4] = s.AT.view.nblk;
+    out[5] = s.A.view.grid(); out[6] = s.AT.view.grid();
+    out[7] = 0;
+    return 0;
+    GUARD_END(-1)
+}
+
+extern "C" int hprlp_solver_time_iterations(hprlp_solver *h, int warmup, int steps, int mode, double *total_ms,
+                                            double *xhalf_ms, double *yhalf_ms) {
+    GUARD_BEGIN
+    Solver &s = h->s;
+    if (steps <= 0) throw std::runtime_error("steps must be positive");
+    s.run_normal(warmup);
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    double tx = 0, ty = 0;
+    float ms = 0;
+    if (mode == 0) {
+        HIP_CHECK(hipEventRecord(e0, s.stream));
+        s.run_normal(steps);
+        HIP_CHECK(hipEventRecord(e1, s.stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } else {
+        std::vector<hipEvent_t> ev(static_cast<size_t>(steps) * 3);
+        for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
+        XHalfArgs xa{s.gy.p, s.x.p, s.x_hat, s.l.p, s.u.p, s.c.p, s.last_x.p, nullptr, nullptr, nullptr, s.ctrl.p, nullptr, 0};
+        YHalfArgs ya{s.gxh.p, s.y, s.AL.p, s.AU.p, s.last_y.p, nullptr, nullptr, nullptr, s.ctrl.p, nullptr, 0};
+        HIP_CHECK(hipEventRecord(e0, s.stream));
+        for (int i = 0; i < steps; ++i) {
+            HIP_CHECK(hipEventRecord(ev[3 * i], s.stream));
+            launch_x_half(s.AT.view, xa, false, s.stream);
+            HIP_CHECK(hipEventRecord(ev[3 * i + 1], s.stream));
+            s.gather(s.gxh.p, false);
+            launch_y_half(s.A.view, ya, false, s.stream);
+            HIP_CHECK(hipEventRecord(ev[3 * i + 2], s.stream));
+            s.gather(s.gy.p, true);
+        }
+        HIP_CHECK(hipEventRecord(e1, s.stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        for (int i = 0; i < steps; ++i) {
+            float a = 0, b = 0;
+            HIP_CHECK(hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
+            HIP_CHECK(hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
+            tx += a;
+            ty += b;
+        }
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (total_ms) *total_ms = ms;
+    if (xhalf_ms) *xhalf_ms = tx;
+    if (yhalf_ms) *yhalf_ms = ty;
+    return 0;
+    GUARD_END(-1)
+}

@@ -1,0 +1,106 @@
+// common.h -- private helpers shared by the host side of the MI355X HPR-LP library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "structs.h"
+
+namespace hprlp {
+
+// Every HIP failure becomes an exception that is caught at the extern "C" boundary and turned into
+// status "ERROR" / NULL (the reference lets it escape: include/cuda_kernels/cuda_check.h:56-63).
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e_) + " at " + \
+                                     __FILE__ + ":" + std::to_string(__LINE__) + " in " #expr);  \
+        }                                                                                        \
+    } while (0)
+
+void set_last_error(const std::string &msg);
+const char *last_error_cstr();
+
+using clock_type = std::chrono::steady_clock;
+inline clock_type::time_point time_now() { return clock_type::now(); }
+inline double time_since(clock_type::time_point t0) {
+    return std::chrono::duration<double>(clock_type::now() - t0).count();
+}
+
+// Device buffer with RAII; sized in elements.
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    explicit DBuf(size_t count) { alloc(count); }
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf &operator=(DBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T)));
+    }
+    void alloc_zero(size_t count) {
+        alloc(count);
+        HIP_CHECK(hipMemset(p, 0, (count ? count : 1) * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void upload(const T *src, size_t count) {
+        if (count) HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void download(T *dst, size_t count) const {
+        if (count) HIP_CHECK(hipMemcpy(dst, p, count * sizeof(T), hipMemcpyDeviceToHost));
+    }
+    operator T *() const { return p; }
+};
+
+// Pinned host buffer.
+template <class T>
+struct HBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    HBuf() = default;
+    HBuf(const HBuf &) = delete;
+    HBuf &operator=(const HBuf &) = delete;
+    ~HBuf() { if (p) (void)hipHostFree(p); }
+    void alloc(size_t count) {
+        n = count;
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T), hipHostMallocDefault));
+        std::memset(p, 0, (count ? count : 1) * sizeof(T));
+    }
+    T &operator[](size_t i) { return p[i]; }
+};
+
+// Host-side CSR transpose, stable in row order (reference src/utils.cu:203-232).
+void csr_transpose_host(int rows, int cols, long nnz, const int *rp, const int *ci, const double *v,
+                        std::vector<int> &trp, std::vector<int> &tci, std::vector<double> &tv);
+
+// Deterministic start vector for the power iteration (spec in oracle/hpr_oracle.c; this is the
+// product's own implementation of the same counter RNG).
+void power_start_vector(int m, unsigned long long seed, long long offset, double *z);
+
+// Print cadence of the iteration log (reference src/utils.cu:100-102).
+int log_step(int iter);
+
+void free_lp_info_cpu_members(LP_info_cpu *model);
+
+}  // namespace hprlp

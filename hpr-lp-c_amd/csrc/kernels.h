@@ -1,0 +1,148 @@
+// kernels.h -- device data views and launch wrappers of the hand-written gfx950 kernels.
+// Everything here is private to the library; the C ABI is in include/*.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace hprlp {
+
+constexpr int kWave = 64;         // CDNA wavefront
+constexpr int kWavesPerBlock = 4; // 256-thread workgroups, one row block per wave
+constexpr int kThreads = kWave * kWavesPerBlock;
+constexpr int kStreamW = 512;     // max nonzeros staged through LDS by one wave (4 KiB per vector)
+constexpr int kStreamRows = 64;   // max rows per stream block: one lane per row
+constexpr int kLongRow = 256;     // rows longer than this get a whole wave (vector mode)
+constexpr int kNumScalars = 24;   // device scalar slots (see enum Slot)
+
+// Scalar slots filled by the reduction epilogues.  0-9 follow the reference's 10-slot buffer
+// (reference include/structs.h:196-206); the rest are ours.
+enum Slot : int {
+    S_CX = 0,      // c . x_bar
+    S_YOBJ_Y = 1,  // y_obj . y_bar
+    S_XZ = 2,      // x_bar . z_bar
+    S_RD2 = 3,     // |Rd|^2
+    S_RP2 = 4,     // |Rp|^2
+    S_ADX_DY = 5,  // <A x_temp, y_temp>
+    S_DY2 = 6,     // |y_temp|^2
+    S_DX2 = 7,     // |x_temp|^2
+    S_MOVE_X2 = 8, // |x_bar - last_x|^2
+    S_MOVE_Y2 = 9, // |y_bar - last_y|^2
+    S_LU2 = 10,    // iteration-0 bound violation
+    S_PW_ZZ = 11,  // power iteration z.z
+    S_PW_QZ = 12,  // power iteration q.z
+    S_PW_ERR2 = 13,
+    S_NB2 = 14,    // |conceptual b|^2
+    S_NC2 = 15,    // |c|^2
+    S_TMP0 = 16,
+    S_TMP1 = 17,
+};
+
+// Row-block descriptor: one per wave.  {first row, number of rows, first nonzero, nonzero count}.
+// rows==1 && nz>kLongRow: vector mode (lanes stride the row); otherwise stream mode (nz<=kStreamW,
+// rows<=kStreamRows): products staged in LDS in CSR order, lane t sums row t sequentially.
+struct CsrDev {
+    int rows = 0, cols = 0;
+    int nnz = 0;
+    const int *rowptr = nullptr;
+    const int *col = nullptr;
+    double *val = nullptr;
+    const int4 *blk = nullptr;
+    int nblk = 0;
+    int grid() const { return (nblk + kWavesPerBlock - 1) / kWavesPerBlock; }
+};
+
+// Device-resident iteration scalars (reference Halpern_params[4] + halpern_inner,
+// include/structs.h:153-168).  kx is read by the x-half, ky by the y-half; each half writes the
+// other's counter, so no kernel reads a word that is written during the same launch.
+struct Ctrl {
+    double sigma, lam_sigma, inv_lam_sigma, inv_sigma;
+    int kx, ky;
+    int pad0, pad1;
+};
+
+struct XHalfArgs {
+    const double *y_full;  // gather source (all rows of y)
+    double *x, *x_hat;     // local slices (x_hat points into the gathered x_hat buffer)
+    const double *l, *u, *c, *last_x;
+    double *x_bar, *z_bar, *x_temp;  // check variant only
+    Ctrl *ctrl;
+    double *partials;  // check variant: 3 x stride
+    int stride;
+};
+
+struct YHalfArgs {
+    const double *xhat_full;
+    double *y;  // local slice inside the gathered y buffer
+    const double *AL, *AU, *last_y;
+    double *y_bar, *y_obj, *y_temp;
+    Ctrl *ctrl;
+    double *partials;  // check variant: 2 x stride
+    int stride;
+};
+
+struct FinalizeItem {
+    const double *partials;
+    int count;
+    int slot;
+};
+struct FinalizeArgs {
+    FinalizeItem item[8];
+    int n;
+};
+
+void launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s);
+void launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s);
+
+// |(c - AT y_bar - z_bar) .* col_norm|^2 partials (reference residual_compute_Rd, main_iterate.cu:217-226)
+void launch_resid_d(const CsrDev &AT, const double *ybar_full, const double *c, const double *z_bar,
+                    const double *col_norm, double *partials, hipStream_t s);
+// |max(min(AU - A x_bar,0), AL - A x_bar) .* row_norm|^2 partials, optionally <A x_temp, y_temp> in the same pass
+void launch_resid_p(const CsrDev &A, const double *xbar_full, const double *xtemp_full, const double *AL,
+                    const double *AU, const double *row_norm, const double *y_temp, bool with_gap,
+                    double *partials, int stride, hipStream_t s);
+// <A x_temp, y_temp> partials only (reference compute_weighted_norm, main_iterate.cu:486-515)
+void launch_gap(const CsrDev &A, const double *xtemp_full, const double *y_temp, double *partials, hipStream_t s);
+// out = M v ; optionally partials of out.out and out.q  (power iteration)
+void launch_spmv_plain(const CsrDev &M, const double *v_full, double *out, const double *q, bool with_dots,
+                       double *partials, int stride, hipStream_t s);
+
+void launch_finalize(const FinalizeArgs &f, double *scalars, hipStream_t s);
+
+// x_temp = x_bar - last_x, y_temp = y_bar - last_y, squared norms -> partials (2 x stride);
+// then last_x = x = x_bar, last_y = y = y_bar and the Halpern counter is reset
+// (reference update_sigma movement + do_restart, main_iterate.cu:312-322,369-375)
+void launch_movement(int n, int m, const double *x_bar, const double *last_x, double *x_temp, const double *y_bar,
+                     const double *last_y, double *y_temp, double *partials, int stride, int nblocks, hipStream_t s);
+void launch_restart_copy(int n, int m, const double *x_bar, double *x, double *last_x, const double *y_bar,
+                         double *y, double *last_y, Ctrl *ctrl, hipStream_t s);
+// iteration-0 bound violation (reference residual_compute_lu_kernel)
+void launch_lu(int n, const double *x_bar, const double *l, const double *u, const double *col_norm, double *x_temp,
+               double *partials, int nblocks, hipStream_t s);
+void launch_set_ctrl(Ctrl *ctrl, double sigma, double lambda_max, int reset_k, hipStream_t s);
+
+// scaling (reference src/scaling.cu)
+void launch_cr_log_update(const CsrDev &M, const double *other_full, double *result, hipStream_t s);
+void launch_exp_clamp(double *v, int n, hipStream_t s);
+void launch_row_norm(const CsrDev &M, double *result, int norm, hipStream_t s);
+// val = op(op(val, first), second) where first/second are the row vector or the gathered column vector
+void launch_scale_matrix(const CsrDev &M, const double *rowvec, const double *colvec_full, bool row_first,
+                         bool divide, hipStream_t s);
+void launch_vec_scale(double *x, const double *s, int n, bool divide, hipStream_t s_);
+void launch_vec_scal(double *x, double a, int n, hipStream_t s);
+void launch_fill(double *x, double a, int n, hipStream_t s);
+void launch_bnorm2(const double *AL, const double *AU, int m, double *partials, int nblocks, hipStream_t s);
+void launch_norm2(const double *x, int n, double *partials, int nblocks, hipStream_t s);
+
+// power iteration helpers
+void launch_pw_normalize(const double *z, double *q, int m, const double *scalars, hipStream_t s);
+void launch_pw_err(const double *z, const double *q, int m, const double *scalars, double *partials, int nblocks,
+                   hipStream_t s);
+
+// x = b_scale * x_bar / col_norm etc. (reference collect_solution, utils.cu:143-200)
+void launch_unscale(int n, int m, const double *x_bar, const double *y_bar, const double *z_bar,
+                    const double *col_norm, const double *row_norm, double b_scale, double c_scale, double *xo,
+                    double *yo, double *zo, hipStream_t s);
+
+constexpr int kReduceBlocks = 512;  // grid of the plain vector reductions
+
+}  // namespace hprlp

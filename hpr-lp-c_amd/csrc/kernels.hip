@@ -1,0 +1,713 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the HPR-LP iteration.
+//
+// The hot kernel is k_spmv_fused<Epi>: a CSR row-block SpMV whose epilogue is the whole half-step
+// (projection, reflection, Halpern averaging) or a residual/dot reduction, so one HPR half-step is
+// one launch.  Each wave owns one row block:
+//   stream mode  (<= 64 rows, <= 512 nonzeros): the wave streams val/col coalesced (lane = nonzero),
+//                gathers the vector, stages the products in LDS in CSR order, then lane t sums row t
+//                sequentially -- the same summation order as a sequential CPU row dot, which makes
+//                the result bit-identical to the oracle for these rows;
+//   vector mode  (one row, > 256 nonzeros): lanes stride the row, __shfl_xor tree reduction.
+// Compiled with -ffp-contract=off: products and sums round separately (see oracle/hpr_oracle.c).
+//
+// Reference formulas: src/cuda_kernels/HPR_cuda_kernels.cu:203-295 (updates), :160-189 (residuals),
+// :91-157 (scaling), src/scaling.cu:5-38, src/power_iteration.cu:60-100.
+#include "kernels.h"
+
+#include <cmath>
+
+namespace hprlp {
+
+// ------------------------------------------------------------------------------------------------
+// wave / block reductions (fixed order => deterministic)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Sum NACC per-thread accumulators over the block; thread 0 stores partials[i*stride + blockIdx.x].
+template <int NACC>
+__device__ __forceinline__ void block_store_partials(double (&acc)[NACC], double *partials, int stride) {
+    __shared__ double red[kWavesPerBlock][NACC > 0 ? NACC : 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            double v = red[0][i];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) v += red[w][i];
+            partials[(size_t)i * stride + blockIdx.x] = v;
+        }
+    }
+}
+
+// Order LDS traffic between lanes of one wave (no s_barrier needed: one wave's DS ops are in order).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused CSR kernel
+// ------------------------------------------------------------------------------------------------
+template <class Epi>
+__global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
+    constexpr int NV = Epi::NV;
+    constexpr int NACC = Epi::NACC;
+    __shared__ double lds[kWavesPerBlock][NV][kStreamW];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * kWavesPerBlock + wave;
+    double acc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) acc[i] = 0.0;
+
+    epi.begin();
+
+    if (b < A.nblk) {
+        const int4 d = A.blk[b];
+        const int r0 = d.x, nr = d.y, k0 = d.z, nz = d.w;
+        const int *__restrict__ col = A.col + k0;
+        const double *__restrict__ val = A.val + k0;
+
+        if (nr == 1 && nz > kLongRow) {
+            // ---- vector mode: one long row per wave
+            double s[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[v] = 0.0;
+            int j = lane;
+            for (; j + 3 * kWave < nz; j += 4 * kWave) {
+                double a0 = val[j], a1 = val[j + kWave], a2 = val[j + 2 * kWave], a3 = val[j + 3 * kWave];
+                int c0 = col[j], c1 = col[j + kWave], c2 = col[j + 2 * kWave], c3 = col[j + 3 * kWave];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const double *__restrict__ g = epi.gv[v];
+                    double g0 = g[c0], g1 = g[c1], g2 = g[c2], g3 = g[c3];
+                    s[v] += a0 * g0;
+                    s[v] += a1 * g1;
+                    s[v] += a2 * g2;
+                    s[v] += a3 * g3;
+                }
+            }
+            for (; j < nz; j += kWave) {
+                double a0 = val[j];
+                int c0 = col[j];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s[v] += a0 * epi.gv[v][c0];
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[v] = wave_sum(s[v]);
+            if (lane == 0) {
+                typename Epi::Row rw = epi.load_row(r0);
+                epi.apply(r0, rw, s, acc);
+            }
+        } else {
+            // ---- stream mode
+            typename Epi::Row rw;
+            int rs = 0, re = 0;
+            if (lane < nr) {
+                rw = epi.load_row(r0 + lane);
+                rs = A.rowptr[r0 + lane] - k0;
+                re = A.rowptr[r0 + lane + 1] - k0;
+            }
+            if (nz > 0) {
+                const int last = nz - 1;
+                for (int base = 0; base < nz; base += 4 * kWave) {
+                    // unconditional (clamped) loads keep four independent load chains in flight
+                    const int j0 = base + lane, j1 = j0 + kWave, j2 = j0 + 2 * kWave, j3 = j0 + 3 * kWave;
+                    const int q0 = min(j0, last), q1 = min(j1, last), q2 = min(j2, last), q3 = min(j3, last);
+                    double a0 = val[q0], a1 = val[q1], a2 = val[q2], a3 = val[q3];
+                    int c0 = col[q0], c1 = col[q1], c2 = col[q2], c3 = col[q3];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const double *__restrict__ g = epi.gv[v];
+                        double g0 = g[c0], g1 = g[c1], g2 = g[c2], g3 = g[c3];
+                        // j3 < base + 256 <= kStreamW whenever base < nz <= kStreamW: in-bounds stores
+                        lds[wave][v][j0] = a0 * g0;
+                        lds[wave][v][j1] = a1 * g1;
+                        lds[wave][v][j2] = a2 * g2;
+                        lds[wave][v][j3] = a3 * g3;
+                    }
+                }
+            }
+            wave_lds_sync();
+            if (lane < nr) {
+                double s[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s[v] = 0.0;
+                for (int j = rs; j < re; ++j) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) s[v] += lds[wave][v][j];
+                }
+                epi.apply(r0 + lane, rw, s, acc);
+            }
+        }
+    }
+    if constexpr (NACC > 0) block_store_partials<NACC>(acc, epi.partials, epi.stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogues
+// ------------------------------------------------------------------------------------------------
+
+// x-half (reference update_zx_{normal,check}_kernel, HPR_cuda_kernels.cu:203-247)
+template <bool CHECK>
+struct XEpi {
+    static constexpr int NV = 1;
+    static constexpr int NACC = CHECK ? 3 : 0;
+    const double *gv[1];
+    double *x, *x_hat;
+    const double *l, *u, *c, *last_x;
+    double *x_bar, *z_bar, *x_temp;
+    Ctrl *ctrl;
+    double *partials;
+    int stride;
+    // filled by begin()
+    double sigma, f1, f2;
+    struct Row {
+        double xi, ci, li, ui, lx;
+    };
+    __device__ __forceinline__ void begin() {
+        const int k = ctrl->kx;
+        sigma = ctrl->sigma;
+        f1 = 1.0 / (static_cast<double>(k) + 2.0);
+        f2 = 1.0 - f1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->ky = k;
+    }
+    __device__ __forceinline__ Row load_row(int r) const { return Row{x[r], c[r], l[r], u[r], last_x[r]}; }
+    __device__ __forceinline__ void apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 3 : 1]) const {
+        const double gc = s[0] - w.ci;
+        const double zt = w.xi + sigma * gc;
+        const double xb = fmin(w.ui, fmax(w.li, zt));
+        const double xh = 2.0 * xb - w.xi;
+        const double xn = f2 * xh + f1 * w.lx;
+        x_hat[r] = xh;
+        x[r] = xn;
+        if constexpr (CHECK) {
+            const double zb = (xb - zt) / sigma;
+            const double dx = xb - xh;
+            z_bar[r] = zb;
+            x_bar[r] = xb;
+            x_temp[r] = dx;
+            acc[0] += w.ci * xb;
+            acc[1] += xb * zb;
+            acc[2] += dx * dx;
+        }
+    }
+};
+
+// y-half (reference update_y_{normal,check}_kernel, HPR_cuda_kernels.cu:249-295) + the Halpern
+// counter advance (advance_halpern_factors_kernel, :192-200) folded in as the kx hand-off.
+template <bool CHECK>
+struct YEpi {
+    static constexpr int NV = 1;
+    static constexpr int NACC = CHECK ? 2 : 0;
+    const double *gv[1];
+    double *y;
+    const double *AL, *AU, *last_y;
+    double *y_bar, *y_obj, *y_temp;
+    Ctrl *ctrl;
+    double *partials;
+    int stride;
+    double fact1, fact2, hf1, hf2;
+    struct Row {
+        double yi, lo, hi, ly;
+    };
+    __device__ __forceinline__ void begin() {
+        const int k = ctrl->ky;
+        fact1 = ctrl->lam_sigma;
+        fact2 = ctrl->inv_lam_sigma;
+        hf1 = 1.0 / (static_cast<double>(k) + 2.0);
+        hf2 = 1.0 - hf1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->kx = k + 1;
+    }
+    __device__ __forceinline__ Row load_row(int r) const { return Row{y[r], AL[r], AU[r], last_y[r]}; }
+    __device__ __forceinline__ void apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 2 : 1]) const {
+        const double v = s[0] - fact1 * w.yi;
+        const double d = fmax(w.lo - v, fmin(w.hi - v, 0.0));
+        const double yb = fact2 * d;
+        const double yh = 2.0 * yb - w.yi;
+        const double yn = hf2 * yh + hf1 * w.ly;
+        y[r] = yn;
+        if constexpr (CHECK) {
+            const double dy = yb - yh;
+            const double yo = v + d;
+            y_temp[r] = dy;
+            y_bar[r] = yb;
+            y_obj[r] = yo;
+            acc[0] += yo * yb;
+            acc[1] += dy * dy;
+        }
+    }
+};
+
+// dual residual (reference residual_compute_Rd_kernel, HPR_cuda_kernels.cu:183-189)
+struct RdEpi {
+    static constexpr int NV = 1;
+    static constexpr int NACC = 1;
+    const double *gv[1];
+    const double *c, *z_bar, *col_norm;
+    double *partials;
+    int stride;
+    struct Row {
+        double ci, zi, cn;
+    };
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Row load_row(int r) const { return Row{c[r], z_bar[r], col_norm[r]}; }
+    __device__ __forceinline__ void apply(int, const Row &w, const double (&s)[1], double (&acc)[1]) const {
+        const double rd = (w.ci - s[0] - w.zi) * w.cn;
+        acc[0] += rd * rd;
+    }
+};
+
+// primal residual (reference residual_compute_Rp_kernel, :160-172) and, when GAP, <A x_temp, y_temp>
+// from the same pass over A (the reference runs a second SpMV, main_iterate.cu:245-253)
+template <bool GAP>
+struct RpEpi {
+    static constexpr int NV = GAP ? 2 : 1;
+    static constexpr int NACC = GAP ? 2 : 1;
+    const double *gv[GAP ? 2 : 1];
+    const double *AL, *AU, *row_norm, *y_temp;
+    double *partials;
+    int stride;
+    struct Row {
+        double lo, hi, rn, dy;
+    };
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Row load_row(int r) const {
+        return Row{AL[r], AU[r], row_norm[r], GAP ? y_temp[r] : 0.0};
+    }
+    __device__ __forceinline__ void apply(int, const Row &w, const double (&s)[GAP ? 2 : 1],
+                                          double (&acc)[GAP ? 2 : 1]) const {
+        const double v = s[0];
+        const double rp = fmax(fmin(w.hi - v, 0.0), w.lo - v) * w.rn;
+        acc[0] += rp * rp;
+        if constexpr (GAP) acc[1] += s[1] * w.dy;
+    }
+};
+
+struct GapEpi {
+    static constexpr int NV = 1;
+    static constexpr int NACC = 1;
+    const double *gv[1];
+    const double *y_temp;
+    double *partials;
+    int stride;
+    struct Row {
+        double dy;
+    };
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Row load_row(int r) const { return Row{y_temp[r]}; }
+    __device__ __forceinline__ void apply(int, const Row &w, const double (&s)[1], double (&acc)[1]) const {
+        acc[0] += s[0] * w.dy;
+    }
+};
+
+// plain product, optionally with out.out and out.q (power iteration, power_iteration.cu:73-93)
+template <bool DOTS>
+struct PlainEpi {
+    static constexpr int NV = 1;
+    static constexpr int NACC = DOTS ? 2 : 0;
+    const double *gv[1];
+    double *out;
+    const double *q;
+    double *partials;
+    int stride;
+    struct Row {
+        double qi;
+    };
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Row load_row(int r) const { return Row{DOTS ? q[r] : 0.0}; }
+    __device__ __forceinline__ void apply(int r, const Row &w, const double (&s)[1], double (&acc)[DOTS ? 2 : 1]) const {
+        out[r] = s[0];
+        if constexpr (DOTS) {
+            acc[0] += s[0] * s[0];
+            acc[1] += s[0] * w.qi;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers of the fused kernel
+// ------------------------------------------------------------------------------------------------
+template <class Epi>
+static void launch_fused(const CsrDev &M, const Epi &e, hipStream_t s) {
+    if (M.nblk <= 0) return;
+    hipLaunchKernelGGL(k_spmv_fused<Epi>, dim3(M.grid()), dim3(kThreads), 0, s, M, e);
+}
+
+void launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s) {
+    if (check) {
+        XEpi<true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, a.x_bar, a.z_bar, a.x_temp, a.ctrl, a.partials, a.stride, 0, 0, 0};
+        launch_fused(AT, e, s);
+    } else {
+        XEpi<false> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0};
+        launch_fused(AT, e, s);
+    }
+}
+
+void launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s) {
+    if (check) {
+        YEpi<true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, a.y_bar, a.y_obj, a.y_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, 0};
+        launch_fused(A, e, s);
+    } else {
+        YEpi<false> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0};
+        launch_fused(A, e, s);
+    }
+}
+
+void launch_resid_d(const CsrDev &AT, const double *ybar_full, const double *c, const double *z_bar,
+                    const double *col_norm, double *partials, hipStream_t s) {
+    RdEpi e{{ybar_full}, c, z_bar, col_norm, partials, AT.grid()};
+    launch_fused(AT, e, s);
+}
+
+void launch_resid_p(const CsrDev &A, const double *xbar_full, const double *xtemp_full, const double *AL,
+                    const double *AU, const double *row_norm, const double *y_temp, bool with_gap,
+                    double *partials, int stride, hipStream_t s) {
+    if (with_gap) {
+        RpEpi<true> e{{xbar_full, xtemp_full}, AL, AU, row_norm, y_temp, partials, stride};
+        launch_fused(A, e, s);
+    } else {
+        RpEpi<false> e{{xbar_full}, AL, AU, row_norm, nullptr, partials, stride};
+        launch_fused(A, e, s);
+    }
+}
+
+void launch_gap(const CsrDev &A, const double *xtemp_full, const double *y_temp, double *partials, hipStream_t s) {
+    GapEpi e{{xtemp_full}, y_temp, partials, A.grid()};
+    launch_fused(A, e, s);
+}
+
+void launch_spmv_plain(const CsrDev &M, const double *v_full, double *out, const double *q, bool with_dots,
+                       double *partials, int stride, hipStream_t s) {
+    if (with_dots) {
+        PlainEpi<true> e{{v_full}, out, q, partials, stride};
+        launch_fused(M, e, s);
+    } else {
+        PlainEpi<false> e{{v_full}, out, nullptr, nullptr, 0};
+        launch_fused(M, e, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar finalisation: out[slot] = sum of a partial array, one block per item, fixed order
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_finalize(FinalizeArgs f, double *scalars) {
+    const FinalizeItem it = f.item[blockIdx.x];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < it.count; i += kThreads) v += it.partials[i];
+    __shared__ double red[kWavesPerBlock];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) scalars[it.slot] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+void launch_finalize(const FinalizeArgs &f, double *scalars, hipStream_t s) {
+    if (f.n <= 0) return;
+    hipLaunchKernelGGL(k_finalize, dim3(f.n), dim3(kThreads), 0, s, f, scalars);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plain vector kernels (grid-stride, fixed grids so partial counts are static)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_movement(int n, int m, const double *x_bar, const double *last_x,
+                                                      double *x_temp, const double *y_bar, const double *last_y,
+                                                      double *y_temp, double *partials, int stride) {
+    double acc[2] = {0.0, 0.0};
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < n; i += nth) {
+        const double d = 1.0 * x_bar[i] + (-1.0) * last_x[i];
+        x_temp[i] = d;
+        acc[0] += d * d;
+    }
+    for (int i = tid; i < m; i += nth) {
+        const double d = 1.0 * y_bar[i] + (-1.0) * last_y[i];
+        y_temp[i] = d;
+        acc[1] += d * d;
+    }
+    block_store_partials<2>(acc, partials, stride);
+}
+
+void launch_movement(int n, int m, const double *x_bar, const double *last_x, double *x_temp, const double *y_bar,
+                     const double *last_y, double *y_temp, double *partials, int stride, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_movement, dim3(nblocks), dim3(kThreads), 0, s, n, m, x_bar, last_x, x_temp, y_bar, last_y,
+                       y_temp, partials, stride);
+}
+
+__global__ void __launch_bounds__(kThreads) k_restart_copy(int n, int m, const double *x_bar, double *x, double *last_x,
+                                                          const double *y_bar, double *y, double *last_y, Ctrl *ctrl) {
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < n; i += nth) {
+        const double v = x_bar[i];
+        x[i] = v;
+        last_x[i] = v;
+    }
+    for (int i = tid; i < m; i += nth) {
+        const double v = y_bar[i];
+        y[i] = v;
+        last_y[i] = v;
+    }
+    if (tid == 0) {
+        ctrl->kx = 0;
+        ctrl->ky = 0;
+    }
+}
+
+static int vec_grid(long n) {
+    long g = (n + kThreads - 1) / kThreads;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return static_cast<int>(g);
+}
+
+void launch_restart_copy(int n, int m, const double *x_bar, double *x, double *last_x, const double *y_bar,
+                         double *y, double *last_y, Ctrl *ctrl, hipStream_t s) {
+    hipLaunchKernelGGL(k_restart_copy, dim3(vec_grid(n > m ? n : m)), dim3(kThreads), 0, s, n, m, x_bar, x, last_x,
+                       y_bar, y, last_y, ctrl);
+}
+
+__global__ void __launch_bounds__(kThreads) k_lu(int n, const double *x_bar, const double *l, const double *u,
+                                                const double *col_norm, double *x_temp, double *partials) {
+    double acc[1] = {0.0};
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < n; i += nth) {
+        const double xb = x_bar[i], li = l[i], ui = u[i];
+        const double t = (xb < li) ? (li - xb) : ((xb > ui) ? (xb - ui) : 0.0);
+        const double r = t / col_norm[i];
+        x_temp[i] = r;
+        acc[0] += r * r;
+    }
+    block_store_partials<1>(acc, partials, gridDim.x);
+}
+
+void launch_lu(int n, const double *x_bar, const double *l, const double *u, const double *col_norm, double *x_temp,
+               double *partials, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_lu, dim3(nblocks), dim3(kThreads), 0, s, n, x_bar, l, u, col_norm, x_temp, partials);
+}
+
+__global__ void k_set_ctrl(Ctrl *ctrl, double sigma, double lambda_max, int reset_k) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double f = lambda_max * sigma;
+        ctrl->sigma = sigma;
+        ctrl->lam_sigma = f;
+        ctrl->inv_lam_sigma = 1.0 / f;
+        ctrl->inv_sigma = 1.0 / sigma;
+        if (reset_k) {
+            ctrl->kx = 0;
+            ctrl->ky = 0;
+        }
+    }
+}
+
+void launch_set_ctrl(Ctrl *ctrl, double sigma, double lambda_max, int reset_k, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_ctrl, dim3(1), dim3(64), 0, s, ctrl, sigma, lambda_max, reset_k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scaling kernels (reference src/scaling.cu:5-38, HPR_cuda_kernels.cu:34-43,91-157)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_cr_log_update(int rows, const int *rowptr, const int *col,
+                                                           const double *val, const double *other, double *result) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const int s = rowptr[r], e = rowptr[r + 1];
+    if (e - s <= 0) {
+        result[r] = 0.0;
+        return;
+    }
+    double sum = 0.0;
+    for (int k = s; k < e; ++k) {
+        const double a = fmax(fabs(val[k]), 1e-300);
+        sum += -log(a) - other[col[k]];
+    }
+    result[r] = sum / static_cast<double>(e - s);
+}
+
+void launch_cr_log_update(const CsrDev &M, const double *other_full, double *result, hipStream_t s) {
+    if (M.rows <= 0) return;
+    hipLaunchKernelGGL(k_cr_log_update, dim3((M.rows + kThreads - 1) / kThreads), dim3(kThreads), 0, s, M.rows,
+                       M.rowptr, M.col, M.val, other_full, result);
+}
+
+__global__ void __launch_bounds__(kThreads) k_exp_clamp(double *v, int n) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) v[i] = fmin(fmax(exp(v[i]), 1e-30), 1e30);
+}
+
+void launch_exp_clamp(double *v, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_exp_clamp, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, v, n);
+}
+
+__global__ void __launch_bounds__(kThreads) k_row_norm(int rows, const int *rowptr, const double *val, double *result,
+                                                      int norm) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    double acc = 0.0;
+    if (norm == 99) {
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const double a = fabs(val[k]);
+            if (acc < a) acc = a;
+        }
+    } else {
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) acc += fabs(val[k]);
+    }
+    acc = sqrt(acc);
+    if (acc < 1e-15) acc = 1.0;
+    result[r] = acc;
+}
+
+void launch_row_norm(const CsrDev &M, double *result, int norm, hipStream_t s) {
+    if (M.rows <= 0) return;
+    hipLaunchKernelGGL(k_row_norm, dim3((M.rows + kThreads - 1) / kThreads), dim3(kThreads), 0, s, M.rows, M.rowptr,
+                       M.val, result, norm);
+}
+
+template <bool ROW_FIRST, bool DIVIDE>
+__global__ void __launch_bounds__(kThreads) k_scale_matrix(int rows, const int *rowptr, const int *col, double *val,
+                                                          const double *rowvec, const double *colvec) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const double rv = rowvec[r];
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const double cv = colvec[col[k]];
+        double v = val[k];
+        if (ROW_FIRST) {
+            v = DIVIDE ? v / rv : v * rv;
+            v = DIVIDE ? v / cv : v * cv;
+        } else {
+            v = DIVIDE ? v / cv : v * cv;
+            v = DIVIDE ? v / rv : v * rv;
+        }
+        val[k] = v;
+    }
+}
+
+void launch_scale_matrix(const CsrDev &M, const double *rowvec, const double *colvec_full, bool row_first,
+                         bool divide, hipStream_t s) {
+    if (M.rows <= 0) return;
+    const dim3 g((M.rows + kThreads - 1) / kThreads), b(kThreads);
+    if (row_first && divide)
+        hipLaunchKernelGGL((k_scale_matrix<true, true>), g, b, 0, s, M.rows, M.rowptr, M.col, M.val, rowvec, colvec_full);
+    else if (row_first && !divide)
+        hipLaunchKernelGGL((k_scale_matrix<true, false>), g, b, 0, s, M.rows, M.rowptr, M.col, M.val, rowvec, colvec_full);
+    else if (!row_first && divide)
+        hipLaunchKernelGGL((k_scale_matrix<false, true>), g, b, 0, s, M.rows, M.rowptr, M.col, M.val, rowvec, colvec_full);
+    else
+        hipLaunchKernelGGL((k_scale_matrix<false, false>), g, b, 0, s, M.rows, M.rowptr, M.col, M.val, rowvec, colvec_full);
+}
+
+__global__ void __launch_bounds__(kThreads) k_vec_scale(double *x, const double *s, int n, int divide) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) x[i] = divide ? x[i] / s[i] : x[i] * s[i];
+}
+void launch_vec_scale(double *x, const double *sv, int n, bool divide, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_vec_scale, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, x, sv, n, divide ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(kThreads) k_vec_scal(double *x, double a, int n) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) x[i] = x[i] * a;
+}
+void launch_vec_scal(double *x, double a, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_vec_scal, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, x, a, n);
+}
+
+__global__ void __launch_bounds__(kThreads) k_fill(double *x, double a, int n) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) x[i] = a;
+}
+void launch_fill(double *x, double a, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fill, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, x, a, n);
+}
+
+__global__ void __launch_bounds__(kThreads) k_bnorm2(const double *AL, const double *AU, int m, double *partials) {
+    double acc[1] = {0.0};
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < m; i += nth) {
+        double a = AL[i], b = AU[i];
+        a = isinf(a) ? 0.0 : a;
+        b = isinf(b) ? 0.0 : b;
+        const double v = fmax(fabs(a), fabs(b));
+        acc[0] += v * v;
+    }
+    block_store_partials<1>(acc, partials, gridDim.x);
+}
+void launch_bnorm2(const double *AL, const double *AU, int m, double *partials, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_bnorm2, dim3(nblocks), dim3(kThreads), 0, s, AL, AU, m, partials);
+}
+
+__global__ void __launch_bounds__(kThreads) k_norm2(const double *x, int n, double *partials) {
+    double acc[1] = {0.0};
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < n; i += nth) acc[0] += x[i] * x[i];
+    block_store_partials<1>(acc, partials, gridDim.x);
+}
+void launch_norm2(const double *x, int n, double *partials, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_norm2, dim3(nblocks), dim3(kThreads), 0, s, x, n, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// power iteration helpers (reference src/power_iteration.cu:60-100)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_pw_normalize(const double *z, double *q, int m, const double *scalars) {
+    const double invn = 1.0 / sqrt(scalars[S_PW_ZZ] + 2.220446049250313e-16);
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < m; i += nth) q[i] = invn * z[i];
+}
+void launch_pw_normalize(const double *z, double *q, int m, const double *scalars, hipStream_t s) {
+    hipLaunchKernelGGL(k_pw_normalize, dim3(vec_grid(m)), dim3(kThreads), 0, s, z, q, m, scalars);
+}
+
+__global__ void __launch_bounds__(kThreads) k_pw_err(const double *z, const double *q, int m, const double *scalars,
+                                                    double *partials) {
+    const double lambda = scalars[S_PW_QZ];
+    double acc[1] = {0.0};
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < m; i += nth) {
+        const double d = -lambda * q[i] + 1.0 * z[i];
+        acc[0] += d * d;
+    }
+    block_store_partials<1>(acc, partials, gridDim.x);
+}
+void launch_pw_err(const double *z, const double *q, int m, const double *scalars, double *partials, int nblocks,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_pw_err, dim3(nblocks), dim3(kThreads), 0, s, z, q, m, scalars, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// unscale (reference collect_solution, src/utils.cu:172-189)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_unscale(int n, int m, const double *x_bar, const double *y_bar,
+                                                     const double *z_bar, const double *col_norm,
+                                                     const double *row_norm, double b_scale, double c_scale, double *xo,
+                                                     double *yo, double *zo) {
+    const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;
+    for (int i = tid; i < n; i += nth) {
+        xo[i] = (x_bar[i] / col_norm[i]) * b_scale;
+        zo[i] = (z_bar[i] * col_norm[i]) * c_scale;
+    }
+    for (int i = tid; i < m; i += nth) yo[i] = (y_bar[i] / row_norm[i]) * c_scale;
+}
+void launch_unscale(int n, int m, const double *x_bar, const double *y_bar, const double *z_bar,
+                    const double *col_norm, const double *row_norm, double b_scale, double c_scale, double *xo,
+                    double *yo, double *zo, hipStream_t s) {
+    hipLaunchKernelGGL(k_unscale, dim3(vec_grid(n > m ? n : m)), dim3(kThreads), 0, s, n, m, x_bar, y_bar, z_bar,
+                       col_norm, row_norm, b_scale, c_scale, xo, yo, zo);
+}
+
+}  // namespace hprlp

@@ -1,0 +1,647 @@
+// solver.cpp -- device-resident HPR-LP solve on one GPU or one rank of a row-partitioned job.
+//
+// Host orchestration only: every vector operation is a kernel from kernels.hip on `stream`; the host
+// synchronises exactly where the reference does (one scalar fetch per residual evaluation / sigma
+// update, reference src/utils.cu:65-69).  Normal iterations between two residual evaluations are
+// replayed from captured hipGraphs of 2 launches per iteration.
+#include "solver.h"
+
+#include <algorithm>
+#include <cmath>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+
+#include "dist.h"
+
+namespace hprlp {
+
+constexpr int kMaxGraphIters = 64;
+
+// ------------------------------------------------------------------------------------------------
+std::vector<int4> build_row_blocks(int rows, const int *rowptr) {
+    std::vector<int4> blk;
+    blk.reserve(static_cast<size_t>(rows) / 8 + 16);
+    int r = 0;
+    while (r < rows) {
+        const int len = rowptr[r + 1] - rowptr[r];
+        if (len > kLongRow) {
+            blk.push_back(make_int4(r, 1, rowptr[r], len));
+            ++r;
+            continue;
+        }
+        const int start = r;
+        int nz = 0;
+        while (r < rows && r - start < kStreamRows) {
+            const int l2 = rowptr[r + 1] - rowptr[r];
+            if (l2 > kLongRow || nz + l2 > kStreamW) break;
+            nz += l2;
+            ++r;
+        }
+        blk.push_back(make_int4(start, r - start, rowptr[start], nz));
+    }
+    return blk;
+}
+
+void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, const double *v) {
+    const int nnz = rp[rows];
+    // the kernels index without bounds checks: refuse anything that could fault on the device
+    for (int i = 0; i < rows; ++i)
+        if (rp[i + 1] < rp[i]) throw std::runtime_error("row pointer array is not monotone");
+    for (int k = 0; k < nnz; ++k)
+        if (ci[k] < 0 || ci[k] >= cols) throw std::runtime_error("column index out of range");
+    rowptr.alloc(static_cast<size_t>(rows) + 1);
+    rowptr.upload(rp, static_cast<size_t>(rows) + 1);
+    col.alloc(nnz);
+    col.upload(ci, nnz);
+    val.alloc(nnz);
+    val.upload(v, nnz);
+    std::vector<int4> b = build_row_blocks(rows, rp);
+    for (const int4 &d : b) {
+        const bool vec = (d.y == 1 && d.w > kLongRow);
+        if (!vec && (d.w > kStreamW || d.y > kStreamRows || d.y < 1)) throw std::runtime_error("bad row block");
+    }
+    blk.alloc(b.size());
+    blk.upload(b.data(), b.size());
+    view.rows = rows;
+    view.cols = cols;
+    view.nnz = nnz;
+    view.rowptr = rowptr.p;
+    view.col = col.p;
+    view.val = val.p;
+    view.blk = blk.p;
+    view.nblk = static_cast<int>(b.size());
+}
+
+// ------------------------------------------------------------------------------------------------
+Solver::~Solver() {
+    for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Solver::alloc_work() {
+    x.alloc_zero(n_loc); last_x.alloc_zero(n_loc); z_bar.alloc_zero(n_loc);
+    last_y.alloc_zero(m_loc); y_obj.alloc_zero(m_loc); y_temp.alloc_zero(m_loc);
+    gy.alloc_zero(m_pad); gyb.alloc_zero(m_pad); gsm.alloc_zero(m_pad);
+    gxh.alloc_zero(n_pad); gxb.alloc_zero(n_pad); gxt.alloc_zero(n_pad); gsn.alloc_zero(n_pad);
+    y = gy.p + row_off; y_bar = gyb.p + row_off;
+    x_hat = gxh.p + col_off; x_bar = gxb.p + col_off; x_temp = gxt.p + col_off;
+    sm1.alloc_zero(m_loc); sn1.alloc_zero(n_loc);
+    row_norm.alloc(m_loc); col_norm.alloc(n_loc);
+    ctrl.alloc_zero(1);
+    scal.alloc_zero(kNumScalars);
+    scal_h.alloc(kNumScalars);
+    stride_x = std::max(AT.view.grid(), 1);
+    stride_y = std::max(A.view.grid(), 1);
+    part_x.alloc_zero(static_cast<size_t>(3) * stride_x);
+    part_y.alloc_zero(static_cast<size_t>(2) * stride_y);
+    part_r.alloc_zero(static_cast<size_t>(2) * std::max(stride_x, stride_y));
+    part_v.alloc_zero(static_cast<size_t>(2) * kReduceBlocks);
+    const char *ng = std::getenv("HPRLP_NO_GRAPH");
+    use_graph = !(ng && ng[0] == '1') && comm == nullptr;
+}
+
+void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
+    const auto t0 = time_now();
+    prm = *param;
+    HIP_CHECK(hipSetDevice(prm.device_number));
+    HIP_CHECK(hipStreamCreate(&stream));
+    m = m_loc = model->m;
+    n = n_loc = model->n;
+    m_pad = m; n_pad = n;
+    row_off = col_off = 0;
+    obj_constant = model->obj_constant;
+    const sparseMatrix *As = model->A;
+    if (!As || As->row != m || As->col != n) throw std::runtime_error("model matrix dimensions inconsistent");
+    const long nnz = As->numElements;
+    A.upload(m, n, As->rowPtr, As->colIndex, As->value);
+    {   // explicit A^T built on the host, stable in row order (reference src/preprocess.cu:78-82)
+        std::vector<int> trp, tci;
+        std::vector<double> tv;
+        csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
+        AT.upload(n, m, trp.data(), tci.data(), tv.data());
+    }
+    AL.alloc(m); AL.upload(model->AL, m);
+    AU.alloc(m); AU.upload(model->AU, m);
+    l.alloc(n); l.upload(model->l, n);
+    u.alloc(n); u.upload(model->u, n);
+    c.alloc(n); c.upload(model->c, n);
+    alloc_work();
+    HIP_CHECK(hipDeviceSynchronize());
+    setup_time = time_since(t0);
+}
+
+void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int col_off_, int n_loc_, const int *Arp,
+                         const int *Aci, const double *Av, const int *ATrp, const int *ATci, const double *ATv,
+                         const double *AL_, const double *AU_, const double *l_, const double *u_, const double *c_,
+                         double obj_constant_, const HPRLP_parameters *param, Comm *comm_) {
+    const auto t0 = time_now();
+    prm = *param;
+    comm = comm_;
+    HIP_CHECK(hipSetDevice(prm.device_number));
+    HIP_CHECK(hipStreamCreate(&stream));
+    m = m_glob; n = n_glob;
+    m_loc = m_loc_; n_loc = n_loc_;
+    row_off = row_off_; col_off = col_off_;
+    const int P = comm ? comm->size : 1;
+    const int chunk_m = (m + P - 1) / P, chunk_n = (n + P - 1) / P;
+    m_pad = chunk_m * P; n_pad = chunk_n * P;
+    if (comm) {
+        if (row_off != comm->rank * chunk_m || col_off != comm->rank * chunk_n ||
+            m_loc != std::max(0, std::min(m, row_off + chunk_m) - row_off) ||
+            n_loc != std::max(0, std::min(n, col_off + chunk_n) - col_off))
+            throw std::runtime_error("shard bounds do not match the block partition of hprlp_partition()");
+    }
+    obj_constant = obj_constant_;
+    A.upload(m_loc, n, Arp, Aci, Av);
+    AT.upload(n_loc, m, ATrp, ATci, ATv);
+    AL.alloc(m_loc); AL.upload(AL_, m_loc);
+    AU.alloc(m_loc); AU.upload(AU_, m_loc);
+    l.alloc(n_loc); l.upload(l_, n_loc);
+    u.alloc(n_loc); u.upload(u_, n_loc);
+    c.alloc(n_loc); c.upload(c_, n_loc);
+    alloc_work();
+    HIP_CHECK(hipDeviceSynchronize());
+    setup_time = time_since(t0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// collectives (no-ops on one GPU)
+// ------------------------------------------------------------------------------------------------
+void Solver::gather(double *gbuf, bool is_m) {
+    if (!comm || comm->size == 1) return;
+    const size_t chunk = static_cast<size_t>(is_m ? m_pad : n_pad) / comm->size;
+    comm->allgather_inplace(gbuf, chunk, stream);
+}
+
+void Solver::fetch_scalars() {
+    HIP_CHECK(hipMemcpyAsync(scal_h.p, scal.p, kNumScalars * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+static void allreduce_slots(Solver *s, int first, int count) {
+    if (!s->comm || s->comm->size == 1) return;
+    s->comm->allreduce_sum(s->scal.p + first, count, s->stream);
+}
+
+double Solver::reduce_sum_sq(const double *v, int n_local) {
+    launch_norm2(v, n_local, part_v.p, kReduceBlocks, stream);
+    FinalizeArgs f{};
+    f.n = 1;
+    f.item[0] = {part_v.p, kReduceBlocks, S_TMP0};
+    launch_finalize(f, scal.p, stream);
+    allreduce_slots(this, S_TMP0, 1);
+    fetch_scalars();
+    return scal_h[S_TMP0];
+}
+
+static double bnorm_sq(Solver *s) {
+    launch_bnorm2(s->AL.p, s->AU.p, s->m_loc, s->part_v.p, kReduceBlocks, s->stream);
+    FinalizeArgs f{};
+    f.n = 1;
+    f.item[0] = {s->part_v.p, kReduceBlocks, S_TMP0};
+    launch_finalize(f, s->scal.p, s->stream);
+    allreduce_slots(s, S_TMP0, 1);
+    s->fetch_scalars();
+    return s->scal_h[S_TMP0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// scaling (reference src/scaling.cu:88-216).  t1 lives in the gathered m-vector gsm, t2 in gsn, so
+// that the column-side scaling of each stored matrix can index the full vector.
+// ------------------------------------------------------------------------------------------------
+void Solver::scale() {
+    const auto t0 = time_now();
+    double *t1 = gsm.p + row_off, *t2 = gsn.p + col_off;
+    launch_fill(row_norm.p, 1.0, m_loc, stream);
+    launch_fill(col_norm.p, 1.0, n_loc, stream);
+    norm_b_org = 1.0 + std::sqrt(bnorm_sq(this));
+    norm_c_org = 1.0 + std::sqrt(reduce_sum_sq(c.p, n_loc));
+
+    if (prm.use_CR_scaling) {  // :40-83
+        HIP_CHECK(hipMemsetAsync(gsm.p, 0, sizeof(double) * m_pad, stream));
+        HIP_CHECK(hipMemsetAsync(gsn.p, 0, sizeof(double) * n_pad, stream));
+        for (int it = 0; it < 20; ++it) {
+            launch_cr_log_update(A.view, gsn.p, t1, stream);
+            gather(gsm.p, true);
+            launch_cr_log_update(AT.view, gsm.p, t2, stream);
+            gather(gsn.p, false);
+        }
+        launch_exp_clamp(t1, m_loc, stream);
+        launch_exp_clamp(t2, n_loc, stream);
+        gather(gsm.p, true);
+        gather(gsn.p, false);
+        launch_vec_scale(row_norm.p, t1, m_loc, true, stream);
+        launch_vec_scale(col_norm.p, t2, n_loc, true, stream);
+        launch_scale_matrix(A.view, t1, gsn.p, /*row_first=*/true, /*divide=*/false, stream);
+        launch_scale_matrix(AT.view, t2, gsm.p, /*row_first=*/false, /*divide=*/false, stream);
+        launch_vec_scale(AL.p, t1, m_loc, false, stream);
+        launch_vec_scale(AU.p, t1, m_loc, false, stream);
+        launch_vec_scale(c.p, t2, n_loc, false, stream);
+        launch_vec_scale(l.p, t2, n_loc, true, stream);
+        launch_vec_scale(u.p, t2, n_loc, true, stream);
+    }
+
+    const int passes = (prm.use_Ruiz_scaling ? 10 : 0) + (prm.use_Pock_Chambolle_scaling ? 1 : 0);
+    for (int it = 0; it < passes; ++it) {  // Ruiz :123-153 then Pock-Chambolle :157-183
+        const int norm = (prm.use_Ruiz_scaling && it < 10) ? 99 : 1;
+        launch_row_norm(A.view, t1, norm, stream);
+        launch_row_norm(AT.view, t2, norm, stream);
+        gather(gsm.p, true);
+        gather(gsn.p, false);
+        launch_vec_scale(row_norm.p, t1, m_loc, false, stream);
+        launch_vec_scale(AL.p, t1, m_loc, true, stream);
+        launch_vec_scale(AU.p, t1, m_loc, true, stream);
+        launch_vec_scale(col_norm.p, t2, n_loc, false, stream);
+        launch_scale_matrix(A.view, t1, gsn.p, true, true, stream);
+        launch_scale_matrix(AT.view, t2, gsm.p, false, true, stream);
+        launch_vec_scale(c.p, t2, n_loc, true, stream);
+        launch_vec_scale(l.p, t2, n_loc, false, stream);
+        launch_vec_scale(u.p, t2, n_loc, false, stream);
+    }
+
+    if (prm.use_bc_scaling) {  // :185-202
+        b_scale = 1.0 + std::sqrt(bnorm_sq(this));
+        c_scale = 1.0 + std::sqrt(reduce_sum_sq(c.p, n_loc));
+        const double bs = 1.0 / b_scale, cs = 1.0 / c_scale;
+        launch_vec_scal(AU.p, bs, m_loc, stream);
+        launch_vec_scal(AL.p, bs, m_loc, stream);
+        launch_vec_scal(l.p, bs, n_loc, stream);
+        launch_vec_scal(u.p, bs, n_loc, stream);
+        launch_vec_scal(c.p, cs, n_loc, stream);
+    } else {
+        b_scale = 1.0;
+        c_scale = 1.0;
+    }
+    norm_b = std::sqrt(bnorm_sq(this));
+    norm_c = std::sqrt(reduce_sum_sq(c.p, n_loc));
+    HIP_CHECK(hipMemsetAsync(gsm.p, 0, sizeof(double) * m_pad, stream));
+    HIP_CHECK(hipMemsetAsync(gsn.p, 0, sizeof(double) * n_pad, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    scaling_time = time_since(t0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lambda_max(A A^T) by the power method (reference src/power_iteration.cu:20-119).  q lives in gsm,
+// A^T q in gsn, z in sm1; the dots ride on the second SpMV's epilogue and stay on the device; the
+// host reads back only at the every-10th-iteration convergence check.
+// ------------------------------------------------------------------------------------------------
+double Solver::power_iteration(int max_iter, double tol, int *iters) {
+    const auto t0 = time_now();
+    double *q = gsm.p + row_off, *ATq = gsn.p + col_off, *z = sm1.p;
+    {
+        std::vector<double> z0(static_cast<size_t>(std::max(m_loc, 1)));
+        power_start_vector(m_loc, 1ULL, row_off, z0.data());
+        HIP_CHECK(hipMemcpyAsync(z, z0.data(), sizeof(double) * m_loc, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    launch_norm2(z, m_loc, part_v.p, kReduceBlocks, stream);
+    FinalizeArgs f0{};
+    f0.n = 1;
+    f0.item[0] = {part_v.p, kReduceBlocks, S_PW_ZZ};
+    launch_finalize(f0, scal.p, stream);
+    allreduce_slots(this, S_PW_ZZ, 1);
+
+    double lambda = 1.0;
+    int done = max_iter;
+    const int gridA = A.view.grid();
+    for (int i = 1; i <= max_iter; ++i) {
+        launch_pw_normalize(z, q, m_loc, scal.p, stream);
+        gather(gsm.p, true);
+        launch_spmv_plain(AT.view, gsm.p, ATq, nullptr, false, nullptr, 0, stream);
+        gather(gsn.p, false);
+        launch_spmv_plain(A.view, gsn.p, z, q, true, part_y.p, stride_y, stream);
+        FinalizeArgs f{};
+        f.n = 2;
+        f.item[0] = {part_y.p, gridA, S_PW_ZZ};
+        f.item[1] = {part_y.p + stride_y, gridA, S_PW_QZ};
+        launch_finalize(f, scal.p, stream);
+        allreduce_slots(this, S_PW_ZZ, 2);
+        if (i % 10 == 0) {
+            launch_pw_err(z, q, m_loc, scal.p, part_v.p, kReduceBlocks, stream);
+            FinalizeArgs fe{};
+            fe.n = 1;
+            fe.item[0] = {part_v.p, kReduceBlocks, S_PW_ERR2};
+            launch_finalize(fe, scal.p, stream);
+            allreduce_slots(this, S_PW_ERR2, 1);
+            fetch_scalars();
+            lambda = scal_h[S_PW_QZ];
+            const double err = std::sqrt(scal_h[S_PW_ERR2]);
+            if (err < tol) {
+                done = i;
+                break;
+            }
+        }
+    }
+    if (iters) *iters = done;
+    power_iters = done;
+    // leave the scratch vectors clean
+    HIP_CHECK(hipMemsetAsync(gsm.p, 0, sizeof(double) * m_pad, stream));
+    HIP_CHECK(hipMemsetAsync(gsn.p, 0, sizeof(double) * n_pad, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    power_time = time_since(t0);
+    return lambda;
+}
+
+// ------------------------------------------------------------------------------------------------
+void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
+    sigma = sigma_;
+    lambda_max = lambda_;
+    launch_set_ctrl(ctrl.p, sigma, lambda_max, reset_k ? 1 : 0, stream);
+}
+
+void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
+    const double s0 = (norm_b > 1e-8 && norm_c > 1e-8) ? norm_b / norm_c : 1.0;
+    set_sigma_lambda(s0, lambda_max, true);
+}
+
+void Solver::launch_normal_pair() {
+    XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
+    launch_x_half(AT.view, xa, false, stream);
+    gather(gxh.p, false);
+    YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
+    launch_y_half(A.view, ya, false, stream);
+    gather(gy.p, true);
+}
+
+void Solver::step(bool check) {
+    if (!check) {
+        launch_normal_pair();
+        return;
+    }
+    XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, x_bar, z_bar.p, x_temp, ctrl.p, part_x.p, stride_x};
+    launch_x_half(AT.view, xa, true, stream);
+    gather(gxh.p, false);
+    YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, y_bar, y_obj.p, y_temp.p, ctrl.p, part_y.p, stride_y};
+    launch_y_half(A.view, ya, true, stream);
+    gather(gy.p, true);
+    FinalizeArgs f{};
+    const int gx = AT.view.grid(), gyy = A.view.grid();
+    f.n = 5;
+    f.item[0] = {part_x.p, gx, S_CX};
+    f.item[1] = {part_x.p + stride_x, gx, S_XZ};
+    f.item[2] = {part_x.p + 2 * static_cast<size_t>(stride_x), gx, S_DX2};
+    f.item[3] = {part_y.p, gyy, S_YOBJ_Y};
+    f.item[4] = {part_y.p + stride_y, gyy, S_DY2};
+    launch_finalize(f, scal.p, stream);
+}
+
+hipGraphExec_t Solver::graph_for(int len) {
+    auto it = graphs.find(len);
+    if (it != graphs.end()) return it->second;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < len; ++i) launch_normal_pair();
+    HIP_CHECK(hipStreamEndCapture(stream, &g));
+    HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(g));
+    graphs[len] = ge;
+    return ge;
+}
+
+void Solver::run_normal(int count) {
+    if (count <= 0) return;
+    if (!use_graph) {
+        for (int i = 0; i < count; ++i) launch_normal_pair();
+        return;
+    }
+    while (count > 0) {
+        const int len = std::min(count, kMaxGraphIters);
+        HIP_CHECK(hipGraphLaunch(graph_for(len), stream));
+        count -= len;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// residuals (reference src/main_iterate.cu:229-309).  c.x_bar, y_obj.y_bar, x_bar.z_bar, |x_temp|^2
+// and |y_temp|^2 were already reduced by the check-variant epilogues of the step that produced them.
+// ------------------------------------------------------------------------------------------------
+static double weighted_norm_from(Solver *s, double dot_adx_dy, double dy2, double dx2) {
+    const double dot_prod = 2.0 * dot_adx_dy;
+    double wn = s->sigma * (s->lambda_max * dy2) + dx2 / s->sigma + dot_prod;
+    if (wn < 0) {
+        if (s->verbose)
+            std::cout << "The estimated maximum eigenvalue is too small! Current value is " << s->lambda_max << "\n";
+        s->lambda_max = -(dot_prod + dx2 / s->sigma) / (s->sigma * dy2) * 1.05;
+        if (s->verbose) std::cout << "The new estimated maximum eigenvalue is " << s->lambda_max << "\n";
+        wn = std::sqrt(-(dot_prod + dx2 / s->sigma) * 0.05);
+        s->set_sigma_lambda(s->sigma, s->lambda_max, false);
+    } else {
+        wn = std::sqrt(wn);
+    }
+    return wn;
+}
+
+void Solver::compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs) {
+    const int gx = AT.view.grid(), gyy = A.view.grid();
+    const int rstride = std::max(stride_x, stride_y);
+    gather(gyb.p, true);
+    gather(gxb.p, false);
+    if (compute_gap) gather(gxt.p, false);
+    FinalizeArgs f{};
+    launch_resid_d(AT.view, gyb.p, c.p, z_bar.p, col_norm.p, part_x.p, stream);
+    f.item[f.n++] = {part_x.p, gx, S_RD2};
+    launch_resid_p(A.view, gxb.p, gxt.p, AL.p, AU.p, row_norm.p, y_temp.p, compute_gap, part_r.p, rstride, stream);
+    f.item[f.n++] = {part_r.p, gyy, S_RP2};
+    if (compute_gap) f.item[f.n++] = {part_r.p + rstride, gyy, S_ADX_DY};
+    if (iter == 0) {
+        launch_lu(n_loc, x_bar, l.p, u.p, col_norm.p, x_temp, part_v.p, kReduceBlocks, stream);
+        f.item[f.n++] = {part_v.p, kReduceBlocks, S_LU2};
+    }
+    launch_finalize(f, scal.p, stream);
+    allreduce_slots(this, S_CX, 8);
+    if (iter == 0) allreduce_slots(this, S_LU2, 1);
+    fetch_scalars();
+
+    const double obj_scale = b_scale * c_scale;
+    r->primal_obj = obj_scale * scal_h[S_CX] + obj_constant;
+    r->dual_obj = obj_scale * (scal_h[S_YOBJ_Y] + scal_h[S_XZ]) + obj_constant;
+    r->rel_gap = std::abs(r->primal_obj - r->dual_obj) / (1.0 + std::abs(r->primal_obj) + std::abs(r->dual_obj));
+    r->err_Rd = c_scale * std::sqrt(scal_h[S_RD2]) / norm_c_org;
+    r->err_Rp = b_scale * std::sqrt(scal_h[S_RP2]) / norm_b_org;
+    if (iter == 0) r->err_Rp = std::max(r->err_Rp, b_scale * std::sqrt(scal_h[S_LU2]));
+    r->kkt = std::max(std::max(r->err_Rd, r->err_Rp), r->rel_gap);
+    if (compute_gap && rs) rs->current_gap = weighted_norm_from(this, scal_h[S_ADX_DY], scal_h[S_DY2], scal_h[S_DX2]);
+}
+
+double Solver::weighted_norm_after_restart() {
+    gather(gxt.p, false);
+    launch_gap(A.view, gxt.p, y_temp.p, part_r.p, stream);
+    FinalizeArgs f{};
+    f.n = 1;
+    f.item[0] = {part_r.p, A.view.grid(), S_ADX_DY};
+    launch_finalize(f, scal.p, stream);
+    allreduce_slots(this, S_ADX_DY, 3);  // S_ADX_DY, S_DY2, S_DX2 are adjacent
+    fetch_scalars();
+    return weighted_norm_from(this, scal_h[S_ADX_DY], scal_h[S_DY2], scal_h[S_DX2]);
+}
+
+static void check_restart(RestartState *rs, int iter, int check_iter, double sigma, bool verbose) {
+    rs->flag = 0;
+    if (rs->first) {
+        if (iter == check_iter) {
+            rs->first = false;
+            rs->flag = 1;
+            rs->best_gap = rs->current_gap;
+            rs->best_sigma = sigma;
+        }
+    } else if (iter % check_iter == 0) {
+        if (rs->current_gap < 0) {
+            rs->current_gap = 1e-6;
+            if (verbose) std::cout << "current_gap < 0" << std::endl;
+        }
+        if (rs->current_gap <= 0.2 * rs->last_gap) { rs->sufficient += 1; rs->flag = 1; }
+        if (rs->current_gap <= 0.6 * rs->last_gap && rs->current_gap > 1.00 * rs->save_gap) { rs->necessary += 1; rs->flag = 2; }
+        if (rs->inner >= 0.2 * iter) { rs->long_ += 1; rs->flag = 3; }
+        if (rs->best_gap > rs->current_gap) { rs->best_gap = rs->current_gap; rs->best_sigma = sigma; }
+        rs->save_gap = rs->current_gap;
+    }
+}
+
+void Solver::update_sigma_and_restart(RestartState *rs, const Residuals &r) {
+    if (rs->flag <= 0) return;
+    // movement x_bar - last_x, y_bar - last_y and their norms (update_sigma, main_iterate.cu:367-404)
+    launch_movement(n_loc, m_loc, x_bar, last_x.p, x_temp, y_bar, last_y.p, y_temp.p, part_v.p, kReduceBlocks,
+                    kReduceBlocks, stream);
+    FinalizeArgs f{};
+    f.n = 2;
+    f.item[0] = {part_v.p, kReduceBlocks, S_MOVE_X2};
+    f.item[1] = {part_v.p + kReduceBlocks, kReduceBlocks, S_MOVE_Y2};
+    launch_finalize(f, scal.p, stream);
+    allreduce_slots(this, S_MOVE_X2, 2);
+    fetch_scalars();
+    const double primal_move = std::sqrt(scal_h[S_MOVE_X2]), dual_move = std::sqrt(scal_h[S_MOVE_Y2]);
+    double new_sigma = 1.0;
+    if (primal_move > 1e-16 && dual_move > 1e-16 && primal_move < 1e12 && dual_move < 1e12) {
+        const double ratio = (primal_move / dual_move) / std::sqrt(lambda_max);
+        const double fact = std::exp(-0.05 * (rs->current_gap / rs->best_gap));
+        const double temp1 = std::max(std::min(r.err_Rd, r.err_Rp), std::min(r.rel_gap, rs->current_gap));
+        const double sigma_cand = std::exp(fact * std::log(ratio) + (1 - fact) * std::log(rs->best_sigma));
+        double kappa;
+        if (temp1 > 9e-10) {
+            kappa = 1.0;
+        } else if (temp1 > 5e-10) {
+            kappa = std::max(std::min(std::sqrt(r.err_Rd / r.err_Rp), 100.0), 1e-2);
+        } else {
+            kappa = std::max(std::min(r.err_Rd / r.err_Rp, 100.0), 1e-2);
+        }
+        new_sigma = kappa * sigma_cand;
+    }
+    // do_restart (main_iterate.cu:312-322) + Halpern reset (:54-66)
+    launch_restart_copy(n_loc, m_loc, x_bar, x.p, last_x.p, y_bar, y, last_y.p, ctrl.p, stream);
+    gather(gy.p, true);
+    set_sigma_lambda(new_sigma, lambda_max, true);
+    rs->inner = 0;
+    rs->times += 1;
+    rs->save_gap = std::numeric_limits<double>::infinity();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the outer loop (reference src/HPRLP.cu:154-310).  `iter` only ever stops at event iterations
+// (periodic check, log line, iteration limit); everything between two events is enqueued at once.
+// ------------------------------------------------------------------------------------------------
+static int next_event(int iter, int check_iter, int max_iter) {
+    int j = iter + 1;
+    while (true) {
+        if (j % check_iter == 0 || j % log_step(j) == 0 || j >= max_iter) return j;
+        ++j;
+    }
+}
+
+void Solver::solve_loop(HPRLP_results *out) {
+    const auto t_loop = time_now();
+    const double t_before = power_time;  // reported `time` includes the power iteration (HPRLP.cu:150)
+    Residuals r;
+    RestartState rs;
+    rs.best_sigma = sigma;
+    bool first4 = true, first6 = true, first8 = true;
+    const int check_iter = std::max(prm.check_iter, 1);
+    const int max_iter = std::max(prm.max_iter, 0);
+    *out = HPRLP_results();
+    std::string status = "CONTINUE";
+    trace_n = 0;
+    if (verbose)
+        std::cout << " iter     errRp        errRd         p_obj            d_obj          gap         sigma       time\n"
+                  << std::flush;
+    int iter = 0;
+    while (true) {
+        const bool at_limit = iter >= max_iter;
+        const bool periodic = (iter % check_iter == 0);
+        compute_residuals(iter, periodic && iter > 0, &r, &rs);
+        const double elapsed = t_before + time_since(t_loop);
+        if (r.kkt < prm.stop_tol) status = "OPTIMAL";
+        else if (at_limit) status = "ITER_LIMIT";
+        else if (elapsed > prm.time_limit) status = "TIME_LIMIT";
+        if (periodic && !at_limit) check_restart(&rs, iter, check_iter, sigma, verbose);
+        else rs.flag = 0;
+        if (trace && trace_n < trace_cap)
+            trace[trace_n++] = TraceRow{iter, rs.flag, r.err_Rp, r.err_Rd, r.primal_obj, r.dual_obj, r.rel_gap, r.kkt,
+                                        sigma, rs.current_gap, lambda_max};
+        if (verbose) {
+            std::cout << std::setw(5) << iter << "    " << std::scientific << std::setprecision(2) << r.err_Rp << "    "
+                      << r.err_Rd << "    " << std::setprecision(6) << std::showpos << r.primal_obj << "    "
+                      << r.dual_obj << "    " << std::setprecision(2) << std::noshowpos << r.rel_gap << "    " << sigma
+                      << "      " << std::fixed << std::setprecision(2) << elapsed << "\n" << std::defaultfloat
+                      << std::flush;
+        }
+        auto mark = [&](bool &first, double thr, int &it_out, double &t_out, const char *label) {
+            if (first && r.kkt < thr) {
+                it_out = iter;
+                t_out = elapsed;
+                first = false;
+                if (verbose) std::cout << "Residual < " << label << " at iter = " << iter << "\n" << std::flush;
+            }
+        };
+        mark(first4, 1e-4, out->iter4, out->time4, "1e-4");
+        mark(first6, 1e-6, out->iter6, out->time6, "1e-6");
+        mark(first8, 1e-8, out->iter8, out->time8, "1e-8");
+        if (status != "CONTINUE") break;
+
+        const int flag = rs.flag;
+        update_sigma_and_restart(&rs, r);
+        const int next = next_event(iter, check_iter, max_iter);
+        int it = iter;
+        if (flag > 0) {
+            step(true);
+            rs.last_gap = weighted_norm_after_restart();
+            ++it;
+        }
+        if (it < next) {
+            run_normal(next - 1 - it);
+            step(true);
+        }
+        rs.inner += next - iter;
+        iter = next;
+    }
+    std::strncpy(out->status, status.c_str(), sizeof(out->status) - 1);
+    out->status[sizeof(out->status) - 1] = '\0';
+    out->iter = iter;
+    out->gap = r.rel_gap;
+    out->residuals = r.kkt;
+    out->primal_obj = r.primal_obj;
+    out->time = t_before + time_since(t_loop);
+    if (out->time4 == 0.0) out->time4 = out->time;
+    if (out->time6 == 0.0) out->time6 = out->time;
+    if (out->time8 == 0.0) out->time8 = out->time;
+    if (out->iter4 == 0) out->iter4 = out->iter;
+    if (out->iter6 == 0) out->iter6 = out->iter;
+    if (out->iter8 == 0) out->iter8 = out->iter;
+}
+
+void Solver::collect_solution(HPRLP_results *out) {
+    // scratch: sn1 (x), sm1 (y), gsn local slice (z)
+    double *zo = gsn.p + col_off;
+    launch_unscale(n_loc, m_loc, x_bar, y_bar, z_bar.p, col_norm.p, row_norm.p, b_scale, c_scale, sn1.p, sm1.p, zo,
+                   stream);
+    out->x = static_cast<double *>(std::malloc(sizeof(double) * std::max(n_loc, 1)));
+    out->y = static_cast<double *>(std::malloc(sizeof(double) * std::max(m_loc, 1)));
+    out->z = static_cast<double *>(std::malloc(sizeof(double) * std::max(n_loc, 1)));
+    if (!out->x || !out->y || !out->z) throw std::runtime_error("host allocation of the solution failed");
+    HIP_CHECK(hipMemcpyAsync(out->x, sn1.p, sizeof(double) * n_loc, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(out->y, sm1.p, sizeof(double) * m_loc, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(out->z, zo, sizeof(double) * n_loc, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+}  // namespace hprlp

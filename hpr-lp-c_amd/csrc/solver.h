@@ -1,0 +1,116 @@
+// solver.h -- device-resident single-LP HPR solver state (private).
+// Replaces the reference's HPRLP_workspace_gpu / LP_info_gpu / Scaling_info / HPRLP_restart
+// (reference include/structs.h:127-277) without vendor-library handles.
+#pragma once
+
+#include <map>
+#include <memory>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace hprlp {
+
+struct Comm;  // collective layer (dist.cpp); nullptr on one GPU
+
+struct Residuals {  // reference HPRLP_residuals, include/structs.h:255-263
+    double err_Rp = 0, err_Rd = 0, primal_obj = 0, dual_obj = 0, rel_gap = 0;
+    double kkt = std::numeric_limits<double>::infinity();
+};
+
+struct RestartState {  // reference HPRLP_restart, include/structs.h:215-228
+    int flag = 0;
+    bool first = true;
+    double last_gap = std::numeric_limits<double>::infinity();
+    double current_gap = std::numeric_limits<double>::infinity();
+    double save_gap = std::numeric_limits<double>::infinity();
+    double best_gap = std::numeric_limits<double>::infinity();
+    double best_sigma = 1.0;
+    int inner = 0, sufficient = 0, necessary = 0, long_ = 0, times = 0;
+};
+
+struct TraceRow {  // same layout as hprlp_trace_row in include/hprlp_amd.h
+    int iter, restart_flag;
+    double err_Rp, err_Rd, primal_obj, dual_obj, gap, kkt, sigma, current_gap, lambda_max;
+};
+
+// One row-partitioned CSR matrix resident on the device together with its row-block descriptors.
+struct DeviceMatrix {
+    DBuf<int> rowptr, col;
+    DBuf<double> val;
+    DBuf<int4> blk;
+    CsrDev view;
+    void upload(int rows, int cols, const int *rp, const int *ci, const double *v);
+};
+
+std::vector<int4> build_row_blocks(int rows, const int *rowptr);
+
+struct Solver {
+    HPRLP_parameters prm;
+    int m = 0, n = 0;          // global sizes
+    int m_loc = 0, n_loc = 0;  // rows of A / rows of A^T owned by this rank
+    int row_off = 0, col_off = 0;
+    int m_pad = 0, n_pad = 0;  // gathered-vector lengths (multiple of the chunk size)
+    double obj_constant = 0.0;
+    bool verbose = true;
+    hipStream_t stream = nullptr;
+    Comm *comm = nullptr;
+
+    DeviceMatrix A, AT;  // A: m_loc x n (global columns); AT: n_loc x m (global columns)
+    DBuf<double> AL, AU, l, u, c, row_norm, col_norm;
+    // local work vectors
+    DBuf<double> x, last_x, z_bar, last_y, y_obj, y_temp;
+    // gathered vectors (length *_pad); the local slice starts at *_off
+    DBuf<double> gy, gxh, gxb, gyb, gxt, gsn, gsm;
+    double *y = nullptr, *x_hat = nullptr, *x_bar = nullptr, *y_bar = nullptr, *x_temp = nullptr;
+    DBuf<double> sm1, sn1;  // local scratch
+    DBuf<Ctrl> ctrl;
+    DBuf<double> scal;
+    HBuf<double> scal_h;
+    DBuf<double> part_x, part_y, part_r, part_v;
+    int stride_x = 0, stride_y = 0;
+
+    double b_scale = 1, c_scale = 1, norm_b = 0, norm_c = 0, norm_b_org = 1, norm_c_org = 1;
+    double sigma = 1.0, lambda_max = 1.0;
+    double setup_time = 0, scaling_time = 0, power_time = 0;
+    int power_iters = 0;
+    bool use_graph = true;
+
+    std::map<int, hipGraphExec_t> graphs;
+    TraceRow *trace = nullptr;
+    int trace_cap = 0, trace_n = 0;
+
+    Solver() = default;
+    ~Solver();
+    Solver(const Solver &) = delete;
+
+    // reference copy_lpinfo_to_device + allocate_memory (src/preprocess.cu:66-256)
+    void setup(const LP_info_cpu *model, const HPRLP_parameters *param);
+    // distributed variant: the caller supplies this rank's rows of A and rows of A^T
+    void setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int col_off_, int n_loc_, const int *Arp,
+                     const int *Aci, const double *Av, const int *ATrp, const int *ATci, const double *ATv,
+                     const double *AL_, const double *AU_, const double *l_, const double *u_, const double *c_,
+                     double obj_constant_, const HPRLP_parameters *param, Comm *comm_);
+    void scale();                                                   // src/scaling.cu:88-216
+    double power_iteration(int max_iter, double tol, int *iters);   // src/power_iteration.cu:20-119
+    void init_iteration_state();                                    // src/HPRLP.cu:154-167
+    void set_sigma_lambda(double sigma_, double lambda_, bool reset_k);
+    void step(bool check);                                          // one HPR iteration
+    void run_normal(int count);                                     // count normal iterations (graph replay)
+    void fetch_scalars();
+    void compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs);  // main_iterate.cu:229-309
+    double weighted_norm_after_restart();                           // main_iterate.cu:486-515
+    void update_sigma_and_restart(RestartState *rs, const Residuals &r);  // main_iterate.cu:312-322,367-404
+    void solve_loop(HPRLP_results *out);                            // src/HPRLP.cu:154-310
+    void collect_solution(HPRLP_results *out);                      // src/utils.cu:143-200
+    double reduce_sum_sq(const double *v, int n_local);             // allreduced ||v||^2
+    void gather(double *gbuf, bool is_m);                           // all-gather a length-m or length-n vector
+    void allreduce_scalars();
+
+   private:
+    void alloc_work();
+    hipGraphExec_t graph_for(int len);
+    void launch_normal_pair();
+};
+
+}  // namespace hprlp

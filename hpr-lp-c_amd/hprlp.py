@@ -1,0 +1,366 @@
+"""ctypes host mirror of the HPR-LP boundary (lib/libhprlp.so, include/HPRLP.h + hprlp_amd.h).
+
+Same names and argument meaning as the reference's Python package (reference
+bindings/python/hprlp/{model,parameters,results,solver}.py): Parameters, Model.from_arrays /
+Model.from_mps, Model.solve, solve_batched, Results.  Plumbing only: every number is produced by the
+HIP library; nothing here falls back to a CPU path, and loading fails loudly when the library (or,
+for solves, a GPU) is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_ROOT, "lib", "libhprlp.so")
+
+c_int_p = C.POINTER(C.c_int)
+c_dbl_p = C.POINTER(C.c_double)
+
+
+class CParameters(C.Structure):  # include/structs.h HPRLP_parameters (40 bytes)
+    _fields_ = [
+        ("max_iter", C.c_int), ("stop_tol", C.c_double), ("time_limit", C.c_double),
+        ("device_number", C.c_int), ("check_iter", C.c_int),
+        ("CUSPARSE_spmv", C.c_bool), ("autotune_verbose", C.c_bool), ("use_CR_scaling", C.c_bool),
+        ("use_Ruiz_scaling", C.c_bool), ("use_Pock_Chambolle_scaling", C.c_bool),
+        ("use_bc_scaling", C.c_bool), ("use_presolve", C.c_bool),
+    ]
+
+
+class CResults(C.Structure):  # HPRLP_results (160 bytes)
+    _fields_ = [
+        ("residuals", C.c_double), ("primal_obj", C.c_double), ("gap", C.c_double),
+        ("time4", C.c_double), ("time6", C.c_double), ("time8", C.c_double), ("time", C.c_double),
+        ("iter4", C.c_int), ("iter6", C.c_int), ("iter8", C.c_int), ("iter", C.c_int),
+        ("status", C.c_char * 64),
+        ("x", c_dbl_p), ("y", c_dbl_p), ("z", c_dbl_p),
+    ]
+
+
+class CBatchedResults(C.Structure):  # HPRLP_batched_results (112 bytes)
+    _fields_ = [
+        ("m", C.c_int), ("n", C.c_int), ("batch_size", C.c_int),
+        ("x", c_dbl_p), ("y", c_dbl_p), ("z", c_dbl_p),
+        ("primal_obj", c_dbl_p), ("residuals", c_dbl_p), ("gap", c_dbl_p),
+        ("iter", c_int_p), ("status", C.POINTER(C.c_char)),
+        ("time", C.c_double), ("setup_time", C.c_double), ("solve_time", C.c_double), ("power_time", C.c_double),
+    ]
+
+
+class CSparseMatrix(C.Structure):
+    _fields_ = [("row", C.c_int), ("col", C.c_int), ("numElements", C.c_int),
+                ("colIndex", c_int_p), ("rowPtr", c_int_p), ("value", c_dbl_p)]
+
+
+class CLPInfo(C.Structure):
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("A", C.POINTER(CSparseMatrix)),
+                ("AL", c_dbl_p), ("AU", c_dbl_p), ("c", c_dbl_p), ("l", c_dbl_p), ("u", c_dbl_p),
+                ("obj_constant", C.c_double)]
+
+
+class CTraceRow(C.Structure):
+    _fields_ = [("iter", C.c_int), ("restart_flag", C.c_int)] + [
+        (k, C.c_double)
+        for k in ("err_Rp", "err_Rd", "primal_obj", "dual_obj", "gap", "kkt", "sigma", "current_gap", "lambda_max")
+    ]
+
+
+_lib = None
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def lib():
+    """Load lib/libhprlp.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `make` (no CPU fallback exists)")
+    L = C.CDLL(LIB_PATH)
+    L.create_model_from_arrays.restype = C.POINTER(CLPInfo)
+    L.create_model_from_arrays.argtypes = [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p,
+                                           c_dbl_p, c_dbl_p, c_dbl_p, C.c_bool]
+    L.create_model_from_mps.restype = C.POINTER(CLPInfo)
+    L.create_model_from_mps.argtypes = [C.c_char_p]
+    L.free_model.argtypes = [C.POINTER(CLPInfo)]
+    L.solve.restype = CResults
+    L.solve.argtypes = [C.POINTER(CLPInfo), C.POINTER(CParameters)]
+    L.HPRLP_main_solve.restype = CResults
+    L.HPRLP_main_solve.argtypes = [C.POINTER(CLPInfo), C.POINTER(CParameters)]
+    L.solve_batched.restype = CBatchedResults
+    L.solve_batched.argtypes = [C.POINTER(CLPInfo), C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p,
+                                C.POINTER(CParameters)]
+    L.free_batched_results.argtypes = [C.POINTER(CBatchedResults)]
+    L.hprlp_last_error.restype = C.c_char_p
+    L.hprlp_backend.restype = C.c_char_p
+    L.hprlp_solver_create.restype = C.c_void_p
+    L.hprlp_solver_create.argtypes = [C.POINTER(CLPInfo), C.POINTER(CParameters)]
+    L.hprlp_solver_destroy.argtypes = [C.c_void_p]
+    L.hprlp_solver_set_verbose.argtypes = [C.c_void_p, C.c_int]
+    L.hprlp_solver_scale.argtypes = [C.c_void_p]
+    L.hprlp_solver_power_iteration.restype = C.c_double
+    L.hprlp_solver_power_iteration.argtypes = [C.c_void_p, C.c_int, C.c_double, c_int_p]
+    L.hprlp_solver_init.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.hprlp_solver_iterate.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.hprlp_solver_residuals.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dbl_p]
+    L.hprlp_solver_restart.argtypes = [C.c_void_p, c_dbl_p, c_dbl_p]
+    L.hprlp_solver_weighted_norm.restype = C.c_double
+    L.hprlp_solver_weighted_norm.argtypes = [C.c_void_p]
+    L.hprlp_solver_run.argtypes = [C.c_void_p, C.POINTER(CResults), C.POINTER(CTraceRow), C.c_int, c_int_p]
+    L.hprlp_solver_get_vector.restype = C.c_long
+    L.hprlp_solver_get_vector.argtypes = [C.c_void_p, C.c_char_p, c_dbl_p, C.c_long]
+    L.hprlp_solver_set_vector.argtypes = [C.c_void_p, C.c_char_p, c_dbl_p, C.c_long]
+    L.hprlp_solver_get_scalars.argtypes = [C.c_void_p, c_dbl_p]
+    L.hprlp_solver_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    L.hprlp_solver_time_iterations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().hprlp_last_error().decode()
+
+
+class Parameters:
+    """Solver parameters; defaults of reference include/structs.h:26-39."""
+
+    _names = [f for f, _ in CParameters._fields_]
+
+    def __init__(self, **kw):
+        self.max_iter = 2**31 - 1
+        self.stop_tol = 1e-4
+        self.time_limit = 3600.0
+        self.device_number = 0
+        self.check_iter = 150
+        self.CUSPARSE_spmv = False
+        self.autotune_verbose = False
+        self.use_CR_scaling = True
+        self.use_Ruiz_scaling = True
+        self.use_Pock_Chambolle_scaling = True
+        self.use_bc_scaling = True
+        self.use_presolve = True
+        for k, v in kw.items():
+            if k not in self._names:
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+    def to_c(self):
+        return CParameters(*[getattr(self, k) for k in self._names])
+
+
+def _as(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _take(ptr, n):
+    """Copy a malloc'd result array into numpy and free() it (the caller owns HPRLP_results.x/y/z)."""
+    if not ptr:
+        return None
+    out = np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+    _libc.free(C.cast(ptr, C.c_void_p))
+    return out
+
+
+class Results:
+    def __init__(self, cres, m, n):
+        self.status = cres.status.decode()
+        for k in ("residuals", "primal_obj", "gap", "time4", "time6", "time8", "time", "iter4", "iter6", "iter8", "iter"):
+            setattr(self, k, getattr(cres, k))
+        self.x = _take(cres.x, n)
+        self.y = _take(cres.y, m)
+        self.z = _take(cres.z, n)
+
+
+class Model:
+    """LP model: min c'x s.t. AL <= Ax <= AU, l <= x <= u (wraps LP_info_cpu*)."""
+
+    def __init__(self, ptr):
+        if not ptr:
+            raise RuntimeError("model creation failed (see stderr)")
+        self._ptr = ptr
+
+    @property
+    def m(self):
+        return self._ptr.contents.m
+
+    @property
+    def n(self):
+        return self._ptr.contents.n
+
+    @property
+    def obj_constant(self):
+        return self._ptr.contents.obj_constant
+
+    @staticmethod
+    def from_csr(m, n, rowptr, colind, values, AL, AU, l, u, c, is_csc=False):
+        rp = _as(rowptr, np.int32); ci = _as(colind, np.int32); v = _as(values, np.float64)
+        AL = _as(AL, np.float64); AU = _as(AU, np.float64); l = _as(l, np.float64); u = _as(u, np.float64)
+        c = _as(c, np.float64)
+        P = lambda a: a.ctypes.data_as(c_dbl_p)
+        ptr = lib().create_model_from_arrays(m, n, len(v), rp.ctypes.data_as(c_int_p), ci.ctypes.data_as(c_int_p),
+                                             P(v), P(AL), P(AU), P(l), P(u), P(c), bool(is_csc))
+        return Model(ptr)
+
+    @staticmethod
+    def from_arrays(A, AL, AU, l, u, c):
+        """A: dense ndarray or scipy.sparse matrix (reference bindings/python/hprlp/model.py:96-174)."""
+        from scipy import sparse
+        A = sparse.csr_matrix(A)
+        A.sort_indices()
+        m, n = A.shape
+        return Model.from_csr(m, n, A.indptr, A.indices, A.data, AL, AU, l, u, c)
+
+    @staticmethod
+    def from_mps(path):
+        return Model(lib().create_model_from_mps(str(path).encode()))
+
+    def csr(self):
+        """Host copy of the stored CSR arrays (rowPtr, colIndex, value)."""
+        A = self._ptr.contents.A.contents
+        rp = np.ctypeslib.as_array(A.rowPtr, shape=(A.row + 1,)).copy()
+        ci = np.ctypeslib.as_array(A.colIndex, shape=(A.numElements,)).copy()
+        v = np.ctypeslib.as_array(A.value, shape=(A.numElements,)).copy()
+        return rp, ci, v
+
+    def vectors(self):
+        p = self._ptr.contents
+        g = lambda q, k: np.ctypeslib.as_array(q, shape=(k,)).copy()
+        return dict(AL=g(p.AL, p.m), AU=g(p.AU, p.m), l=g(p.l, p.n), u=g(p.u, p.n), c=g(p.c, p.n))
+
+    def solve(self, param=None):
+        cp = (param or Parameters()).to_c()
+        res = lib().solve(self._ptr, C.byref(cp))
+        return Results(res, self.m, self.n)
+
+    def free(self):
+        if self._ptr:
+            lib().free_model(self._ptr)
+            self._ptr = None
+
+
+def solve(A, AL, AU, l, u, c, param=None):
+    model = Model.from_arrays(A, AL, AU, l, u, c)
+    try:
+        return model.solve(param)
+    finally:
+        model.free()
+
+
+def solve_batched(model, Cmat, AL, AU, l, u, obj_constants=None, param=None):
+    """Cmat,l,u: (n,B) arrays; AL,AU: (m,B) arrays (any layout; passed column-major as the ABI asks)."""
+    Cmat = np.asfortranarray(Cmat, dtype=np.float64)
+    B = Cmat.shape[1]
+    F = lambda a: np.asfortranarray(a, dtype=np.float64)
+    AL, AU, l, u = F(AL), F(AU), F(l), F(u)
+    P = lambda a: a.ctypes.data_as(c_dbl_p)
+    oc = None if obj_constants is None else _as(obj_constants, np.float64)
+    cp = (param or Parameters()).to_c()
+    res = lib().solve_batched(model._ptr, B, P(Cmat), P(AL), P(AU), P(l), P(u), None if oc is None else P(oc),
+                              C.byref(cp))
+    m, n = model.m, model.n
+    g = lambda q, k: None if not q else np.ctypeslib.as_array(q, shape=(k,)).copy()
+    out = dict(batch_size=res.batch_size, time=res.time, setup_time=res.setup_time, solve_time=res.solve_time,
+               power_time=res.power_time)
+    out["x"] = None if not res.x else g(res.x, n * B).reshape(B, n).T
+    out["y"] = None if not res.y else g(res.y, m * B).reshape(B, m).T
+    out["z"] = None if not res.z else g(res.z, n * B).reshape(B, n).T
+    out["primal_obj"] = g(res.primal_obj, B); out["residuals"] = g(res.residuals, B); out["gap"] = g(res.gap, B)
+    out["iter"] = None if not res.iter else np.ctypeslib.as_array(res.iter, shape=(B,)).copy()
+    raw = C.string_at(res.status, 64 * res.batch_size) if res.status else b""
+    out["status"] = [raw[64 * k:64 * (k + 1)].split(b"\0")[0].decode() for k in range(res.batch_size if raw else 0)]
+    lib().free_batched_results(C.byref(res))
+    return out
+
+
+class Solver:
+    """Step-level handle (include/hprlp_amd.h) used by the parity tests and bench.py."""
+
+    def __init__(self, model, param=None):
+        cp = (param or Parameters()).to_c()
+        self.model = model
+        self.h = lib().hprlp_solver_create(model._ptr, C.byref(cp))
+        if not self.h:
+            raise RuntimeError("hprlp_solver_create failed: " + last_error())
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(last_error())
+        return rc
+
+    def close(self):
+        if self.h:
+            lib().hprlp_solver_destroy(self.h)
+            self.h = None
+
+    def scale(self):
+        self._chk(lib().hprlp_solver_scale(self.h))
+
+    def power_iteration(self, max_iter=5000, tol=1e-4):
+        it = C.c_int(0)
+        lam = lib().hprlp_solver_power_iteration(self.h, max_iter, tol, C.byref(it))
+        if lam < 0:
+            raise RuntimeError(last_error())
+        return lam, it.value
+
+    def init(self, sigma=-1.0, lambda_max=1.0):
+        self._chk(lib().hprlp_solver_init(self.h, sigma, lambda_max))
+
+    def iterate(self, normal, then_check=False):
+        self._chk(lib().hprlp_solver_iterate(self.h, int(normal), int(bool(then_check))))
+
+    def residuals(self, it, compute_gap=False):
+        out = np.zeros(8)
+        self._chk(lib().hprlp_solver_residuals(self.h, int(it), int(bool(compute_gap)), out.ctypes.data_as(c_dbl_p)))
+        return dict(zip(("err_Rp", "err_Rd", "primal_obj", "dual_obj", "gap", "kkt", "weighted_norm", "lambda_max"), out))
+
+    def restart(self, current_gap, best_gap, best_sigma, err_Rd, err_Rp, rel_gap):
+        a = np.array([current_gap, best_gap, best_sigma, err_Rd, err_Rp, rel_gap], dtype=np.float64)
+        s = C.c_double(0)
+        self._chk(lib().hprlp_solver_restart(self.h, a.ctypes.data_as(c_dbl_p), C.byref(s)))
+        return s.value
+
+    def weighted_norm(self):
+        return lib().hprlp_solver_weighted_norm(self.h)
+
+    def get(self, name):
+        info = self.info()
+        cap = max(info["m"], info["n"], info["nnz"], 1)
+        buf = np.zeros(cap)
+        k = lib().hprlp_solver_get_vector(self.h, name.encode(), buf.ctypes.data_as(c_dbl_p), cap)
+        if k < 0:
+            raise RuntimeError(last_error())
+        return buf[:k].copy()
+
+    def set(self, name, arr):
+        a = _as(arr, np.float64)
+        self._chk(lib().hprlp_solver_set_vector(self.h, name.encode(), a.ctypes.data_as(c_dbl_p), len(a)))
+
+    def scalars(self):
+        out = np.zeros(16)
+        self._chk(lib().hprlp_solver_get_scalars(self.h, out.ctypes.data_as(c_dbl_p)))
+        keys = ("b_scale", "c_scale", "norm_b", "norm_c", "norm_b_org", "norm_c_org", "sigma", "lambda_max",
+                "setup_time", "scaling_time", "power_time", "power_iters", "kx", "ky")
+        return dict(zip(keys, out))
+
+    def info(self):
+        out = (C.c_long * 8)()
+        self._chk(lib().hprlp_solver_info(self.h, out))
+        keys = ("m", "n", "nnz", "blocks_A", "blocks_AT", "grid_y", "grid_x", "long_rows")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def run(self, max_trace=4096):
+        res = CResults()
+        trace = (CTraceRow * max_trace)()
+        nt = C.c_int(0)
+        self._chk(lib().hprlp_solver_run(self.h, C.byref(res), trace, max_trace, C.byref(nt)))
+        r = Results(res, self.model.m, self.model.n)
+        r.trace = [{f: getattr(trace[i], f) for f, _ in CTraceRow._fields_} for i in range(nt.value)]
+        return r
+
+    def time_iterations(self, warmup, steps, mode=0):
+        t = C.c_double(0); tx = C.c_double(0); ty = C.c_double(0)
+        self._chk(lib().hprlp_solver_time_iterations(self.h, warmup, steps, mode, C.byref(t), C.byref(tx), C.byref(ty)))
+        return dict(total_ms=t.value, xhalf_ms=tx.value, yhalf_ms=ty.value)

@@ -1,0 +1,77 @@
+/*
+ * hprlp_amd.h -- step-level C ABI of the MI355X HPR-LP library (extension of HPRLP.h).
+ *
+ * The reference exposes its solver phases only as C++-linkage functions on a CUDA workspace struct
+ * (reference include/preprocess.h, scaling.h, power_iteration.h, main_iterate.h).  These entry
+ * points expose the same phases over an opaque handle with plain pointers and sizes, so that the
+ * parity tests, bench.py and a multi-GPU launcher can drive them from any language.  Each function
+ * cites the reference function it stands for.  All functions return 0 / a valid value on success
+ * and a negative value (or NULL) on failure with the message available from hprlp_last_error();
+ * none throws across the boundary.
+ */
+#ifndef HPRLP_AMD_H
+#define HPRLP_AMD_H
+
+#include "HPRLP.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hprlp_solver hprlp_solver; /* opaque: device-resident scaled LP + iteration state */
+
+/* One row per residual evaluation = one line of the reference's iteration log (src/HPRLP.cu:207-218). */
+typedef struct hprlp_trace_row {
+    int iter, restart_flag;
+    double err_Rp, err_Rd, primal_obj, dual_obj, gap, kkt, sigma, current_gap, lambda_max;
+} hprlp_trace_row;
+
+const char *hprlp_last_error(void);
+const char *hprlp_backend(void); /* "hip-gfx950" */
+
+/* copy_lpinfo_to_device + allocate_memory (reference src/preprocess.cu:66-256): uploads A, builds A^T
+ * and the wave row-block descriptors, allocates the work vectors.  Does not scale. */
+hprlp_solver *hprlp_solver_create(const LP_info_cpu *model, const HPRLP_parameters *param);
+void hprlp_solver_destroy(hprlp_solver *s);
+void hprlp_solver_set_verbose(hprlp_solver *s, int verbose);
+
+/* scaling() (reference src/scaling.cu:88-216) */
+int hprlp_solver_scale(hprlp_solver *s);
+/* power_method_cusparse() (reference src/power_iteration.cu:20-119); returns lambda (not x1.01) */
+double hprlp_solver_power_iteration(hprlp_solver *s, int max_iter, double tol, int *iters_out);
+/* sigma_0, Halpern reset (reference src/HPRLP.cu:154-167).  sigma<=0: norm_b/norm_c rule. */
+int hprlp_solver_init(hprlp_solver *s, double sigma, double lambda_max);
+/* `normal` normal iterations then, if then_check, one check-variant iteration
+ * (reference update_zx_*_gpu + update_y_*_gpu, src/main_iterate.cu:422-481) */
+int hprlp_solver_iterate(hprlp_solver *s, int normal, int then_check);
+/* compute_residuals() (reference src/main_iterate.cu:229-309):
+ * out = {err_Rp, err_Rd, primal_obj, dual_obj, rel_gap, kkt, weighted_norm (if compute_gap), lambda_max} */
+int hprlp_solver_residuals(hprlp_solver *s, int iter, int compute_gap, double out[8]);
+/* update_sigma + do_restart as if check_restart had raised a flag (reference main_iterate.cu:312-404);
+ * in = {current_gap, best_gap, best_sigma, err_Rd, err_Rp, rel_gap}; returns new sigma in *sigma_out */
+int hprlp_solver_restart(hprlp_solver *s, const double in[6], double *sigma_out);
+/* compute_weighted_norm() (reference main_iterate.cu:486-515) */
+double hprlp_solver_weighted_norm(hprlp_solver *s);
+/* the whole loop from the current state (reference src/HPRLP.cu:154-310) + collect_solution */
+int hprlp_solver_run(hprlp_solver *s, HPRLP_results *out, hprlp_trace_row *trace, int max_trace, int *n_trace);
+
+/* Named device vectors: x y x_hat x_bar y_bar z_bar x_temp y_temp y_obj last_x last_y AL AU l u c
+ * row_norm col_norm A_val AT_val.  get returns the length (or -1); cap is the capacity of out. */
+long hprlp_solver_get_vector(hprlp_solver *s, const char *name, double *out, long cap);
+int hprlp_solver_set_vector(hprlp_solver *s, const char *name, const double *in, long len);
+/* out = {b_scale, c_scale, norm_b, norm_c, norm_b_org, norm_c_org, sigma, lambda_max,
+ *        setup_time, scaling_time, power_time, power_iters, kx, ky} */
+int hprlp_solver_get_scalars(hprlp_solver *s, double out[16]);
+/* out = {m, n, nnz, row blocks of A, row blocks of A^T, grid of y-half, grid of x-half, long rows} */
+int hprlp_solver_info(hprlp_solver *s, long out[8]);
+
+/* Timed normal iterations for bench.py.  mode 0: graph replay as the product runs it; wall time by
+ * HIP events around the whole batch.  mode 1: eager launches with an event pair around every kernel
+ * on the solver's stream; xhalf_ms / yhalf_ms are the SUMS of the x-half / y-half kernel durations. */
+int hprlp_solver_time_iterations(hprlp_solver *s, int warmup, int steps, int mode, double *total_ms,
+                                 double *xhalf_ms, double *yhalf_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPRLP_AMD_H */

@@ -1,0 +1,53 @@
+"""pytest configuration: registers the `gpu` marker and loads the package by path
+(the package directory `hpr-lp-c_amd/` is not a valid Python identifier)."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _load(name, rel):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+hprlp = _load("hprlp_amd", os.path.join("hpr-lp-c_amd", "hprlp.py"))
+lpgen = _load("hprlp_lpgen", os.path.join("hpr-lp-c_amd", "lpgen.py"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """GPU tests fail loudly (never skip silently) when the HIP library is missing."""
+    if not os.path.exists(hprlp.LIB_PATH):
+        pytest.fail("lib/libhprlp.so missing on a GPU run: build with `make`")
+    if not _have_gpu():
+        pytest.fail("no /dev/kfd: -m gpu tests need the MI355X box")
+    return hprlp.lib()
+
+
+INF = float("inf")
+
+
+@pytest.fixture(scope="session")
+def model_mps_arrays():
+    """The reference's only known-answer LP (reference data/model.mps, examples/c/example_direct_lp.c:20-33)."""
+    return dict(m=2, n=2, rowptr=[0, 2, 4], colind=[0, 1, 0, 1], values=[1.0, 2.0, 3.0, 1.0],
+                AL=[-INF, -INF], AU=[10.0, 12.0], l=[0.0, 0.0], u=[INF, INF], c=[-3.0, -5.0])

@@ -1,0 +1,44 @@
+"""End-to-end parity of the HIP solve against the CPU oracle and against known optima (GPU)."""
+import numpy as np
+import pytest
+
+from conftest import hprlp, lpgen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(lp):
+    return hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                lp["l"], lp["u"], lp["c"])
+
+
+def test_model_mps_known_answer(gpu, model_mps_arrays):
+    """reference examples/cpp/example_direct_lp.cpp:14: x=(2.8,3.6), obj=-26.4."""
+    a = model_mps_arrays
+    model = _model(a)
+    res = model.solve(hprlp.Parameters(stop_tol=1e-9, use_presolve=False))
+    ref = O.solve(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"],
+                  params=O.Params.default(stop_tol=1e-9))
+    assert res.status == "OPTIMAL"
+    assert abs(res.primal_obj + 26.4) < 1e-6
+    np.testing.assert_allclose(res.x, [2.8, 3.6], atol=1e-6)
+    np.testing.assert_allclose(res.y, [-2.4, -0.2], atol=1e-6)
+    assert res.iter == ref["iter"]
+    np.testing.assert_allclose(res.x, ref["x"], rtol=0, atol=1e-10)
+    model.free()
+
+
+@pytest.mark.parametrize("m,n,nnz,seed", [(50, 80, 400, 11), (300, 500, 3000, 12)])
+def test_planted_lp_matches_oracle(gpu, m, n, nnz, seed):
+    lp = lpgen.planted_lp(m, n, nnz, seed)
+    model = _model(lp)
+    tol = 1e-6
+    res = model.solve(hprlp.Parameters(stop_tol=tol, use_presolve=False))
+    ref = O.solve(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                  params=O.Params.default(stop_tol=tol))
+    assert res.status == "OPTIMAL"
+    assert abs(res.primal_obj - lp["obj_star"]) / (1 + abs(lp["obj_star"])) <= 10 * tol
+    # same schedule => same iteration count unless a thresholded decision forks (FP64 reduction order)
+    assert abs(res.iter - ref["iter"]) <= 0.2 * ref["iter"] + 150
+    model.free()
