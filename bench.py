@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""bench.py -- HPR iterations/sec (FP64) of the MI355X HPR-LP hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one HPR iteration (x-half + y-half, reference src/main_iterate.cu:434-481) on synthetic
+data already resident in HBM.  Default workload: BASELINE.json config 5, the banded-random 10M x 10M,
+~200M-nnz LP (the largest configuration; it fits one MI355X, so N=1 runs all of it and N>1
+row-partitions the SAME problem: strong scaling).  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+H = _load("hprlp_amd", os.path.join("hpr-lp-c_amd", "hprlp.py"))
+G = _load("hprlp_lpgen", os.path.join("hpr-lp-c_amd", "lpgen.py"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
+
+WORKLOADS = {
+    # name: (m, n, per_row, band)
+    "c5": (10_000_000, 10_000_000, 20, 100_000),
+    "c5_eighth": (1_250_000, 10_000_000, 20, 100_000),
+    "c5_small": (1_000_000, 1_000_000, 20, 10_000),
+    "c5_tiny": (100_000, 100_000, 20, 1_000),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def gen_banded(m, n, per_row, band, seed=5, row0=0, rows=None, threads=0):
+    rows = m - row0 if rows is None else rows
+    rp = np.zeros(rows + 1, np.int32)
+    ci = np.zeros(rows * per_row, np.int32)
+    v = np.zeros(rows * per_row, np.float64)
+    L = H.lib()
+    L.hprlp_gen_banded_csr.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int, H.c_int_p,
+                                       H.c_int_p, H.c_dbl_p, C.c_int]
+    rc = L.hprlp_gen_banded_csr(m, n, per_row, band, seed, row0, rows, rp.ctypes.data_as(H.c_int_p),
+                                ci.ctypes.data_as(H.c_int_p), v.ctypes.data_as(H.c_dbl_p), threads)
+    if rc != 0:
+        raise RuntimeError(H.last_error())
+    return rp, ci, v
+
+
+def banded_lp(m, n, per_row, band, seed=5):
+    """Planted LP on the banded matrix: box 0<=x<=u, half equality rows, half active/inactive '<=' rows."""
+    from scipy import sparse
+    rp, ci, v = gen_banded(m, n, per_row, band, seed)
+    A = sparse.csr_matrix((v, ci, rp), shape=(m, n), copy=False)
+    rng = np.random.default_rng(seed + 1)
+    at_lower = rng.random(n) < 0.5
+    x = np.where(at_lower, 0.0, rng.uniform(0.5, 2.0, size=n))
+    z = np.where(at_lower, rng.uniform(0.0, 1.0, size=n), 0.0)
+    l = np.zeros(n)
+    u = np.where(rng.random(n) < 0.2, x + rng.uniform(0.5, 2.0, size=n), np.inf)
+    b = A @ x
+    is_eq = rng.random(m) < 0.5
+    active = rng.random(m) < 0.6
+    AL = np.where(is_eq, b, -np.inf)
+    AU = np.where(is_eq | active, b, b + rng.uniform(0.5, 2.0, size=m))
+    y = np.where(is_eq, rng.normal(size=m), np.where(active, -rng.uniform(0.0, 1.0, size=m), 0.0))
+    c = A.T @ y + z
+    return dict(m=m, n=n, rowptr=rp, colind=ci, values=v, AL=AL, AU=AU, l=l, u=u, c=c, obj_star=float(c @ x))
+
+
+def bytes_per_iteration(m, n, nnz):
+    """algorithmic HBM bytes of one fused normal HPR iteration."""
+    return 24 * nnz + 4 * (m + n + 2) + 8 * (7 * n + 5 * m) + 8 * (m + n)
+
+
+def bytes_x_half(m, n, nnz):
+    """x-half launch: A^T CSR (12 B/nnz + row pointers), gather of y once (8m), x,c,l,u,last_x read and
+    x,x_hat written (7 n-vectors)."""
+    return 12 * nnz + 4 * (n + 1) + 8 * m + 56 * n
+
+
+def bytes_y_half(m, n, nnz):
+    return 12 * nnz + 4 * (m + 1) + 8 * n + 40 * m
+
+
+def cpu_baseline(name, steps_budget_s=12.0):
+    """Oracle (CPU port) timed on the host cores on a bounded sample of the same workload: the banded
+    generator at 1/16 of the rows/columns (same nnz per row); work per iteration is linear in nnz,
+    so iterations/sec of the full workload = sample rate / 16."""
+    from oracle import oracle as O
+    m, n, per_row, band = WORKLOADS[name]
+    shrink = 16 if m >= 1_000_000 else 1
+    ms, ns = m // shrink, n // shrink
+    rp, ci, v = gen_banded(ms, ns, per_row, max(band // shrink, 1), seed=5)
+    trp, tci, tv = O.transpose(ms, ns, rp, ci, v)
+    lp = O.ScaledLP.__new__(O.ScaledLP)
+    lp.m, lp.n = ms, ns
+    lp.Arp, lp.Aci, lp.Av = rp, ci, v
+    lp.ATrp, lp.ATci, lp.ATv = trp, np.ascontiguousarray(tci), np.ascontiguousarray(tv)
+    rng = np.random.default_rng(1)
+    lp.AL = -np.ones(ms); lp.AU = np.ones(ms); lp.l = np.zeros(ns); lp.u = np.full(ns, 10.0); lp.c = rng.normal(size=ns)
+    t1 = lp.time_iterations(1.0, 50.0, 2)  # warm caches, estimate
+    iters = max(3, int(steps_budget_s / max(t1 / 2, 1e-6)))
+    iters = min(iters, 2000)
+    t = lp.time_iterations(1.0, 50.0, iters)
+    rate = iters / t
+    return {"value": rate / shrink, "unit": "iterations/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"oracle/hpr_oracle.c normal iterations on the same banded generator at {ms}x{ns}, "
+                      f"{len(v)} nnz (1/{shrink} of the workload), {iters} iterations in {t:.1f}s = {rate:.2f} it/s; "
+                      f"value = that / {shrink} (work per iteration is linear in nnz)"}
+
+
+def side_configs():
+    """BASELINE configs 2 and 3 (shape-matched stand-ins) on one GPU: it/s by graph replay and time-to-1e-4."""
+    out = {}
+    for key, lp in (("c2_25fv47_like", G.c2_25fv47_like()), ("c3_pds20_like", G.c3_pds20_like())):
+        model = H.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+        s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
+        s.scale()
+        lam, _ = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        t = s.time_iterations(200, 2000, 0)
+        nnz = len(lp["values"])
+        rate = 2000 / (t["total_ms"] * 1e-3)
+        s.close()
+        s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
+        s.scale()
+        lam, _ = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        t0 = time.time()
+        r = s.run()
+        tt = time.time() - t0
+        out[key] = {"m": lp["m"], "n": lp["n"], "nnz": nnz, "iterations_per_s": rate,
+                    "GBps_algorithmic": bytes_per_iteration(lp["m"], lp["n"], nnz) * rate / 1e9,
+                    "time_to_1e-4_s": tt + s.scalars()["power_time"], "iters_to_1e-4": r.iter, "status": r.status,
+                    "rel_obj_err": abs(r.primal_obj - lp["obj_star"]) / (1 + abs(lp["obj_star"]))}
+        s.close()
+        model.free()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=os.environ.get("HPRLP_BENCH_WORKLOAD", "c5"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-side", action="store_true", help="skip the config-2/3 side measurements")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # gloo carries only the bootstrap (RCCL unique id), barriers and the max-over-ranks of the
+        # timing; the data path is RCCL inside lib/libhprlp.so.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+
+    m, n, per_row, band = WORKLOADS[args.workload]
+    t0 = time.time()
+    lp = banded_lp(m, n, per_row, band)
+    nnz = len(lp["values"])
+    if rank == 0:
+        log(f"[bench] generated {args.workload}: {m}x{n}, nnz={nnz} in {time.time() - t0:.1f}s")
+    model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    lp.pop("rowptr"); lp.pop("colind"); lp.pop("values")
+    prm = H.Parameters(stop_tol=1e-4, use_presolve=False, device_number=local_rank)
+    t0 = time.time()
+    if world > 1:
+        uid = np.zeros(128, np.uint8)
+        if rank == 0 and H.lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 128) != 0:
+            raise RuntimeError(H.last_error())
+        tu = torch.from_numpy(uid)
+        dist.broadcast(tu, src=0)
+        H.lib().hprlp_solver_create_dist.restype = C.c_void_p
+        H.lib().hprlp_solver_create_dist.argtypes = [C.POINTER(H.CLPInfo), C.POINTER(H.CParameters), C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_int]
+        s = H.Solver.__new__(H.Solver)
+        s.model = model
+        cp = prm.to_c()
+        s.h = H.lib().hprlp_solver_create_dist(model._ptr, C.byref(cp), rank, world, uid.ctypes.data_as(C.c_void_p), 128)
+        if not s.h:
+            raise RuntimeError("hprlp_solver_create_dist failed: " + H.last_error())
+    else:
+        s = H.Solver(model, prm)
+    model.free()
+    s.scale()
+    lam, pw_it = s.power_iteration()
+    s.init(-1.0, lam * 1.01)
+    sc = s.scalars()
+    if rank == 0:
+        log(f"[bench] setup {time.time() - t0:.1f}s (device setup {sc['setup_time']:.2f}s, scaling {sc['scaling_time']:.2f}s, "
+            f"power iteration {sc['power_time']:.2f}s / {pw_it} its, lambda_max={lam:.4g})")
+
+    # ---- timed region: warmup W, then exactly K iterations between barrier+synchronize pairs
+    s.iterate(args.warmup)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    tm = s.time_iterations(0, args.steps, 1)  # eager launches with HIP events around every kernel
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist:
+        te = torch.tensor([elapsed, tm["xhalf_ms"], tm["yhalf_ms"]], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed, tm["xhalf_ms"], tm["yhalf_ms"] = float(te[0]), float(te[1]), float(te[2])
+
+    # sanity: the iterate must be finite and the KKT error must not have blown up
+    s.iterate(0, True)
+    res = s.residuals(args.warmup + args.steps + 1)
+    ok = np.isfinite(res["kkt"])
+
+    out = None
+    if rank == 0:
+        P = world
+        # per-rank algorithmic bytes of the dominant kernel (x-half): 1/P of the matrix and streams, full gather vector
+        bx = (12 * nnz + 4 * (n + P) + 56 * n) / P + 8 * m
+        x_ms = tm["xhalf_ms"] / args.steps
+        y_ms = tm["yhalf_ms"] / args.steps
+        achieved = bx / (x_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf) and P == 1:
+            try:
+                traffic = json.load(open(tf)).get(args.workload, {}).get("xhalf_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "HPR iterations/sec (FP64)", "value": args.steps / elapsed, "unit": "iterations/s",
+            "n_gpus": P, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5: banded-random CSR LP {m}x{n}, nnz={nnz} "
+                                   f"({'row-partitioned over %d GPUs, 2 RCCL all-gathers per iteration' % P if P > 1 else 'one GPU'})",
+                       "m": m, "n": n, "nnz": nnz, "parallelism": f"rowpart{P}",
+                       "bytes_per_iteration_algorithmic": bytes_per_iteration(m, n, nnz)},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_fused<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": bx, "avg_launch_ms": x_ms,
+                         "yhalf_avg_launch_ms": y_ms,
+                         "yhalf_GBps": ((12 * nnz + 4 * (m + P) + 40 * m) / P + 8 * n) / (y_ms * 1e-3) / 1e9,
+                         "iteration_GBps": bytes_per_iteration(m, n, nnz) / P / (1e-3 * (x_ms + y_ms)) / 1e9},
+            "kkt_after_run": res["kkt"], "finite": bool(ok),
+        }
+    s.close()
+    if rank == 0 and world == 1:
+        if not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload)
+            except Exception as e:  # the oracle is only a reported baseline; never fail the bench on it
+                out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if not args.no_side:
+            try:
+                out["other_configs"] = side_configs()
+            except Exception as e:
+                out["other_configs"] = {"error": str(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

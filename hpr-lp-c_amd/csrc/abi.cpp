@@ -5,6 +5,7 @@
 #include <iostream>
 
 #include "hprlp_amd.h"
+#include "dist.h"
 #include "solver.h"
 #include "version.h"
 
@@ -12,6 +13,8 @@ using namespace hprlp;
 
 struct hprlp_solver {
     Solver s;
+    Comm *comm = nullptr;  // owned; destroyed after the solver's device state
+    ~hprlp_solver() {}
 };
 
 static HPRLP_results make_error_result(const char *status) {
@@ -120,9 +123,44 @@ extern "C" hprlp_solver *hprlp_solver_create(const LP_info_cpu *model, const HPR
     }
 }
 
+extern "C" hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank,
+                                                  int size, const void *unique_id, int id_bytes) {
+    if (!model) {
+        set_last_error("null model");
+        return nullptr;
+    }
+    hprlp_solver *h = nullptr;
+    hprlp_shard sh;
+    std::memset(&sh, 0, sizeof(sh));
+    try {
+        HPRLP_parameters dflt;
+        const HPRLP_parameters *p = param ? param : &dflt;
+        if (hprlp_extract_shard(model, rank, size, &sh) != 0) throw std::runtime_error(last_error_cstr());
+        h = new hprlp_solver();
+        h->s.verbose = false;
+        if (size > 1) h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
+        h->s.setup_shard(sh.m, sh.n, sh.row_off, sh.m_loc, sh.col_off, sh.n_loc, sh.A_rowptr, sh.A_col, sh.A_val,
+                         sh.AT_rowptr, sh.AT_col, sh.AT_val, sh.AL, sh.AU, sh.l, sh.u, sh.c, sh.obj_constant, p, h->comm);
+        hprlp_free_shard(&sh);
+        return h;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        hprlp_free_shard(&sh);
+        if (h) {
+            Comm *c = h->comm;
+            delete h;
+            delete c;
+        }
+        return nullptr;
+    }
+}
+
 extern "C" void hprlp_solver_destroy(hprlp_solver *h) {
     try {
+        if (!h) return;
+        Comm *c = h->comm;
         delete h;
+        delete c;
     } catch (...) {
     }
 }

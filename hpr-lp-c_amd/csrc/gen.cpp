@@ -1,0 +1,92 @@
+// gen.cpp -- deterministic generator of the banded-random benchmark matrix (BASELINE.json config 5:
+// "Synthetic random CSR 10M x 10M, ~200M nnz").  Benchmark/test utility, not part of the solve path.
+// Every row is a pure function of (seed, row), so any rank can produce any row range on its own.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "hprlp_amd.h"
+
+namespace {
+
+inline uint64_t mix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+struct RowRng {
+    uint64_t state;
+    RowRng(uint64_t seed, uint64_t row) : state(mix64(seed * 0x2545F4914F6CDD1DULL + row)) {}
+    uint64_t next() { return state = mix64(state); }
+    double uniform() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+    // uniform integer in [0, bound)
+    uint64_t below(uint64_t bound) { return static_cast<uint64_t>(uniform() * static_cast<double>(bound)); }
+    double normal() {
+        const double u1 = (static_cast<double>(next() >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+        const double u2 = uniform();
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925286766559 * u2);
+    }
+};
+
+void gen_rows(int m, int n, int per_row, int band, uint64_t seed, int row0, int r_begin, int r_end, int *col,
+              double *val) {
+    const int width = std::min(2 * band + 1, n);
+    std::vector<int> c(static_cast<size_t>(per_row));
+    for (int r = r_begin; r < r_end; ++r) {
+        const int grow = row0 + r;
+        RowRng rng(seed, static_cast<uint64_t>(grow));
+        const long center = (static_cast<long>(grow) * n) / m;
+        long base = center - band;
+        if (base < 0) base = 0;
+        if (base > n - width) base = n - width;
+        for (int k = 0; k < per_row; ++k) {
+            const bool far = rng.uniform() < 0.05;
+            c[k] = far ? static_cast<int>(rng.below(static_cast<uint64_t>(n)))
+                       : static_cast<int>(base + static_cast<long>(rng.below(static_cast<uint64_t>(width))));
+        }
+        std::sort(c.begin(), c.end());
+        for (int k = 1; k < per_row; ++k)
+            if (c[k] <= c[k - 1]) c[k] = c[k - 1] + 1;  // make the row's columns distinct
+        if (c[per_row - 1] >= n) {                      // pushed past the last column: pack against it
+            int top = n - 1;
+            for (int k = per_row - 1; k >= 0 && c[k] > top; --k, --top) c[k] = top;
+        }
+        int *co = col + static_cast<size_t>(r) * per_row;
+        double *vo = val + static_cast<size_t>(r) * per_row;
+        for (int k = 0; k < per_row; ++k) {
+            co[k] = c[k];
+            vo[k] = rng.normal();
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hprlp_gen_banded_csr(int m, int n, int per_row, int band, unsigned long long seed, int row0, int rows,
+                                    int *rowptr, int *col, double *val, int nthreads) {
+    try {
+        if (m <= 0 || n <= 0 || per_row <= 0 || per_row > n || band < 0 || row0 < 0 || rows < 0 || row0 + rows > m ||
+            static_cast<long>(rows) * per_row > 2147483647L)
+            throw std::runtime_error("hprlp_gen_banded_csr: bad arguments");
+        for (int r = 0; r <= rows; ++r) rowptr[r] = r * per_row;
+        if (nthreads <= 0) nthreads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+        nthreads = std::min(nthreads, std::max(1, rows / 4096));
+        std::vector<std::thread> th;
+        const int chunk = (rows + nthreads - 1) / std::max(nthreads, 1);
+        for (int t = 0; t < nthreads; ++t) {
+            const int b = t * chunk, e = std::min(rows, b + chunk);
+            if (b >= e) break;
+            th.emplace_back(gen_rows, m, n, per_row, band, static_cast<uint64_t>(seed), row0, b, e, col, val);
+        }
+        for (auto &t : th) t.join();
+        return 0;
+    } catch (const std::exception &e) {
+        hprlp::set_last_error(e.what());
+        return -1;
+    }
+}

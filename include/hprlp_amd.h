@@ -71,6 +71,41 @@ int hprlp_solver_info(hprlp_solver *s, long out[8]);
 int hprlp_solver_time_iterations(hprlp_solver *s, int warmup, int steps, int mode, double *total_ms,
                                  double *xhalf_ms, double *yhalf_ms);
 
+/* ---- benchmark utility -------------------------------------------------------------------------
+ * Rows [row0,row0+rows) of the banded-random matrix of BASELINE.json config 5 (per_row entries per
+ * row, 95 % within +-band of the diagonal, 5 % anywhere, N(0,1) values).  Each row depends only on
+ * (seed,row).  rowptr has rows+1 entries, col/val rows*per_row.  Not part of the solve path. */
+int hprlp_gen_banded_csr(int m, int n, int per_row, int band, unsigned long long seed, int row0, int rows,
+                         int *rowptr, int *col, double *val, int nthreads);
+
+/* ---- row-partitioned multi-GPU solve (new design; the reference is single-GPU) -----------------
+ * Rank p owns rows [p*ceil(m/P),...) of A with y/AL/AU and rows [p*ceil(n/P),...) of A^T with
+ * x/c/l/u; one in-place RCCL all-gather of the fresh vector slice follows each half-step. */
+typedef struct hprlp_shard {
+    int m, n;              /* global sizes */
+    int row_off, m_loc;    /* rows of A owned by the rank */
+    int col_off, n_loc;    /* rows of A^T (= columns of A) owned by the rank */
+    int *A_rowptr, *A_col; /* m_loc x n, global column indices */
+    double *A_val;
+    int *AT_rowptr, *AT_col; /* n_loc x m, global column (= row of A) indices */
+    double *AT_val;
+    double *AL, *AU;       /* m_loc */
+    double *l, *u, *c;     /* n_loc */
+    double obj_constant;
+} hprlp_shard;
+
+/* block partition of `total` items over `parts` ranks: returns the chunk size ceil(total/parts) */
+int hprlp_partition(int total, int parts, int rank, int *offset, int *count);
+/* host only: cut this rank's shard out of a full model (arrays malloc'd; release with hprlp_free_shard) */
+int hprlp_extract_shard(const LP_info_cpu *model, int rank, int size, hprlp_shard *out);
+void hprlp_free_shard(hprlp_shard *s);
+/* rank 0: create the 128-byte RCCL unique id; the launcher broadcasts it (bench.py: torch.distributed) */
+int hprlp_dist_unique_id(void *out, int bytes);
+/* every rank: create the solver for its shard of `model` (param->device_number selects the GPU).
+ * get_vector/run then return this rank's slices; scalars/residuals are global. */
+hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
+                                       const void *unique_id, int id_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,144 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol the headers declare, and the
+public structs have the layout of SURVEY.md Appendix B (Julia binds them by raw layout)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, hprlp
+
+INC = os.path.join(ROOT, "include")
+
+
+def declared_functions():
+    names = set()
+    for h in ("HPRLP.h", "batched_solver.h", "hprlp_amd.h"):
+        text = open(os.path.join(INC, h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = "\n".join(ln for ln in text.split("\n") if not ln.lstrip().startswith("#"))
+        for mm in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text):
+            names.add(mm.group(1))
+    names -= {"HPRLP_DEFAULT_ARG", "defined"}
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    L = hprlp.lib()
+    fns = declared_functions()
+    assert {"create_model_from_arrays", "create_model_from_mps", "solve", "free_model", "HPRLP_main_solve",
+            "solve_batched", "free_batched_results"} <= set(fns)
+    missing = [f for f in fns if not hasattr(L, f)]
+    assert not missing, missing
+    assert L.hprlp_backend().decode() == "hip-gfx950"
+
+
+def test_ctypes_mirror_sizes():
+    assert C.sizeof(hprlp.CParameters) == 40
+    assert C.sizeof(hprlp.CResults) == 160
+    assert C.sizeof(hprlp.CBatchedResults) == 112
+    assert C.sizeof(hprlp.CLPInfo) == 64
+    assert C.sizeof(hprlp.CSparseMatrix) == 40
+    assert hprlp.CResults.status.offset == 72 and hprlp.CResults.x.offset == 136
+    assert hprlp.CParameters.CUSPARSE_spmv.offset == 32 and hprlp.CParameters.use_presolve.offset == 38
+    assert hprlp.CBatchedResults.status.offset == 72 and hprlp.CBatchedResults.time.offset == 80
+
+
+PROBE = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "HPRLP.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu\n", sizeof(HPRLP_parameters), sizeof(HPRLP_results), sizeof(HPRLP_batched_results),
+           sizeof(LP_info_cpu), sizeof(sparseMatrix));
+    printf("%zu %zu %zu %zu\n", offsetof(HPRLP_parameters, stop_tol), offsetof(HPRLP_parameters, check_iter),
+           offsetof(HPRLP_results, status), offsetof(HPRLP_batched_results, iter));
+    HPRLP_parameters p = HPRLP_PARAMETERS_DEFAULT;
+    printf("%d %g %g %d %d %d %d\n", p.max_iter, p.stop_tol, p.time_limit, p.check_iter, (int)p.use_CR_scaling,
+           (int)p.use_presolve, (int)p.CUSPARSE_spmv);
+    return 0;
+}
+"""
+
+
+@pytest.mark.parametrize("cc,std", [("gcc", "-std=c11"), ("g++", "-std=c++11")])
+def test_headers_compile_without_hip_and_keep_layout(cc, std):
+    """The public headers must compile with a plain host compiler, as C and as C++11 (pybind/MEX/Julia
+    builds of the reference bindings use nothing else) and give the Appendix-B layout."""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "probe.c" if cc == "gcc" else "probe.cpp")
+        open(src, "w").write(PROBE if cc == "gcc" else PROBE.replace("HPRLP_parameters p = HPRLP_PARAMETERS_DEFAULT;", "HPRLP_parameters p;"))
+        exe = os.path.join(d, "probe")
+        subprocess.check_call([cc, std, "-I", INC, src, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split("\n")
+    assert out[0].split() == ["40", "160", "112", "64", "40"]
+    assert out[1].split() == ["8", "28", "72", "64"]
+    assert out[2].split() == ["2147483647", "0.0001", "3600", "150", "1", "1", "0"]
+
+
+def test_model_from_arrays_host_behaviour(model_mps_arrays):
+    a = model_mps_arrays
+    m = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"])
+    assert (m.m, m.n, m.obj_constant) == (2, 2, 0.0)
+    rp, ci, v = m.csr()
+    assert list(rp) == [0, 2, 4] and list(ci) == [0, 1, 0, 1] and list(v) == [1, 2, 3, 1]
+    vec = m.vectors()
+    assert np.isinf(vec["AL"]).all() and list(vec["AU"]) == [10, 12] and np.isinf(vec["u"]).all()
+    m.free()
+    # CSC input of the same matrix (column pointers) gives the same stored CSR (reference HPRLP.cu:354-396)
+    m2 = hprlp.Model.from_csr(2, 2, [0, 2, 4], [0, 1, 0, 1], [1.0, 3.0, 2.0, 1.0], a["AL"], a["AU"], a["l"], a["u"], a["c"], is_csc=True)
+    rp, ci, v = m2.csr()
+    assert list(rp) == [0, 2, 4] and list(ci) == [0, 1, 0, 1] and list(v) == [1, 2, 3, 1]
+    m2.free()
+
+
+@pytest.mark.parametrize("bad", ["m0", "nnz0", "rowptr0", "rowptr_end", "null", "col_range", "decreasing"])
+def test_model_from_arrays_rejects_bad_input(bad, model_mps_arrays, capfd):
+    a = dict(model_mps_arrays)
+    L = hprlp.lib()
+    rp = np.array(a["rowptr"], np.int32); ci = np.array(a["colind"], np.int32); v = np.array(a["values"])
+    AL = np.array(a["AL"]); AU = np.array(a["AU"]); l = np.array(a["l"]); u = np.array(a["u"]); c = np.array(a["c"])
+    m, n, nnz = 2, 2, 4
+    P = lambda x: x.ctypes.data_as(hprlp.c_dbl_p)
+    I = lambda x: x.ctypes.data_as(hprlp.c_int_p)
+    pc = P(c)
+    if bad == "m0": m = 0
+    if bad == "nnz0": nnz = 0
+    if bad == "rowptr0": rp[0] = 1
+    if bad == "rowptr_end": rp[2] = 3
+    if bad == "null": pc = None
+    if bad == "col_range": ci[3] = 2
+    if bad == "decreasing": rp[1] = 5
+    ptr = L.create_model_from_arrays(m, n, nnz, I(rp), I(ci), P(v), P(AL), P(AU), P(l), P(u), pc, False)
+    assert not ptr                                   # NULL + message on stderr (reference HPRLP.cu:329-337)
+    assert "[error]" in capfd.readouterr().err
+    L.free_model(None)                               # NULL is a no-op (reference HPRLP.cu:530)
+
+
+def test_gpu_calls_fail_loudly_without_gpu(model_mps_arrays):
+    """No CPU fallback exists: on a box without a GPU the solve returns status ERROR, it does not
+    silently compute on the host."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    a = model_mps_arrays
+    m = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"])
+    r = m.solve(hprlp.Parameters(use_presolve=False))
+    assert r.status == "ERROR" and r.x is None
+    with pytest.raises(RuntimeError):
+        hprlp.Solver(m)
+    m.free()
+
+
+def test_banded_generator_is_row_consistent():
+    import bench_helpers as bh
+    rp, ci, v = bh.gen_banded(5000, 5000, 20, 100, seed=7)
+    rp2, ci2, v2 = bh.gen_banded(5000, 5000, 20, 100, seed=7, row0=1200, rows=800)
+    assert np.array_equal(ci[1200 * 20:2000 * 20], ci2) and np.array_equal(v[1200 * 20:2000 * 20], v2)
+    c = ci.reshape(5000, 20)
+    assert (np.diff(c, axis=1) > 0).all() and c.min() >= 0 and c.max() < 5000
+    near = np.abs(c - np.arange(5000)[:, None]) <= 121
+    assert 0.90 < near.mean() < 0.99

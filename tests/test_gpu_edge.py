@@ -1,0 +1,153 @@
+"""Edge cases of the boundary on the GPU: ragged/empty rows, infinite and free bounds, CSC input,
+limits and error statuses (behaviour of reference src/HPRLP.cu:321-524, main_iterate.cu:406-420)."""
+import numpy as np
+import pytest
+from scipy import sparse
+from scipy.optimize import linprog
+
+from conftest import hprlp, lpgen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+INF = np.inf
+
+
+def highs(A, AL, AU, l, u, c):
+    """Independent optimum: split AL<=Ax<=AU into equality / one-sided rows for HiGHS."""
+    A = sparse.csr_matrix(A)
+    eq = np.isfinite(AL) & np.isfinite(AU) & (AL == AU)
+    ub_rows, ub_rhs = [], []
+    for i in np.where(~eq)[0]:
+        if np.isfinite(AU[i]):
+            ub_rows.append(A[i]); ub_rhs.append(AU[i])
+        if np.isfinite(AL[i]):
+            ub_rows.append(-A[i]); ub_rhs.append(-AL[i])
+    kw = {}
+    if ub_rows:
+        kw.update(A_ub=sparse.vstack(ub_rows), b_ub=np.array(ub_rhs))
+    if eq.any():
+        kw.update(A_eq=A[eq], b_eq=AU[eq])
+    bounds = [(None if not np.isfinite(a) else a, None if not np.isfinite(b) else b) for a, b in zip(l, u)]
+    r = linprog(c, bounds=bounds, method="highs", **kw)
+    assert r.status == 0
+    return r.fun
+
+
+def solve(A, AL, AU, l, u, c, **kw):
+    prm = hprlp.Parameters(use_presolve=False, **kw)
+    return hprlp.solve(A, np.asarray(AL, float), np.asarray(AU, float), np.asarray(l, float), np.asarray(u, float),
+                       np.asarray(c, float), prm)
+
+
+def test_empty_rows_and_columns(gpu):
+    rng = np.random.default_rng(1)
+    A = sparse.random(40, 60, density=0.08, random_state=3, format="lil")
+    A[5, :] = 0; A[17, :] = 0          # empty rows (0 within [AL,AU])
+    A[:, 9] = 0; A[:, 33] = 0          # empty columns (bounded, so the LP stays bounded)
+    A = sparse.csr_matrix(A); A.eliminate_zeros()
+    x0 = rng.uniform(0, 1, 60)
+    b = A @ x0
+    AL = np.full(40, -INF); AU = b + 0.5
+    AL[5] = -1.0; AU[5] = 2.0; AL[17] = 0.0; AU[17] = 0.0
+    c = rng.normal(size=60)
+    l = np.zeros(60); u = np.full(60, 3.0)
+    r = solve(A, AL, AU, l, u, c, stop_tol=1e-8)
+    assert r.status == "OPTIMAL"
+    want = highs(A, AL, AU, l, u, c)
+    assert abs(r.primal_obj - want) <= 1e-6 * (1 + abs(want))
+
+
+def test_free_variables_and_two_sided_rows(gpu):
+    rng = np.random.default_rng(2)
+    A = sparse.random(50, 30, density=0.2, random_state=4, format="csr")
+    x0 = rng.normal(size=30)
+    b = A @ x0
+    AL = b - rng.uniform(0.1, 1.0, 50); AU = b + rng.uniform(0.1, 1.0, 50)   # ranged rows
+    c = A.T @ rng.normal(size=50) * 0.1
+    l = np.full(30, -INF); u = np.full(30, INF)                               # all free
+    l[:5] = -2.0; u[5:10] = 2.0                                               # lower-only / upper-only mixes
+    r = solve(A, AL, AU, l, u, c, stop_tol=1e-8)
+    want = highs(A, AL, AU, l, u, c)
+    assert r.status == "OPTIMAL"
+    assert abs(r.primal_obj - want) <= 1e-6 * (1 + abs(want))
+
+
+def test_row_length_boundaries(gpu):
+    """Rows of 255/256/257/511/512/513/1500 nonzeros cross the stream/vector mode and block limits."""
+    rng = np.random.default_rng(3)
+    n = 2000
+    lens = [255, 256, 257, 511, 512, 513, 1500, 1, 0, 3]
+    rows, cols, vals = [], [], []
+    for i, L in enumerate(lens):
+        cc = np.sort(rng.choice(n, size=L, replace=False))
+        rows += [i] * L; cols += list(cc); vals += list(rng.normal(size=L))
+    A = sparse.csr_matrix((vals, (rows, cols)), shape=(len(lens), n))
+    x0 = rng.uniform(0, 1, n)
+    b = A @ x0
+    AL = b.copy(); AU = b.copy()
+    c = rng.normal(size=n)
+    l = np.zeros(n); u = np.ones(n)
+    r = solve(A, AL, AU, l, u, c, stop_tol=1e-8)
+    want = highs(A, AL, AU, l, u, c)
+    assert r.status == "OPTIMAL"
+    assert abs(r.primal_obj - want) <= 1e-6 * (1 + abs(want))
+    # the same matrix as CSC input must give the same model (reference src/HPRLP.cu:354-396)
+    Ac = sparse.csc_matrix(A)
+    m1 = hprlp.Model.from_csr(len(lens), n, A.indptr, A.indices, A.data, AL, AU, l, u, c)
+    m2 = hprlp.Model.from_csr(len(lens), n, Ac.indptr, Ac.indices, Ac.data, AL, AU, l, u, c, is_csc=True)
+    for a, b2 in zip(m1.csr(), m2.csr()):
+        assert np.array_equal(a, b2)
+    m1.free(); m2.free()
+
+
+def test_one_by_one(gpu):
+    r = solve(np.array([[2.0]]), [1.0], [INF], [0.0], [INF], [3.0], stop_tol=1e-9)   # min 3x, 2x>=1
+    assert r.status == "OPTIMAL" and abs(r.x[0] - 0.5) < 1e-7 and abs(r.primal_obj - 1.5) < 1e-7
+
+
+def test_iteration_limit_and_defaults(gpu, model_mps_arrays):
+    a = model_mps_arrays
+    model = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"],
+                                 a["u"], a["c"])
+    r = model.solve(hprlp.Parameters(max_iter=57, stop_tol=1e-12, use_presolve=False))
+    assert r.status == "ITER_LIMIT" and r.iter == 57 and r.x is not None
+    ref = O.solve(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"],
+                  params=O.Params.default(max_iter=57, stop_tol=1e-12))
+    assert ref["status"] == "ITER_LIMIT" and ref["iter"] == 57
+    np.testing.assert_allclose(r.x, ref["x"], rtol=0, atol=1e-12)
+    r = model.solve(hprlp.Parameters(time_limit=0.0, stop_tol=1e-14, use_presolve=False))
+    assert r.status == "TIME_LIMIT"
+    # param == NULL -> defaults (stop_tol 1e-4): reference src/HPRLP.cu:501-502
+    res = hprlp.lib().solve(model._ptr, None)
+    r = hprlp.Results(res, 2, 2)
+    assert r.status == "OPTIMAL" and r.iter == 180 and abs(r.primal_obj + 26.4) < 1e-2
+    # scaling switches are honoured
+    r = model.solve(hprlp.Parameters(stop_tol=1e-8, use_CR_scaling=False, use_Ruiz_scaling=False,
+                                     use_Pock_Chambolle_scaling=False, use_bc_scaling=False, use_presolve=False))
+    assert r.status == "OPTIMAL" and abs(r.primal_obj + 26.4) < 1e-5
+    model.free()
+
+
+def test_null_model_is_error(gpu):
+    res = hprlp.lib().solve(None, None)
+    assert res.status == b"ERROR" and not res.x and not res.y and not res.z
+
+
+def test_independent_kkt_on_c3(gpu):
+    """BASELINE config 3 size: the reported residuals equal KKT residuals recomputed from x,y,z on the
+    UNSCALED problem with scipy (formulas of reference src/pslp_integration.cpp:499-580)."""
+    lp = lpgen.c3_pds20_like()
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+    r = model.solve(hprlp.Parameters(stop_tol=1e-6, use_presolve=False))
+    assert r.status == "OPTIMAL"
+    A = lp["A"]
+    Ax = A @ r.x
+    rp = np.linalg.norm(np.maximum(np.minimum(lp["AU"] - Ax, 0), lp["AL"] - Ax))
+    bnorm = np.linalg.norm(np.maximum(np.abs(np.where(np.isinf(lp["AL"]), 0, lp["AL"])), np.abs(np.where(np.isinf(lp["AU"]), 0, lp["AU"]))))
+    rd = np.linalg.norm(lp["c"] - A.T @ r.y - r.z)
+    assert rp / (1 + bnorm) <= 1e-6 and rd / (1 + np.linalg.norm(lp["c"])) <= 1e-6
+    assert abs(lp["c"] @ r.x - r.primal_obj) <= 1e-9 * (1 + abs(r.primal_obj))
+    assert abs(r.primal_obj - lp["obj_star"]) <= 1e-5 * (1 + abs(lp["obj_star"]))
+    assert (r.x >= lp["l"] - 1e-9).all() and (r.x <= lp["u"] + 1e-9).all()
+    model.free()

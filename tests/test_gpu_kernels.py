@@ -1,0 +1,224 @@
+"""Step-level parity of the HIP kernels against the CPU oracle, through the C ABI (GPU).
+
+Tolerances (FP64):
+  * basic-op phases (Ruiz / Pock-Chambolle / b-c scaling, stream-mode SpMV + updates): BIT-EXACT --
+    IEEE +,-,*,/,sqrt round identically on both sides and the kernels sum each row in CSR order;
+  * phases that call exp/log (Curtis-Reid) or reduce in a different order (dots, norms, rows longer
+    than 256 handled by a wave tree): relative 1e-12, stated at each assert.
+"""
+import numpy as np
+import pytest
+
+from conftest import hprlp, lpgen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NAMES_N = ("x", "x_hat", "x_bar", "z_bar", "x_temp", "last_x")
+NAMES_M = ("y", "y_bar", "y_obj", "y_temp", "last_y")
+
+
+def make(lp, **params):
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(use_presolve=False, **params)
+    s = hprlp.Solver(model, prm)
+    op = O.Params.default(**{k: int(v) for k, v in params.items() if k.startswith("use_")})
+    ref = O.ScaledLP(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"],
+                     lp["c"], op)
+    return model, s, ref
+
+
+def adopt_gpu_data(s, ref):
+    """Make the oracle iterate on exactly the scaled data the GPU holds (bit-identical inputs)."""
+    for name, arr in (("A_val", ref.Av), ("AT_val", ref.ATv), ("AL", ref.AL), ("AU", ref.AU), ("l", ref.l),
+                      ("u", ref.u), ("c", ref.c), ("row_norm", ref.row_norm), ("col_norm", ref.col_norm)):
+        arr[:] = s.get(name)
+    sc = s.scalars()
+    for k in ("b_scale", "c_scale", "norm_b", "norm_c", "norm_b_org", "norm_c_org"):
+        setattr(ref.sc, k, sc[k])
+
+
+def lp_with_long_rows(seed=5):
+    """300 x 400 LP with one 350-nonzero row and one 290-nonzero column (vector-mode rows in A and A^T)."""
+    from scipy import sparse
+    lp = lpgen.planted_lp(300, 400, 2500, seed)
+    A = lp["A"].tolil()
+    rng = np.random.default_rng(seed)
+    cols = rng.choice(400, size=350, replace=False)
+    A[7, cols] = rng.normal(size=350)
+    rows = rng.choice(300, size=290, replace=False)
+    A[rows, 11] = rng.normal(size=290).reshape(-1, 1)
+    A = sparse.csr_matrix(A)
+    A.sort_indices()
+    out = lpgen._plant(np.random.default_rng(seed + 1), A)
+    out.update(m=300, n=400, A=A, rowptr=A.indptr.astype(np.int32), colind=A.indices.astype(np.int32), values=A.data.copy())
+    return out
+
+
+def test_scaling_without_cr_is_bit_exact(gpu):
+    """Ruiz + Pock-Chambolle use only /, *, sqrt, max, abs: identical bits on both sides.  (b/c scaling
+    divides by 1+||.||, a reduction whose order differs, so it is covered by the rtol test below.)"""
+    lp = lpgen.planted_lp(300, 500, 3000, 21)
+    model, s, ref = make(lp, use_CR_scaling=False, use_bc_scaling=False)
+    s.scale()
+    for name, want in (("A_val", ref.Av), ("AT_val", ref.ATv), ("AL", ref.AL), ("AU", ref.AU), ("l", ref.l),
+                       ("u", ref.u), ("c", ref.c), ("row_norm", ref.row_norm), ("col_norm", ref.col_norm)):
+        got = s.get(name)
+        assert np.array_equal(got, want), name
+    sc = s.scalars()
+    for k in ("b_scale", "c_scale", "norm_b", "norm_c", "norm_b_org", "norm_c_org"):
+        assert abs(sc[k] - getattr(ref.sc, k)) <= 1e-13 * abs(getattr(ref.sc, k)), k  # reduction order
+    s.close(); model.free()
+
+
+def test_scaling_with_cr_matches(gpu):
+    lp = lpgen.planted_lp(300, 500, 3000, 22)
+    model, s, ref = make(lp)
+    s.scale()
+    for name, want in (("A_val", ref.Av), ("AT_val", ref.ATv), ("AL", ref.AL), ("AU", ref.AU), ("l", ref.l),
+                       ("u", ref.u), ("c", ref.c), ("row_norm", ref.row_norm), ("col_norm", ref.col_norm)):
+        got = s.get(name)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin), name
+        assert np.array_equal(got[~fin], want[~fin]), name
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-12, atol=0, err_msg=name)  # device exp/log vs glibc
+    s.close(); model.free()
+
+
+def test_power_iteration_matches(gpu):
+    lp = lpgen.planted_lp(300, 500, 3000, 23)
+    model, s, ref = make(lp)
+    s.scale()
+    adopt_gpu_data(s, ref)
+    lam, it = s.power_iteration()
+    lam_ref, it_ref = ref.power_iteration()
+    assert it == it_ref
+    assert abs(lam - lam_ref) <= 1e-12 * lam_ref  # dots reduce in a different order
+    s.close(); model.free()
+
+
+def run_steps(s, ref, sigma, lam, schedule):
+    """schedule: list of (normal_count, then_check).  Drives GPU and oracle identically."""
+    st = ref.new_state()
+    s.init(sigma, lam)
+    k = 0
+    for normal, chk in schedule:
+        s.iterate(normal, chk)
+        for _ in range(normal):
+            ref.x_half(st, sigma, k, 0)
+            ref.y_half(st, sigma, lam, k, 0)
+            k += 1
+        if chk:
+            ref.x_half(st, sigma, k, 1)
+            ref.y_half(st, sigma, lam, k, 1)
+            k += 1
+    return st
+
+
+def test_iterations_bit_exact_on_short_rows(gpu):
+    lp = lpgen.planted_lp(300, 500, 3000, 24, dense_col_frac=0.0)
+    model, s, ref = make(lp, use_CR_scaling=False)
+    assert np.diff(ref.Arp).max() <= 256 and np.diff(ref.ATrp).max() <= 256
+    s.scale()
+    adopt_gpu_data(s, ref)
+    st = run_steps(s, ref, 0.7, 1.3, [(37, True), (0, True), (9, True), (70, False)])
+    for name in NAMES_N + NAMES_M:
+        assert np.array_equal(s.get(name), st[name]), name
+    sc = s.scalars()
+    assert sc["kx"] == 119 and sc["ky"] == 118
+    s.close(); model.free()
+
+
+def test_iterations_with_long_rows(gpu):
+    lp = lp_with_long_rows()
+    model, s, ref = make(lp, use_CR_scaling=False)
+    assert np.diff(ref.Arp).max() > 256 and np.diff(ref.ATrp).max() > 256
+    s.scale()
+    adopt_gpu_data(s, ref)
+    st = run_steps(s, ref, 0.5, 2.0, [(25, True), (10, True)])
+    for name in NAMES_N + NAMES_M:
+        # rows > 256 nonzeros are reduced by a 64-lane tree instead of sequentially
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+    s.close(); model.free()
+
+
+def test_residuals_and_weighted_norm(gpu):
+    lp = lpgen.planted_lp(300, 500, 3000, 25)
+    model, s, ref = make(lp, use_CR_scaling=False)
+    s.scale()
+    adopt_gpu_data(s, ref)
+    sigma, lam = 0.9, 1.7
+    st = run_steps(s, ref, sigma, lam, [(149, True)])
+    got = s.residuals(150, True)
+    # oracle formulas (src/main_iterate.cu:229-309) evaluated in numpy on the oracle's state
+    sc = ref.sc
+    obj_scale = sc.b_scale * sc.c_scale
+    pobj = obj_scale * (ref.c @ st["x_bar"])
+    dobj = obj_scale * (st["y_obj"] @ st["y_bar"] + st["x_bar"] @ st["z_bar"])
+    ATy = O.spmv(ref.n, ref.ATrp, ref.ATci, ref.ATv, st["y_bar"])
+    Ax = O.spmv(ref.m, ref.Arp, ref.Aci, ref.Av, st["x_bar"])
+    rd = np.linalg.norm((ref.c - ATy - st["z_bar"]) * ref.col_norm) * sc.c_scale / sc.norm_c_org
+    rp = np.linalg.norm(np.maximum(np.minimum(ref.AU - Ax, 0.0), ref.AL - Ax) * ref.row_norm) * sc.b_scale / sc.norm_b_org
+    Adx = O.spmv(ref.m, ref.Arp, ref.Aci, ref.Av, st["x_temp"])
+    wn = np.sqrt(sigma * lam * (st["y_temp"] @ st["y_temp"]) + (st["x_temp"] @ st["x_temp"]) / sigma + 2 * (Adx @ st["y_temp"]))
+    rtol = 1e-11  # reductions in a different order
+    assert abs(got["primal_obj"] - pobj) <= rtol * (1 + abs(pobj))
+    assert abs(got["dual_obj"] - dobj) <= rtol * (1 + abs(dobj))
+    assert abs(got["err_Rd"] - rd) <= rtol * rd
+    assert abs(got["err_Rp"] - rp) <= rtol * rp
+    assert abs(got["weighted_norm"] - wn) <= 1e-9 * wn
+    assert abs(s.weighted_norm() - wn) <= 1e-9 * wn
+    s.close(); model.free()
+
+
+def test_restart_moves_anchor_and_resets_counter(gpu):
+    lp = lpgen.planted_lp(120, 200, 1200, 26)
+    model, s, ref = make(lp, use_CR_scaling=False)
+    s.scale()
+    adopt_gpu_data(s, ref)
+    run_steps(s, ref, 0.8, 1.5, [(149, True)])
+    xb, yb = s.get("x_bar"), s.get("y_bar")
+    lx, ly = s.get("last_x"), s.get("last_y")
+    pm, dm = np.linalg.norm(xb - lx), np.linalg.norm(yb - ly)
+    new_sigma = s.restart(current_gap=0.3, best_gap=0.3, best_sigma=0.8, err_Rd=1e-2, err_Rp=1e-2, rel_gap=1e-2)
+    # update_sigma formula (reference src/main_iterate.cu:377-399) with kappa = 1
+    want = np.exp(np.exp(-0.05) * np.log((pm / dm) / np.sqrt(1.5)) + (1 - np.exp(-0.05)) * np.log(0.8))
+    assert abs(new_sigma - want) <= 1e-12 * want
+    for name, v in (("x", xb), ("last_x", xb), ("y", yb), ("last_y", yb)):
+        assert np.array_equal(s.get(name), v), name
+    sc = s.scalars()
+    assert sc["kx"] == 0 and sc["ky"] == 0 and sc["sigma"] == new_sigma
+    s.close(); model.free()
+
+
+@pytest.mark.parametrize("seed,tol", [(31, 1e-6), (32, 1e-8)])
+def test_trace_matches_oracle(gpu, seed, tol):
+    """Whole-loop parity: same check schedule, same restart decisions, same sigma sequence."""
+    lp = lpgen.planted_lp(200, 320, 2000, seed)
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+    s = hprlp.Solver(model, hprlp.Parameters(stop_tol=tol, use_presolve=False))
+    s.scale()
+    lam, _ = s.power_iteration()
+    s.init(-1.0, lam * 1.01)
+    res = s.run()
+    ref = O.solve(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"],
+                  lp["c"], params=O.Params.default(stop_tol=tol), lambda_override=lam * 1.01)
+    assert res.status == ref["status"] == "OPTIMAL"
+    # compare the common prefix of the logs until the first restart decision that differs (if any)
+    n = min(len(res.trace), len(ref["trace"]))
+    same = 0
+    for a, b in zip(res.trace[:n], ref["trace"][:n]):
+        if a["iter"] != b["iter"] or a["restart_flag"] != b["restart_flag"]:
+            break
+        same += 1
+    assert same >= min(n, 40), (same, n)   # at least the first 40 log rows share every decision
+    # rounding differences (device exp/log in the Curtis-Reid pass, reduction order) grow along the
+    # trajectory: tight at the start, loose (but decision-preserving) later
+    for i, (a, b) in enumerate(zip(res.trace[:same], ref["trace"][:same])):
+        rt = 1e-9 if i < 10 else 1e-3
+        assert abs(a["sigma"] - b["sigma"]) <= rt * b["sigma"]
+        assert abs(a["kkt"] - b["kkt"]) <= rt * b["kkt"] + 1e-13
+    assert abs(res.primal_obj - lp["obj_star"]) <= 10 * tol * (1 + abs(lp["obj_star"]))
+    s.close(); model.free()
