@@ -1,0 +1,54 @@
+"""CPU: the N>1 path (row partition + per-half-step all-gather) on gloo with world_size 2 and 3."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_iteration_equals_single_process(world):
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+        assert f"rank {rank} ok" in out
+
+
+def test_partition_edge_cases():
+    import ctypes as C
+    from conftest import hprlp
+    L = hprlp.lib()
+    off = C.c_int(); cnt = C.c_int()
+    # more ranks than items: trailing ranks own nothing but keep their slot in the padded buffer
+    got = []
+    for r in range(8):
+        chunk = L.hprlp_partition(5, 8, r, C.byref(off), C.byref(cnt))
+        got.append((chunk, off.value, cnt.value))
+    assert got == [(1, r, 1 if r < 5 else 0) for r in range(8)]
+    assert L.hprlp_partition(10, 4, 3, C.byref(off), C.byref(cnt)) == 3 and (off.value, cnt.value) == (9, 1)
+    assert L.hprlp_partition(10, 0, 0, C.byref(off), C.byref(cnt)) < 0
+    assert L.hprlp_partition(10, 2, 2, C.byref(off), C.byref(cnt)) < 0

@@ -1,0 +1,94 @@
+"""solve_batched parity: B LPs sharing A against the oracle's restatement of reference
+src/batched_solver.cu, and against the golden optima (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import hprlp, lpgen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+INF = np.inf
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_example_batch_matches_golden(gpu):
+    """The three LPs of reference examples/c/example_batched_lp.c:37-62."""
+    g = json.load(open(os.path.join(HERE, "golden", "known_lps.json")))
+    B = len(g)
+    model = hprlp.Model.from_csr(2, 2, g[0]["rowptr"], g[0]["colind"], [float(v) for v in g[0]["values"]],
+                                 [-INF, -INF], [10, 12], [0, 0], [INF, INF], [-3, -5])
+    Cm = np.array([[float(v) for v in c["c"]] for c in g]).T
+    AU = np.array([[float(v) for v in c["AU"]] for c in g]).T
+    U = np.array([[float(v) for v in c["u"]] for c in g]).T
+    AL = np.full((2, B), -INF); L = np.zeros((2, B))
+    prm = hprlp.Parameters(stop_tol=1e-8, max_iter=200000, use_presolve=False)
+    r = hprlp.solve_batched(model, Cm, AL, AU, L, U, [0.0] * B, prm)
+    ref = O.solve_batched(2, 2, g[0]["rowptr"], g[0]["colind"], [float(v) for v in g[0]["values"]], B,
+                          Cm.T.ravel(), AL.T.ravel(), AU.T.ravel(), L.T.ravel(), U.T.ravel(), [0.0] * B,
+                          params=O.Params.default(stop_tol=1e-8, max_iter=200000))
+    assert r["status"] == ["OPTIMAL"] * B == ref["status"]
+    assert list(r["iter"]) == list(ref["iter"])
+    for k, c in enumerate(g):
+        assert abs(r["primal_obj"][k] - c["obj"]) < 1e-6
+        np.testing.assert_allclose(r["x"][:, k], c["x"], atol=1e-6)
+        np.testing.assert_allclose(r["y"][:, k], c["y"], atol=1e-6)
+        np.testing.assert_allclose(r["x"][:, k], ref["x"][k], atol=1e-9)
+    assert r["time"] == pytest.approx(r["setup_time"] + r["solve_time"])
+    model.free()
+
+
+def make_batch(lp, B, seed):
+    """Perturbed copies of one planted LP (BASELINE config 4 recipe): c_k = c(1+0.1 N), AU_k = AU + |N(0,0.1)|."""
+    rng = np.random.default_rng(seed)
+    m, n = lp["m"], lp["n"]
+    Cm = lp["c"][:, None] * (1 + 0.1 * rng.normal(size=(n, B)))
+    AU = lp["AU"][:, None] + np.abs(rng.normal(scale=0.1, size=(m, B)))
+    AL = np.repeat(lp["AL"][:, None], B, axis=1)
+    AL = np.where(np.isfinite(AL), np.minimum(AL, AU), AL)
+    L = np.repeat(lp["l"][:, None], B, axis=1)
+    U = np.repeat(lp["u"][:, None], B, axis=1)
+    U = np.where(np.isfinite(U), U, 50.0)         # keep every member bounded
+    return Cm, AL, AU, L, U
+
+
+@pytest.mark.parametrize("B", [5, 64, 70])
+def test_planted_batch_matches_oracle(gpu, B):
+    lp = lpgen.planted_lp(120, 200, 1300, 40 + B)
+    Cm, AL, AU, L, U = make_batch(lp, B, B)
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+    tol = 1e-6
+    prm = hprlp.Parameters(stop_tol=tol, max_iter=60000, use_presolve=False)
+    r = hprlp.solve_batched(model, Cm, AL, AU, L, U, None, prm)
+    ref = O.solve_batched(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], B, Cm.T.ravel(), AL.T.ravel(),
+                          AU.T.ravel(), L.T.ravel(), U.T.ravel(), None,
+                          params=O.Params.default(stop_tol=tol, max_iter=60000))
+    assert r["batch_size"] == B and r["x"].shape == (lp["n"], B) and r["y"].shape == (lp["m"], B)
+    assert r["status"] == ref["status"]
+    done = [k for k in range(B) if ref["status"][k] == "OPTIMAL"]
+    assert len(done) >= B // 2
+    # same schedule and same per-problem decisions => same stopping iteration for (nearly) every member;
+    # a member may fork at a thresholded restart decision (FP64 reduction order)
+    same_iter = sum(int(r["iter"][k] == ref["iter"][k]) for k in done)
+    assert same_iter >= 0.8 * len(done)
+    for k in done:
+        assert abs(r["primal_obj"][k] - ref["primal_obj"][k]) <= 20 * tol * (1 + abs(ref["primal_obj"][k]))
+        assert r["residuals"][k] <= tol
+    model.free()
+
+
+def test_batched_bad_arguments(gpu, model_mps_arrays):
+    a = model_mps_arrays
+    model = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"])
+    L = hprlp.lib()
+    res = L.solve_batched(model._ptr, 2, None, None, None, None, None, None, None)   # NULL panels -> "ERROR" per member
+    assert res.batch_size == 2 and not res.x
+    raw = bytes(bytearray(res.status[i][0] if isinstance(res.status[i], bytes) else res.status[i] for i in range(128)))
+    assert raw[:5] == b"ERROR" and raw[64:69] == b"ERROR"
+    import ctypes as C
+    L.free_batched_results(C.byref(res))
+    assert not res.status and res.batch_size == 0
+    model.free()
