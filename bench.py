@@ -216,6 +216,7 @@ def main():
     lam, pw_it = s.power_iteration()
     s.init(-1.0, lam * 1.01)
     sc = s.scalars()
+    tiled = s.info()["tiled"]
     if rank == 0:
         log(f"[bench] setup {time.time() - t0:.1f}s (device setup {sc['setup_time']:.2f}s, scaling {sc['scaling_time']:.2f}s, "
             f"power iteration {sc['power_time']:.2f}s / {pw_it} its, lambda_max={lam:.4g})")
@@ -264,7 +265,7 @@ def main():
                                    f"({'row-partitioned over %d GPUs, 2 RCCL all-gathers per iteration' % P if P > 1 else 'one GPU'})",
                        "m": m, "n": n, "nnz": nnz, "parallelism": f"rowpart{P}",
                        "bytes_per_iteration_algorithmic": bytes_per_iteration(m, n, nnz)},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_fused<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern)",
+            "roofline": {"bound": "hbm", "kernel": ("k_tiled_fused" if tiled & 2 else "k_spmv_fused") + "<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": bx, "avg_launch_ms": x_ms,
                          "yhalf_avg_launch_ms": y_ms,

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "tiled.h"
+
 namespace hprlp {
 
 constexpr int kWave = 64;         // CDNA wavefront
@@ -48,7 +50,10 @@ struct CsrDev {
     double *val = nullptr;
     const int4 *blk = nullptr;
     int nblk = 0;
-    int grid() const { return (nblk + kWavesPerBlock - 1) / kWavesPerBlock; }
+    TiledDev tiled;  // optional column-tiled copy (tiled.h); when valid every fused launch uses it
+    int csr_grid() const { return (nblk + kWavesPerBlock - 1) / kWavesPerBlock; }
+    // workgroups of a fused launch on this matrix = number of reduction partials it writes
+    int grid() const { return tiled.valid ? tiled.grid : csr_grid(); }
 };
 
 // Device-resident iteration scalars (reference Halpern_params[4] + halpern_inner,

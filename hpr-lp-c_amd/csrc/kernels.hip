@@ -28,9 +28,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Sum NACC per-thread accumulators over the block; thread 0 stores partials[i*stride + blockIdx.x].
-template <int NACC>
+template <int NACC, int NW = kWavesPerBlock>
 __device__ __forceinline__ void block_store_partials(double (&acc)[NACC], double *partials, int stride) {
-    __shared__ double red[kWavesPerBlock][NACC > 0 ? NACC : 1];
+    __shared__ double red[NW][NACC > 0 ? NACC : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
@@ -43,7 +43,7 @@ __device__ __forceinline__ void block_store_partials(double (&acc)[NACC], double
         for (int i = 0; i < NACC; ++i) {
             double v = red[0][i];
 #pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) v += red[w][i];
+            for (int w = 1; w < NW; ++w) v += red[w][i];
             partials[(size_t)i * stride + blockIdx.x] = v;
         }
     }
@@ -159,6 +159,155 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
         }
     }
     if constexpr (NACC > 0) block_store_partials<NACC>(acc, epi.partials, epi.stride);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// the column-tiled fused kernel (format and rationale: tiled.h).  One workgroup = one super-block of
+// kTileRows rows; per tile step: [barrier] stage the prefetched tile of the gathered vector into LDS,
+// issue the loads of the next step, [barrier], every lane folds its chunk of 4 entries into the LDS
+// accumulators (all LDS reads first, running segment sums in registers, then the writes).  The
+// barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain vmcnt
+// and expose the latency of the prefetched global loads in every step.  Super-blocks are mapped
+// XCD-aware (contiguous range per XCD) so that concurrently running workgroups share their column
+// window in one L2.  Summation order per row = CSR order (tiles ascending), remainder entries last.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class Epi>
+__global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi) {
+    static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
+    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols, K = kTileChunk;
+    constexpr int TPT = T / NT;
+    constexpr int NACC = Epi::NACC;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    __shared__ double acc[R];
+    __shared__ double ytile[T];
+    const TiledDev &t = A.tiled;
+    const int tid = threadIdx.x;
+    const int per = gridDim.x / 8;
+    const int sb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    double racc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
+    epi.begin();
+    if (sb < t.nsb) {
+        const double *__restrict__ vec = epi.gv[0];
+        const int ncols = A.cols;
+        for (int i = tid; i < R; i += NT) acc[i] = 0.0;
+        const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
+        if (s0 < smid) {
+            d2_t va, vb;
+            u4_t ix;
+            double tl[TPT];
+            TileStep st = t.steps[s0];
+            TileStep st_next = t.steps[min(s0 + 1, smid - 1)];
+            auto issue = [&](const TileStep &q) {
+                const int e = q.e_begin + K * tid;
+                const int ee = (e < q.e_end) ? e : q.e_begin;
+                va = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee));
+                vb = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee) + 1);
+                ix = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(t.tidx + ee));
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) tl[j] = vec[min(q.col0 + tid + j * NT, ncols - 1)];
+            };
+            issue(st);
+            for (int s = s0; s < smid; ++s) {
+                const TileStep cur = st;
+                const d2_t ca = va, cb = vb;
+                const u4_t cx = ix;
+                lds_barrier();  // every lane is done with the previous tile
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+                st = st_next;
+                st_next = t.steps[min(s + 2, smid - 1)];
+                if (s + 1 < smid) issue(st);
+                lds_barrier();  // tile visible
+                if (K * tid < cur.e_end - cur.e_begin) {
+                    const double v[K] = {ca.x, ca.y, cb.x, cb.y};
+                    const uint32_t id[K] = {cx.x, cx.y, cx.z, cx.w};
+                    uint32_t rw[K];
+                    double a[K], y[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        rw[k] = id[k] & 0xffffu;
+                        a[k] = acc[rw[k]];
+                        y[k] = ytile[id[k] >> 16];
+                    }
+                    double sk[K];
+                    sk[0] = a[0] + v[0] * y[0];
+#pragma unroll
+                    for (int k = 1; k < K; ++k) sk[k] = ((rw[k] == rw[k - 1]) ? sk[k - 1] : a[k]) + v[k] * y[k];
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        if (k == K - 1 || rw[k] != rw[k + 1]) acc[rw[k]] = sk[k];
+                }
+            }
+        }
+        // remainder entries: direct gathers; products staged in the tile buffer, one head lane per row
+        // segment adds them in order (same scheme as the stream kernel)
+        double *prod = ytile;
+        uint16_t *rows = reinterpret_cast<uint16_t *>(ytile + kTileRemCap);
+        for (int s = smid; s < s1; ++s) {
+            const TileStep st = t.steps[s];
+            const int cnt = st.e_end - st.e_begin;
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < kTileRemK; ++k) {
+                const int el = tid + k * NT;
+                if (el < cnt) {
+                    const int e = st.e_begin + el;
+                    prod[el] = t.rval[e] * vec[t.rcol[e]];
+                    rows[el + 1] = t.rrow[e];
+                }
+            }
+            if (tid == 0) rows[0] = 0xffffu;
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < kTileRemK; ++k) {
+                const int el = tid + k * NT;
+                if (el < cnt) {
+                    const uint16_t rw = rows[el + 1];
+                    if (rows[el] != rw) {
+                        double sacc = acc[rw];
+                        int j = el;
+                        do {
+                            sacc += prod[j];
+                            ++j;
+                        } while (j < cnt && rows[j + 1] == rw);
+                        acc[rw] = sacc;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        const int r0 = sb * R;
+        const int nr = min(R, A.rows - r0);
+        for (int i = tid; i < nr; i += NT) {
+            const double sv[1] = {acc[i]};
+            typename Epi::Row rw = epi.load_row(r0 + i);
+            epi.apply(r0 + i, rw, sv, racc);
+        }
+    }
+    if constexpr (NACC > 0) block_store_partials<NACC, kTileThreads / kWave>(racc, epi.partials, epi.stride);
+}
+
+__global__ void __launch_bounds__(kThreads) k_tiled_refresh(long n, const int *perm, const double *csr_val, double *out) {
+    const long i = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < n) {
+        const int p = perm[i];
+        out[i] = p >= 0 ? csr_val[p] : 0.0;
+    }
+}
+
+void launch_tiled_refresh(const DeviceTiled &t, const double *csr_val, hipStream_t s) {
+    if (t.n_tile > 0)
+        hipLaunchKernelGGL(k_tiled_refresh, dim3(static_cast<unsigned>((t.n_tile + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           t.n_tile, t.tperm.p, csr_val, t.tval.p);
+    if (t.n_rem > 0)
+        hipLaunchKernelGGL(k_tiled_refresh, dim3(static_cast<unsigned>((t.n_rem + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           t.n_rem, t.rperm.p, csr_val, t.rval.p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,7 +497,13 @@ struct PlainEpi {
 template <class Epi>
 static void launch_fused(const CsrDev &M, const Epi &e, hipStream_t s) {
     if (M.nblk <= 0) return;
-    hipLaunchKernelGGL(k_spmv_fused<Epi>, dim3(M.grid()), dim3(kThreads), 0, s, M, e);
+    if constexpr (Epi::NV == 1) {
+        if (M.tiled.valid) {
+            hipLaunchKernelGGL(k_tiled_fused<Epi>, dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+            return;
+        }
+    }
+    hipLaunchKernelGGL(k_spmv_fused<Epi>, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, e);
 }
 
 void launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s) {
@@ -380,7 +535,12 @@ void launch_resid_d(const CsrDev &AT, const double *ybar_full, const double *c, 
 void launch_resid_p(const CsrDev &A, const double *xbar_full, const double *xtemp_full, const double *AL,
                     const double *AU, const double *row_norm, const double *y_temp, bool with_gap,
                     double *partials, int stride, hipStream_t s) {
-    if (with_gap) {
+    if (with_gap && A.tiled.valid) {  // the tiled kernel stages one vector: two passes
+        RpEpi<false> e{{xbar_full}, AL, AU, row_norm, nullptr, partials, stride};
+        launch_fused(A, e, s);
+        GapEpi g{{xtemp_full}, y_temp, partials + stride, stride};
+        launch_fused(A, g, s);
+    } else if (with_gap) {
         RpEpi<true> e{{xbar_full, xtemp_full}, AL, AU, row_norm, y_temp, partials, stride};
         launch_fused(A, e, s);
     } else {

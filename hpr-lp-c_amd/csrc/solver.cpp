@@ -71,6 +71,26 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     view.val = val.p;
     view.blk = blk.p;
     view.nblk = static_cast<int>(b.size());
+    // column-tiled copy: only for matrices large enough to fill the chip with 8192-row super-blocks
+    // and with enough column locality (HPRLP_NO_TILED=1 disables; thresholds overridable for tests)
+    const char *no = std::getenv("HPRLP_NO_TILED");
+    if (!(no && no[0] == '1')) {
+        const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
+        const char *md = std::getenv("HPRLP_TILED_MIN_DENSE");
+        const int min_rows = mr ? std::atoi(mr) : 512 * kTileRows;
+        const double min_dense = md ? std::atof(md) : 0.5;
+        TiledHost th;
+        if (build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense)) {
+            tiled.upload(th);
+            view.tiled = tiled.view;
+            launch_tiled_refresh(tiled, val.p, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+    }
+}
+
+void DeviceMatrix::refresh_tiled(hipStream_t s) {
+    if (view.tiled.valid) launch_tiled_refresh(tiled, val.p, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -275,6 +295,8 @@ void Solver::scale() {
     }
     norm_b = std::sqrt(bnorm_sq(this));
     norm_c = std::sqrt(reduce_sum_sq(c.p, n_loc));
+    A.refresh_tiled(stream);
+    AT.refresh_tiled(stream);
     HIP_CHECK(hipMemsetAsync(gsm.p, 0, sizeof(double) * m_pad, stream));
     HIP_CHECK(hipMemsetAsync(gsn.p, 0, sizeof(double) * n_pad, stream));
     HIP_CHECK(hipStreamSynchronize(stream));

@@ -1,0 +1,215 @@
+// tiled.cpp -- host-side construction of the column-tiled matrix copy (see tiled.h).
+#include "tiled.h"
+
+#include <algorithm>
+#include <thread>
+
+namespace hprlp {
+
+namespace {
+
+struct Local {  // what one builder thread produces for a contiguous range of super-blocks
+    std::vector<int> sb_steps, sb_mid;  // per super-block: number of steps, index of first remainder step (local)
+    std::vector<TileStep> steps;        // e_begin/e_end local to this thread's tile / remainder arrays
+    std::vector<char> step_is_rem;
+    std::vector<uint32_t> tidx;
+    std::vector<int> tperm, rcol, rperm;
+    std::vector<uint16_t> rrow;
+    long dense = 0, pad = 0;
+};
+
+void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int sb1, Local *L) {
+    const int R = kTileRows, T = kTileCols, K = kTileChunk;
+    const int ntile = (cols + T - 1) / T;
+    std::vector<int> cnt(static_cast<size_t>(ntile), 0), slot(static_cast<size_t>(ntile), -1);
+    std::vector<int> touched;
+    struct Ent {
+        int row, lcol, k;
+    };
+    std::vector<std::vector<Ent>> bucket;
+    std::vector<std::pair<int, int>> rem;  // (local row, csr index)
+    for (int sb = sb0; sb < sb1; ++sb) {
+        const int r0 = sb * R, r1 = std::min(rows, r0 + R);
+        touched.clear();
+        for (int k = rp[r0]; k < rp[r1]; ++k) {
+            const int tl = ci[k] / T;
+            if (cnt[tl]++ == 0) touched.push_back(tl);
+        }
+        std::sort(touched.begin(), touched.end());
+        int nd = 0;
+        for (int tl : touched) slot[tl] = (cnt[tl] >= kTileDenseMin) ? nd++ : -1;
+        if (static_cast<int>(bucket.size()) < nd) bucket.resize(nd);
+        for (int i = 0; i < nd; ++i) bucket[i].clear();
+        rem.clear();
+        for (int r = r0; r < r1; ++r)
+            for (int k = rp[r]; k < rp[r + 1]; ++k) {
+                const int tl = ci[k] / T;
+                if (slot[tl] >= 0) bucket[slot[tl]].push_back(Ent{r - r0, ci[k] - tl * T, k});
+                else rem.emplace_back(r - r0, k);
+            }
+        const size_t first_step = L->steps.size();
+        for (int tl : touched) {
+            if (slot[tl] < 0) continue;
+            const std::vector<Ent> &b = bucket[slot[tl]];
+            const size_t tile_begin = L->tidx.size();
+            size_t i = 0;
+            int last_row = b.empty() ? 0 : b[0].row;
+            while (i < b.size()) {
+                size_t j = i;
+                while (j < b.size() && b[j].row == b[i].row) ++j;
+                const int len = static_cast<int>(j - i);
+                if (len > K) {  // long segment: remainder path keeps it whole
+                    for (size_t q = i; q < j; ++q) rem.emplace_back(b[q].row, b[q].k);
+                    i = j;
+                    continue;
+                }
+                const int pos = static_cast<int>((L->tidx.size() - tile_begin) % K);
+                if (pos + len > K)
+                    for (int q = pos; q < K; ++q) {
+                        L->tidx.push_back(static_cast<uint32_t>(last_row));
+                        L->tperm.push_back(-1);
+                        ++L->pad;
+                    }
+                for (size_t q = i; q < j; ++q) {
+                    L->tidx.push_back((static_cast<uint32_t>(b[q].lcol) << 16) | static_cast<uint32_t>(b[q].row));
+                    L->tperm.push_back(b[q].k);
+                    ++L->dense;
+                }
+                last_row = b[i].row;
+                i = j;
+            }
+            while ((L->tidx.size() - tile_begin) % K) {
+                L->tidx.push_back(static_cast<uint32_t>(last_row));
+                L->tperm.push_back(-1);
+                ++L->pad;
+            }
+            size_t p = tile_begin;
+            const size_t end = L->tidx.size();
+            while (p < end) {
+                const size_t c = std::min<size_t>(end - p, kTileStepCap);
+                L->steps.push_back(TileStep{tl * T, static_cast<int>(p), static_cast<int>(p + c), 0});
+                L->step_is_rem.push_back(0);
+                p += c;
+            }
+        }
+        L->sb_mid.push_back(static_cast<int>(L->steps.size() - first_step));
+        std::sort(rem.begin(), rem.end());
+        size_t p = L->rcol.size();
+        for (const auto &e : rem) {
+            L->rrow.push_back(static_cast<uint16_t>(e.first));
+            L->rcol.push_back(ci[e.second]);
+            L->rperm.push_back(e.second);
+        }
+        const size_t end = L->rcol.size();
+        while (p < end) {
+            const size_t c = std::min<size_t>(end - p, kTileRemCap);
+            L->steps.push_back(TileStep{0, static_cast<int>(p), static_cast<int>(p + c), 0});
+            L->step_is_rem.push_back(1);
+            p += c;
+        }
+        L->sb_steps.push_back(static_cast<int>(L->steps.size() - first_step));
+        for (int tl : touched) {
+            cnt[tl] = 0;
+            slot[tl] = -1;
+        }
+    }
+}
+
+}  // namespace
+
+bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
+                 double min_dense_fraction) {
+    *out = TiledHost();
+    if (rows < min_rows || rows <= 0 || cols <= 0) return false;
+    const long nnz = rowptr[rows];
+    if (nnz <= 0) return false;
+    const int nsb = (rows + kTileRows - 1) / kTileRows;
+    int nt = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::min(nt, std::max(1, nsb / 4));
+    std::vector<Local> loc(static_cast<size_t>(nt));
+    std::vector<std::thread> th;
+    const int per = (nsb + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int a = t * per, b = std::min(nsb, a + per);
+        if (a >= b) break;
+        th.emplace_back(build_range, rows, cols, rowptr, col, a, b, &loc[t]);
+    }
+    for (auto &t : th) t.join();
+    long dense = 0, pad = 0;
+    size_t n_t = 0, n_r = 0, n_s = 0;
+    for (const Local &L : loc) {
+        dense += L.dense;
+        pad += L.pad;
+        n_t += L.tidx.size();
+        n_r += L.rcol.size();
+        n_s += L.steps.size();
+    }
+    if (static_cast<double>(dense) < min_dense_fraction * static_cast<double>(nnz) || n_t > 2000000000UL ||
+        n_r > 2000000000UL)
+        return false;
+    out->dense_entries = dense;
+    out->padding = pad;
+    out->sb_ptr.reserve(static_cast<size_t>(nsb) + 1);
+    out->sb_mid.reserve(nsb);
+    out->steps.reserve(n_s);
+    out->tidx.reserve(n_t);
+    out->tperm.reserve(n_t);
+    out->rcol.reserve(n_r);
+    out->rperm.reserve(n_r);
+    out->rrow.reserve(n_r);
+    out->sb_ptr.push_back(0);
+    for (Local &L : loc) {
+        const int t_off = static_cast<int>(out->tidx.size()), r_off = static_cast<int>(out->rcol.size());
+        size_t sp = 0;
+        for (size_t i = 0; i < L.sb_steps.size(); ++i) {
+            const int base = out->sb_ptr.back();
+            out->sb_mid.push_back(base + L.sb_mid[i]);
+            out->sb_ptr.push_back(base + L.sb_steps[i]);
+            for (int q = 0; q < L.sb_steps[i]; ++q, ++sp) {
+                TileStep s = L.steps[sp];
+                const int off = L.step_is_rem[sp] ? r_off : t_off;
+                s.e_begin += off;
+                s.e_end += off;
+                out->steps.push_back(s);
+            }
+        }
+        out->tidx.insert(out->tidx.end(), L.tidx.begin(), L.tidx.end());
+        out->tperm.insert(out->tperm.end(), L.tperm.begin(), L.tperm.end());
+        out->rcol.insert(out->rcol.end(), L.rcol.begin(), L.rcol.end());
+        out->rperm.insert(out->rperm.end(), L.rperm.begin(), L.rperm.end());
+        out->rrow.insert(out->rrow.end(), L.rrow.begin(), L.rrow.end());
+        L = Local();  // release
+    }
+    return true;
+}
+
+void DeviceTiled::upload(const TiledHost &h) {
+    n_tile = static_cast<long>(h.tidx.size());
+    n_rem = static_cast<long>(h.rcol.size());
+    const int nsb = static_cast<int>(h.sb_mid.size());
+    sb_ptr.alloc(h.sb_ptr.size()); sb_ptr.upload(h.sb_ptr.data(), h.sb_ptr.size());
+    sb_mid.alloc(h.sb_mid.size()); sb_mid.upload(h.sb_mid.data(), h.sb_mid.size());
+    steps.alloc(h.steps.size()); steps.upload(h.steps.data(), h.steps.size());
+    // +8 entries of slack: the kernel's clamped 16-byte loads never read past e_begin+3 of a valid
+    // chunk, the slack only keeps empty arrays addressable
+    tidx.alloc_zero(h.tidx.size() + 8); tidx.upload(h.tidx.data(), h.tidx.size());
+    tperm.alloc(h.tperm.size() + 8); tperm.upload(h.tperm.data(), h.tperm.size());
+    tval.alloc_zero(h.tidx.size() + 8);
+    rcol.alloc_zero(h.rcol.size() + 8); rcol.upload(h.rcol.data(), h.rcol.size());
+    rperm.alloc(h.rperm.size() + 8); rperm.upload(h.rperm.data(), h.rperm.size());
+    rrow.alloc_zero(h.rrow.size() + 8); rrow.upload(h.rrow.data(), h.rrow.size());
+    rval.alloc_zero(h.rcol.size() + 8);
+    view.valid = true;
+    view.nsb = nsb;
+    view.grid = (nsb + 7) / 8 * 8;
+    view.sb_ptr = sb_ptr.p;
+    view.sb_mid = sb_mid.p;
+    view.steps = steps.p;
+    view.tval = tval.p;
+    view.tidx = tidx.p;
+    view.rval = rval.p;
+    view.rcol = rcol.p;
+    view.rrow = rrow.p;
+}
+
+}  // namespace hprlp

@@ -1,0 +1,86 @@
+// tiled.h -- column-tiled copy of a CSR matrix for the fused kernels (private).
+//
+// Why: with ~20 nonzeros per row and a column window far wider than L1, every gathered 8-byte vector
+// element costs a 128-byte L2->L1 line, and the stream kernel is bound by that (profiles/r01_spmv_probe.txt).
+// Here a workgroup owns a super-block of kTileRows rows, sweeps the column space in tiles of kTileCols
+// columns, stages each tile of the gathered vector in LDS (coalesced, every line fetched once per
+// super-block) and accumulates row sums in LDS.  Entries of a (super-block, tile) pair are sorted by
+// (row, column) and packed in chunks of 4; a row segment never straddles a chunk (zero-valued
+// padding continues the previous row), so exactly one lane touches a given accumulator in a step:
+// no atomics, deterministic, and the per-row summation order stays the CSR order.  Segments longer
+// than 4 and entries of sparse tiles go to a remainder list processed with direct gathers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+
+namespace hprlp {
+
+constexpr int kTileThreads = 512;  // workgroup of the tiled kernel (8 waves)
+constexpr int kTileRows = 8192;    // rows per super-block: 64 KiB of accumulators in LDS
+constexpr int kTileCols = 2048;    // columns per tile: 16 KiB of the gathered vector in LDS
+constexpr int kTileChunk = 4;      // entries per lane per step
+constexpr int kTileStepCap = kTileThreads * kTileChunk;                       // entries per tile step
+constexpr int kTileRemK = (kTileCols * 8 - 8) / (10 * kTileThreads);          // remainder entries per lane per step
+constexpr int kTileRemCap = kTileThreads * kTileRemK;                         // (scratch aliases the tile buffer)
+constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
+static_assert(kTileRemK >= 1, "tile buffer too small for the remainder scratch");
+
+struct TileStep {
+    int col0;     // first column of the tile
+    int e_begin;  // entry range in tval/tidx (tile step) or rval/rcol/rrow (remainder step)
+    int e_end;
+    int pad;
+};
+
+struct TiledDev {
+    bool valid = false;
+    int nsb = 0;               // super-blocks
+    int grid = 0;              // nsb rounded up to a multiple of 8 (XCD-aware mapping)
+    const int *sb_ptr = nullptr;   // nsb+1: steps of a super-block
+    const int *sb_mid = nullptr;   // nsb: first remainder step
+    const TileStep *steps = nullptr;
+    const double *tval = nullptr;  // tile entries: value
+    const uint32_t *tidx = nullptr;  // local column << 16 | local row
+    const double *rval = nullptr;  // remainder entries
+    const int *rcol = nullptr;
+    const uint16_t *rrow = nullptr;
+};
+
+// Host-side result of the analysis; perm arrays give, for every stored entry, its index in the CSR
+// value array (-1 for padding) so that values can be refreshed on the device after scaling.
+struct TiledHost {
+    std::vector<int> sb_ptr, sb_mid;
+    std::vector<TileStep> steps;
+    std::vector<uint32_t> tidx;
+    std::vector<int> tperm;
+    std::vector<int> rcol, rperm;
+    std::vector<uint16_t> rrow;
+    long dense_entries = 0;  // CSR entries that landed in staged tiles
+    long padding = 0;
+};
+
+// Builds the tiled structure of a CSR pattern (rows x cols).  Returns false (and leaves `out` empty)
+// when the matrix is too small or too scattered for the tiled kernel to pay off.
+bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
+                 double min_dense_fraction);
+
+struct DeviceTiled {
+    DBuf<int> sb_ptr, sb_mid, tperm, rperm, rcol;
+    DBuf<TileStep> steps;
+    DBuf<uint32_t> tidx;
+    DBuf<uint16_t> rrow;
+    DBuf<double> tval, rval;
+    TiledDev view;
+    long n_tile = 0, n_rem = 0;
+    void upload(const TiledHost &h);
+};
+
+// tval[e] = csr_val[tperm[e]] (0 for padding), rval likewise
+void launch_tiled_refresh(const DeviceTiled &t, const double *csr_val, hipStream_t s);
+
+}  // namespace hprlp

@@ -348,7 +348,7 @@ class Solver:
     def info(self):
         out = (C.c_long * 8)()
         self._chk(lib().hprlp_solver_info(self.h, out))
-        keys = ("m", "n", "nnz", "blocks_A", "blocks_AT", "grid_y", "grid_x", "long_rows")
+        keys = ("m", "n", "nnz", "blocks_A", "blocks_AT", "grid_y", "grid_x", "tiled")
         return dict(zip(keys, [int(v) for v in out]))
 
     def run(self, max_trace=4096):

@@ -62,7 +62,8 @@ int hprlp_solver_set_vector(hprlp_solver *s, const char *name, const double *in,
 /* out = {b_scale, c_scale, norm_b, norm_c, norm_b_org, norm_c_org, sigma, lambda_max,
  *        setup_time, scaling_time, power_time, power_iters, kx, ky} */
 int hprlp_solver_get_scalars(hprlp_solver *s, double out[16]);
-/* out = {m, n, nnz, row blocks of A, row blocks of A^T, grid of y-half, grid of x-half, long rows} */
+/* out = {m, n, nnz, row blocks of A, row blocks of A^T, grid of y-half, grid of x-half,
+ *        tiled flags (bit0: A, bit1: A^T use the column-tiled kernel)} */
 int hprlp_solver_info(hprlp_solver *s, long out[8]);
 
 /* Timed normal iterations for bench.py.  mode 0: graph replay as the product runs it; wall time by

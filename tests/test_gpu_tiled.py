@@ -1,0 +1,85 @@
+"""The column-tiled fused kernel (hpr-lp-c_amd/csrc/tiled.h) against the oracle.  The tiled path is
+normally reserved for matrices with >= 4M rows; HPRLP_TILED_MIN_ROWS forces it on a small banded LP."""
+import os
+
+import numpy as np
+import pytest
+
+import bench_helpers as bh
+from conftest import hprlp
+from oracle import oracle as O
+from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def force_tiled():
+    old = {k: os.environ.get(k) for k in ("HPRLP_TILED_MIN_ROWS", "HPRLP_TILED_MIN_DENSE", "HPRLP_NO_TILED")}
+    os.environ["HPRLP_TILED_MIN_ROWS"] = "1"
+    os.environ["HPRLP_TILED_MIN_DENSE"] = "0.0"
+    os.environ.pop("HPRLP_NO_TILED", None)
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def build(m, n, per_row, band):
+    lp = bh.banded_lp(m, n, per_row, band)
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    return lp, model
+
+
+def test_tiled_iterations_match_oracle(gpu, force_tiled):
+    m = n = 30000
+    lp, model = build(m, n, 12, 600)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+    ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                     O.Params.default(use_CR_scaling=0))
+    s.scale()
+    adopt_gpu_data(s, ref)
+    st = run_steps(s, ref, 0.6, 1.4, [(23, True), (5, True), (11, False)])
+    for name in NAMES_N + NAMES_M:
+        # rows with entries outside the staged tiles (5 % far columns) add those last: rounding only
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+    lam, it = s.power_iteration()
+    lam_ref, it_ref = ref.power_iteration()
+    assert it == it_ref and abs(lam - lam_ref) <= 1e-11 * lam_ref
+    s.close(); model.free()
+
+
+def test_tiled_equals_stream_kernel_end_to_end(gpu, force_tiled):
+    """Same LP solved with the tiled and with the stream kernel: same iteration count, same optimum."""
+    m = n = 20000
+    lp, model = build(m, n, 10, 300)
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False, max_iter=20000)
+    r_tiled = model.solve(prm)
+    os.environ["HPRLP_NO_TILED"] = "1"
+    r_stream = model.solve(prm)
+    assert r_tiled.status == r_stream.status
+    assert abs(r_tiled.primal_obj - r_stream.primal_obj) <= 1e-5 * (1 + abs(r_stream.primal_obj))
+    assert abs(r_tiled.iter - r_stream.iter) <= 0.2 * r_stream.iter + 150
+    if r_stream.status == "OPTIMAL":
+        assert abs(r_tiled.primal_obj - lp["obj_star"]) <= 1e-4 * (1 + abs(lp["obj_star"]))
+    model.free()
+
+
+def test_tiled_handles_long_segments_and_ragged_edges(gpu, force_tiled):
+    """Narrow band: a row has all its entries in one tile (segments > 4 go to the remainder list);
+    sizes that are not multiples of the super-block / tile sizes."""
+    m, n = 9001, 2500
+    lp, model = build(m, n, 9, 40)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+    ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                     O.Params.default(use_CR_scaling=0))
+    s.scale()
+    adopt_gpu_data(s, ref)
+    st = run_steps(s, ref, 0.9, 1.1, [(9, True)])
+    for name in NAMES_N + NAMES_M:
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+    got = s.residuals(10, True)
+    assert np.isfinite(got["kkt"])
+    s.close(); model.free()
