@@ -848,9 +848,9 @@ int main(int argc, char **argv) {
     printf("m=n=%d nnz=%zu band=%d bytes=%.3f GB\n", m, nnz, band, bytes * 1e-9);
     g_band = band;
     run_cfg4("v4 NT512 R8192 T2048 KC1", k_tiled4<512, 8192, 2048, 1>, 512, 8192, 2048, 1, 256);
-    run_cfg4("v4 NT256 R8192 T2048 KC2", k_tiled4<256, 8192, 2048, 2>, 256, 8192, 2048, 2, 256);
-    run_cfg4("v4 NT512 R6144 T3072 KC1", k_tiled4<512, 6144, 3072, 1>, 512, 6144, 3072, 1, 384);
-    run_cfg4("v4 NT512 R4096 T4096 KC1", k_tiled4<512, 4096, 4096, 1>, 512, 4096, 4096, 1, 512);
+    run_cfg4("v4 NT1024 R16384 T2048 KC1", k_tiled4<1024, 16384, 2048, 1>, 1024, 16384, 2048, 1, 256);
+    run_cfg4("v4 NT512 R16384 T2048 KC2", k_tiled4<512, 16384, 2048, 2>, 512, 16384, 2048, 2, 256);
+    run_cfg4("v4 NT512 R12288 T2048 KC1", k_tiled4<512, 12288, 2048, 1>, 512, 12288, 2048, 1, 256);
     for (g_rotate = 0; g_rotate < 0; ++g_rotate) {
     printf("rotate=%d\n", g_rotate);
     run_cfg4("v4 NT1024 R8192 T8192 KC2", k_tiled4<1024, 8192, 8192, 2>, 1024, 8192, 8192, 2, 512);
