@@ -138,7 +138,8 @@ extern "C" hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, cons
         if (hprlp_extract_shard(model, rank, size, &sh) != 0) throw std::runtime_error(last_error_cstr());
         h = new hprlp_solver();
         h->s.verbose = false;
-        if (size > 1) h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
+        // a unique id given with size 1 builds a one-rank RCCL communicator (exercises the collective path)
+        if (size > 1 || (unique_id && id_bytes >= 128)) h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
         h->s.setup_shard(sh.m, sh.n, sh.row_off, sh.m_loc, sh.col_off, sh.n_loc, sh.A_rowptr, sh.A_col, sh.A_val,
                          sh.AT_rowptr, sh.AT_col, sh.AT_val, sh.AL, sh.AU, sh.l, sh.u, sh.c, sh.obj_constant, p, h->comm);
         hprlp_free_shard(&sh);

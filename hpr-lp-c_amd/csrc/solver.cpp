@@ -189,7 +189,7 @@ void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int c
 // collectives (no-ops on one GPU)
 // ------------------------------------------------------------------------------------------------
 void Solver::gather(double *gbuf, bool is_m) {
-    if (!comm || comm->size == 1) return;
+    if (!comm) return;  // (a one-rank communicator still runs the collective: used to test the RCCL path)
     const size_t chunk = static_cast<size_t>(is_m ? m_pad : n_pad) / comm->size;
     comm->allgather_inplace(gbuf, chunk, stream);
 }
@@ -200,7 +200,7 @@ void Solver::fetch_scalars() {
 }
 
 static void allreduce_slots(Solver *s, int first, int count) {
-    if (!s->comm || s->comm->size == 1) return;
+    if (!s->comm) return;
     s->comm->allreduce_sum(s->scal.p + first, count, s->stream);
 }
 

@@ -285,6 +285,30 @@ class Solver:
         if not self.h:
             raise RuntimeError("hprlp_solver_create failed: " + last_error())
 
+    @classmethod
+    def create_dist(cls, model, param, rank, size, unique_id=None):
+        """One rank of the row-partitioned solve (hprlp_solver_create_dist).  unique_id: 128-byte numpy
+        uint8 array from dist_unique_id() (rank 0) broadcast to every rank."""
+        L = lib()
+        L.hprlp_solver_create_dist.restype = C.c_void_p
+        L.hprlp_solver_create_dist.argtypes = [C.POINTER(CLPInfo), C.POINTER(CParameters), C.c_int, C.c_int,
+                                               C.c_void_p, C.c_int]
+        self = cls.__new__(cls)
+        self.model = model
+        cp = (param or Parameters()).to_c()
+        uid = None if unique_id is None else unique_id.ctypes.data_as(C.c_void_p)
+        self.h = L.hprlp_solver_create_dist(model._ptr, C.byref(cp), rank, size, uid, 0 if unique_id is None else 128)
+        if not self.h:
+            raise RuntimeError("hprlp_solver_create_dist failed: " + last_error())
+        return self
+
+    @staticmethod
+    def dist_unique_id():
+        uid = np.zeros(128, np.uint8)
+        if lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 128) != 0:
+            raise RuntimeError(last_error())
+        return uid
+
     def _chk(self, rc):
         if rc < 0:
             raise RuntimeError(last_error())
