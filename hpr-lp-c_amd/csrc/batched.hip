@@ -272,14 +272,19 @@ struct BFin {
     int slot[3];
     int nacc;
 };
+// grid (ceil(Bp/64), nacc): a block sums one accumulator for 64 problems; its 4 waves stride over the
+// producer blocks (lane = problem: coalesced), then combine in a fixed order
 __global__ void __launch_bounds__(256) kb_finalize(const double *partials, int nblocks, int Bp, BFin f, double *SC) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= Bp) return;
-    for (int i = 0; i < f.nacc; ++i) {
-        double v = 0.0;
-        for (int b = 0; b < nblocks; ++b) v += partials[(static_cast<size_t>(b) * f.nacc + i) * Bp + k];
-        SC[static_cast<size_t>(f.slot[i]) * Bp + k] = v;
-    }
+    __shared__ double red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 64 + lane, i = blockIdx.y;
+    double v = 0.0;
+    if (k < Bp)
+        for (int b = wave; b < nblocks; b += 4) v += partials[(static_cast<size_t>(b) * f.nacc + i) * Bp + k];
+    red[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && k < Bp)
+        SC[static_cast<size_t>(f.slot[i]) * Bp + k] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -319,7 +324,7 @@ void finalize(BatchWS &w, int nblocks, std::initializer_list<int> slots) {
     BFin f{};
     f.nacc = 0;
     for (int s : slots) f.slot[f.nacc++] = s;
-    hipLaunchKernelGGL(kb_finalize, dim3((w.Bp + 255) / 256), dim3(256), 0, w.stream, w.partials.p, nblocks, w.Bp, f,
+    hipLaunchKernelGGL(kb_finalize, dim3((w.Bp + 63) / 64, f.nacc), dim3(256), 0, w.stream, w.partials.p, nblocks, w.Bp, f,
                        w.SC.p);
 }
 
