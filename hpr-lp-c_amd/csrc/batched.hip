@@ -115,33 +115,37 @@ __global__ void __launch_bounds__(256) kb_half(int rows, const int *__restrict__
     for (int r = blockIdx.x * g.rows_per_block + wave * g.rows_per_wave + sub; r < rows;
          r += gridDim.x * g.rows_per_block) {
         if (!act) continue;
+        // the panel operands do not depend on the row sum: issue their loads first so that they
+        // overlap the gather chain of the SpMM loop
+        const size_t t = static_cast<size_t>(r) * Bp + k;
+        const double p_i = a.P[t], p_lo = a.lo[t], p_hi = a.hi[t], p_last = a.last[t];
+        const double p_cost = XHALF ? a.cost[t] : 0.0;
         double s = 0.0;
         const int e = rowptr[r + 1];
         for (int p = rowptr[r]; p < e; ++p) s += val[p] * a.V[static_cast<size_t>(col[p]) * Bp + k];
-        const size_t t = static_cast<size_t>(r) * Bp + k;
         if (XHALF) {
-            const double xi = a.P[t];
-            const double zt = xi + sig * (s - a.cost[t]);
-            const double xb = fmin(fmax(zt, a.lo[t]), a.hi[t]);
+            const double xi = p_i;
+            const double zt = xi + sig * (s - p_cost);
+            const double xb = fmin(fmax(zt, p_lo), p_hi);
             const double xh = 2.0 * xb - xi;
             a.P_hat[t] = xh;
-            a.P[t] = f2 * xh + f1 * a.last[t];
+            a.P[t] = f2 * xh + f1 * p_last;
             if (CHECK) {
                 const double zb = (xb - zt) / sig, dx = xb - xh;
                 a.delta[t] = dx;
                 a.aux[t] = zb;
                 a.bar[t] = xb;
-                acc[0] += a.cost[t] * xb;
+                acc[0] += p_cost * xb;
                 acc[1] += xb * zb;
                 acc[2 % NACC] += dx * dx;
             }
         } else {
-            const double yi = a.P[t];
+            const double yi = p_i;
             const double v = s - fact1 * yi;
-            const double d = fmax(a.lo[t] - v, fmin(a.hi[t] - v, 0.0));
+            const double d = fmax(p_lo - v, fmin(p_hi - v, 0.0));
             const double yb = d / fact1;
             const double yh = 2.0 * yb - yi;
-            a.P[t] = f2 * yh + f1 * a.last[t];
+            a.P[t] = f2 * yh + f1 * p_last;
             if (CHECK) {
                 const double dy = yb - yh, yo = v + d;
                 a.delta[t] = dy;
@@ -339,8 +343,12 @@ void launch_half_pair(BatchWS &w, bool check) {
         hipLaunchKernelGGL((kb_half<false, true>), gyd, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
         finalize(w, w.gy, {B_YOBJ_Y, B_DY2});
     } else {
-        hipLaunchKernelGGL((kb_half<true, false>), gxd, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
-        hipLaunchKernelGGL((kb_half<false, false>), gyd, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
+        // no reduction partials in the normal variant: one pass over the rows, as many workgroups as rows need
+        const Geo g = make_geo(w.Bp);
+        const dim3 fx((AT.rows + g.rows_per_block - 1) / g.rows_per_block, w.kchunks);
+        const dim3 fy((A.rows + g.rows_per_block - 1) / g.rows_per_block, w.kchunks);
+        hipLaunchKernelGGL((kb_half<true, false>), fx, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
+        hipLaunchKernelGGL((kb_half<false, false>), fy, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
     }
 }
 
