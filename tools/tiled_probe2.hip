@@ -57,7 +57,7 @@ static void gen(int m, int n, int per_row, int band, int r0, int r1, int *col, d
 // same accumulator.  Segments longer than K and entries of sparse tiles go to the remainder list.
 // ---------------------------------------------------------------------------------------------
 constexpr int K = 4;
-static int g_rotate = 0, g_band = 0;
+static int g_rotate = 0, g_band = 0, g_step_mult = 1;
 struct Step {
     int col0;     // first column of the tile (tile steps)
     int e_begin;  // entry range (multiple of K for tile steps)
@@ -161,6 +161,11 @@ static Tiled build_tiled(int m, int n, const int *rp, const int *col, const doub
             std::copy(v2.begin(), v2.end(), t.rval.begin() + rb);
             std::copy(c2.begin(), c2.end(), t.rcol.begin() + rb);
             std::copy(r2.begin(), r2.end(), t.rrow.begin() + rb);
+            // pad the tile steps of this super-block to a multiple of g_step_mult with empty steps
+            while (g_step_mult > 1 && (int)t.steps.size() > t.sb_ptr[sb] && ((int)t.steps.size() - t.sb_ptr[sb]) % g_step_mult) {
+                const Step lastst = t.steps.back();
+                t.steps.push_back(Step{lastst.col0, lastst.e_end, lastst.e_end, 2});
+            }
             t.sb_mid.push_back((int)t.steps.size());
             size_t p = rb;
             while (p < re) {
@@ -720,6 +725,119 @@ __global__ void __launch_bounds__(NT) k_tiled5(const int *__restrict__ sb_ptr, c
     for (int i = tid; i < R && r0 + i < m; i += NT) out[r0 + i] = acc[i];
 }
 
+
+// v6: two register sets processed back to back in a straight-line loop body (the step list of a
+// super-block is padded to an even count), so that the compiler can keep one step of loads in flight
+// across the barriers of the other
+template <int NT, int R, int T>
+__global__ void __launch_bounds__(NT) k_tiled6(const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
+                                               const Step *__restrict__ steps,
+                                               const double *__restrict__ tval, const uint32_t *__restrict__ tidx,
+                                               const double *__restrict__ rval, const int *__restrict__ rcol,
+                                               const uint16_t *__restrict__ rrow, const double *__restrict__ vec,
+                                               double *__restrict__ out, int m, int n, int nsb_total) {
+    constexpr int KR = ((T * 8 - 8) / (10 * NT)) < K ? ((T * 8 - 8) / (10 * NT)) : K;
+    constexpr int E = NT * KR;
+    constexpr int TPT = T / NT;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    __shared__ double acc[R];
+    __shared__ double ytile[T];
+    const int tid = threadIdx.x;
+    const int per = gridDim.x / 8;
+    const int sb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (sb >= nsb_total) return;
+    for (int i = tid; i < R; i += NT) acc[i] = 0.0;
+    const int s0 = sb_ptr[sb], smid = sb_mid[sb], s1 = sb_ptr[sb + 1];
+    if (s0 < smid) {
+        d2_t vaA, vbA, vaB, vbB;
+        u4_t ixA, ixB;
+        double tlA[TPT], tlB[TPT];
+        Step stA, stB;
+        auto issue = [&](const Step &q, d2_t &va, d2_t &vb, u4_t &ix, double (&tl)[TPT]) {
+            const int e = q.e_begin + K * tid;
+            const int ee = (e < q.e_end) ? e : q.e_begin;
+            va = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(tval + ee));
+            vb = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(tval + ee) + 1);
+            ix = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(tidx + ee));
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) tl[j] = vec[min(q.col0 + tid + j * NT, n - 1)];
+        };
+        auto process = [&](Step &st, d2_t &va, d2_t &vb, u4_t &ix, double (&tl)[TPT], int next_s) {
+            const Step cur = st;
+            const d2_t ca = va, cb = vb;
+            const u4_t cx = ix;
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+            st = steps[min(next_s, smid - 1)];
+            issue(st, va, vb, ix, tl);
+            lds_barrier();
+            if (K * tid < cur.e_end - cur.e_begin) {
+                const double v[K] = {ca.x, ca.y, cb.x, cb.y};
+                const uint32_t id[K] = {cx.x, cx.y, cx.z, cx.w};
+                uint32_t rw[K];
+                double a[K], y[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    rw[k] = id[k] & 0xffffu;
+                    a[k] = acc[rw[k]];
+                    y[k] = ytile[id[k] >> 16];
+                }
+                double sk[K];
+                sk[0] = a[0] + v[0] * y[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) sk[k] = ((rw[k] == rw[k - 1]) ? sk[k - 1] : a[k]) + v[k] * y[k];
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (k == K - 1 || rw[k] != rw[k + 1]) acc[rw[k]] = sk[k];
+            }
+        };
+        stA = steps[s0];
+        issue(stA, vaA, vbA, ixA, tlA);
+        stB = steps[s0 + 1];
+        issue(stB, vaB, vbB, ixB, tlB);
+        for (int s = s0; s < smid; s += 2) {
+            process(stA, vaA, vbA, ixA, tlA, s + 2);
+            process(stB, vaB, vbB, ixB, tlB, s + 3);
+        }
+    }
+    double *prod = ytile;
+    uint16_t *rows = reinterpret_cast<uint16_t *>(ytile + E);
+    for (int s = smid; s < s1; ++s) {
+        const Step st = steps[s];
+        const int cnt = st.e_end - st.e_begin;
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int el = tid + k * NT;
+            if (el < cnt) {
+                const int e = st.e_begin + el;
+                prod[el] = rval[e] * vec[rcol[e]];
+                rows[el + 1] = rrow[e];
+            }
+        }
+        if (tid == 0) rows[0] = 0xffffu;
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int el = tid + k * NT;
+            if (el < cnt) {
+                const uint16_t rw = rows[el + 1];
+                if (rows[el] != rw) {
+                    double sacc = acc[rw];
+                    int j = el;
+                    do { sacc += prod[j]; ++j; } while (j < cnt && rows[j + 1] == rw);
+                    acc[rw] = sacc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int r0 = sb * R;
+    for (int i = tid; i < R && r0 + i < m; i += NT) out[r0 + i] = acc[i];
+}
+
 int main(int argc, char **argv) {
     const int m = argc > 1 ? atoi(argv[1]) : 10000000, n = m, per_row = 20;
     const int band = argc > 2 ? atoi(argv[2]) : 100000;
@@ -848,9 +966,13 @@ int main(int argc, char **argv) {
     printf("m=n=%d nnz=%zu band=%d bytes=%.3f GB\n", m, nnz, band, bytes * 1e-9);
     g_band = band;
     run_cfg4("v4 NT512 R8192 T2048 KC1", k_tiled4<512, 8192, 2048, 1>, 512, 8192, 2048, 1, 256);
-    run_cfg4("v4 NT1024 R16384 T2048 KC1", k_tiled4<1024, 16384, 2048, 1>, 1024, 16384, 2048, 1, 256);
-    run_cfg4("v4 NT512 R16384 T2048 KC2", k_tiled4<512, 16384, 2048, 2>, 512, 16384, 2048, 2, 256);
-    run_cfg4("v4 NT512 R12288 T2048 KC1", k_tiled4<512, 12288, 2048, 1>, 512, 12288, 2048, 1, 256);
+    g_step_mult = 2;
+    run_cfg4("v6 NT512 R8192 T2048 D2", k_tiled6<512, 8192, 2048>, 512, 8192, 2048, 1, 256);
+    run_cfg4("v6 NT1024 R8192 T4096 D2 (1 WG/CU)", k_tiled6<1024, 8192, 4096>, 1024, 8192, 4096, 1, 512);
+    run_cfg4("v6 NT1024 R4096 T4096 D2 (2 WG/CU)", k_tiled6<1024, 4096, 4096>, 1024, 4096, 4096, 1, 512);
+    run_cfg4("v6 NT512 R4096 T2048 D2 (3 WG/CU)", k_tiled6<512, 4096, 2048>, 512, 4096, 2048, 1, 256);
+    run_cfg4("v6 NT512 R2048 T2048 D2 (5 WG/CU)", k_tiled6<512, 2048, 2048>, 512, 2048, 2048, 1, 256);
+    g_step_mult = 1;
     for (g_rotate = 0; g_rotate < 0; ++g_rotate) {
     printf("rotate=%d\n", g_rotate);
     run_cfg4("v4 NT1024 R8192 T8192 KC2", k_tiled4<1024, 8192, 8192, 2>, 1024, 8192, 8192, 2, 512);
