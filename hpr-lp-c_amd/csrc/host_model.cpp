@@ -1,9 +1,11 @@
 // host_model.cpp -- host side of the boundary: model construction/destruction and small host
 // utilities.  Mirrors the behaviour of reference src/HPRLP.cu:321-446,529-537 and
 // src/mps_reader.cpp:1397-1510 (deep copies, NULL + stderr message on bad input).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <iostream>
+#include <thread>
 
 #include "HPRLP.h"
 #include "common.h"
@@ -19,6 +21,50 @@ void csr_transpose_host(int rows, int cols, long nnz, const int *rp, const int *
     trp.assign(static_cast<size_t>(cols) + 1, 0);
     tci.resize(static_cast<size_t>(nnz));
     tv.resize(static_cast<size_t>(nnz));
+    // Large matrices: the same counting sort run by T threads over contiguous row ranges (thread t owns
+    // rows [t*chunk, ...)).  Per-thread column histograms give every thread its own write cursor per
+    // column, ordered by thread = ordered by row, so the result is identical to the sequential sort.
+    int T = 1;
+    if (nnz > 4000000) {
+        T = static_cast<int>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+        while (T > 1 && static_cast<size_t>(T) * static_cast<size_t>(cols) > 400000000UL) --T;
+    }
+    if (T > 1) {
+        const int chunk = (rows + T - 1) / T;
+        std::vector<std::vector<int>> hist(static_cast<size_t>(T));
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                hist[t].assign(static_cast<size_t>(cols), 0);
+                const int r0 = std::min(rows, t * chunk), r1 = std::min(rows, r0 + chunk);
+                for (int k = rp[r0]; k < rp[r1]; ++k) hist[t][ci[k]]++;
+            });
+        for (auto &x : th) x.join();
+        th.clear();
+        long run = 0;
+        for (int j = 0; j < cols; ++j) {  // cursor of (column j, thread t) = start of column j + entries of earlier threads
+            trp[j] = static_cast<int>(run);
+            for (int t = 0; t < T; ++t) {
+                const int c = hist[t][j];
+                hist[t][j] = static_cast<int>(run);
+                run += c;
+            }
+        }
+        trp[cols] = static_cast<int>(run);
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                const int r0 = std::min(rows, t * chunk), r1 = std::min(rows, r0 + chunk);
+                std::vector<int> &next = hist[t];
+                for (int i = r0; i < r1; ++i)
+                    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                        const int pos = next[ci[k]]++;
+                        tv[pos] = v[k];
+                        tci[pos] = i;
+                    }
+            });
+        for (auto &x : th) x.join();
+        return;
+    }
     for (long k = 0; k < nnz; ++k) trp[ci[k] + 1]++;
     for (int j = 0; j < cols; ++j) trp[j + 1] += trp[j];
     std::vector<int> next(trp.begin(), trp.end() - 1);

@@ -14,6 +14,7 @@ constexpr int kThreads = kWave * kWavesPerBlock;
 constexpr int kStreamW = 512;     // max nonzeros staged through LDS by one wave (4 KiB per vector)
 constexpr int kStreamRows = 64;   // max rows per stream block: one lane per row
 constexpr int kLongRow = 256;     // rows longer than this get a whole wave (vector mode)
+constexpr int kSplitRow = 4096;   // rows longer than this are cut into chunks of this many nonzeros
 constexpr int kNumScalars = 24;   // device scalar slots (see enum Slot)
 
 // Scalar slots filled by the reduction epilogues.  0-9 follow the reference's 10-slot buffer
@@ -51,9 +52,15 @@ struct CsrDev {
     const int4 *blk = nullptr;
     int nblk = 0;
     TiledDev tiled;  // optional column-tiled copy (tiled.h); when valid every fused launch uses it
+    // rows longer than kSplitRow: {row, first chunk slot, one past last slot, 0}; chunk sums land in
+    // long_partial[2*slot + v] and k_long_finish completes the row
+    const int4 *longrows = nullptr;
+    int nlong = 0;
+    double *long_partial = nullptr;
     int csr_grid() const { return (nblk + kWavesPerBlock - 1) / kWavesPerBlock; }
+    int finish_grid() const { return (nlong + kThreads - 1) / kThreads; }
     // workgroups of a fused launch on this matrix = number of reduction partials it writes
-    int grid() const { return tiled.valid ? tiled.grid : csr_grid(); }
+    int grid() const { return tiled.valid ? tiled.grid : csr_grid() + finish_grid(); }
 };
 
 // Device-resident iteration scalars (reference Halpern_params[4] + halpern_inner,

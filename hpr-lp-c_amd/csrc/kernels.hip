@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
         const int *__restrict__ col = A.col + k0;
         const double *__restrict__ val = A.val + k0;
 
-        if (nr == 1 && nz > kLongRow) {
-            // ---- vector mode: one long row per wave
+        if (nr <= 1 && nz > kLongRow) {
+            // ---- vector mode: one long row per wave (nr == 0: one chunk of a split row, see below)
             double s[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) s[v] = 0.0;
@@ -109,8 +109,15 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) s[v] = wave_sum(s[v]);
             if (lane == 0) {
-                typename Epi::Row rw = epi.load_row(r0);
-                epi.apply(r0, rw, s, acc);
+                if (nr == 0) {
+                    // chunk of a row longer than kSplitRow: r0 is the chunk slot; k_long_finish adds the
+                    // chunk sums in order and runs the epilogue for the row
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) A.long_partial[static_cast<size_t>(r0) * 2 + v] = s[v];
+                } else {
+                    typename Epi::Row rw = epi.load_row(r0);
+                    epi.apply(r0, rw, s, acc);
+                }
             }
         } else {
             // ---- stream mode
@@ -494,6 +501,36 @@ struct PlainEpi {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers of the fused kernel
 // ------------------------------------------------------------------------------------------------
+// Rows longer than kSplitRow are cut into chunks that separate waves of k_spmv_fused reduce; this
+// kernel adds the chunk sums of each such row in chunk order (deterministic) and runs the epilogue.
+// Its reduction partials go behind those of the main kernel (index csr_grid() + blockIdx.x).
+template <class Epi>
+__global__ void __launch_bounds__(kThreads) k_long_finish(CsrDev A, Epi epi, int main_grid) {
+    constexpr int NV = Epi::NV;
+    constexpr int NACC = Epi::NACC;
+    double acc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) acc[i] = 0.0;
+    epi.begin();
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < A.nlong) {
+        const int4 d = A.longrows[i];  // {row, first chunk slot, one past the last slot, -}
+        double s[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s[v] = 0.0;
+        for (int c = d.y; c < d.z; ++c) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[v] += A.long_partial[static_cast<size_t>(c) * 2 + v];
+        }
+        typename Epi::Row rw = epi.load_row(d.x);
+        epi.apply(d.x, rw, s, acc);
+    }
+    if constexpr (NACC > 0) {
+        // block_store_partials indexes by blockIdx.x: shift the base so that the slots follow the main kernel's
+        block_store_partials<NACC>(acc, epi.partials + main_grid, epi.stride);
+    }
+}
+
 template <class Epi>
 static void launch_fused(const CsrDev &M, const Epi &e, hipStream_t s) {
     if (M.nblk <= 0) return;
@@ -504,6 +541,8 @@ static void launch_fused(const CsrDev &M, const Epi &e, hipStream_t s) {
         }
     }
     hipLaunchKernelGGL(k_spmv_fused<Epi>, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, e);
+    if (M.nlong > 0)
+        hipLaunchKernelGGL(k_long_finish<Epi>, dim3(M.finish_grid()), dim3(kThreads), 0, s, M, e, M.csr_grid());
 }
 
 void launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s) {

@@ -19,12 +19,22 @@ namespace hprlp {
 constexpr int kMaxGraphIters = 64;
 
 // ------------------------------------------------------------------------------------------------
-std::vector<int4> build_row_blocks(int rows, const int *rowptr) {
+std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows) {
     std::vector<int4> blk;
     blk.reserve(static_cast<size_t>(rows) / 8 + 16);
-    int r = 0;
+    int r = 0, slots = 0;
     while (r < rows) {
         const int len = rowptr[r + 1] - rowptr[r];
+        if (len > kSplitRow && longrows) {
+            // a dense row/column (LPs have them): kSplitRow-sized chunks on separate waves, descriptor
+            // {chunk slot, 0, first nonzero, count}; the row itself is finished by k_long_finish
+            const int first = slots;
+            for (int k = rowptr[r]; k < rowptr[r + 1]; k += kSplitRow)
+                blk.push_back(make_int4(slots++, 0, k, std::min(kSplitRow, rowptr[r + 1] - k)));
+            longrows->push_back(make_int4(r, first, slots, 0));
+            ++r;
+            continue;
+        }
         if (len > kLongRow) {
             blk.push_back(make_int4(r, 1, rowptr[r], len));
             ++r;
@@ -56,13 +66,27 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     col.upload(ci, nnz);
     val.alloc(nnz);
     val.upload(v, nnz);
-    std::vector<int4> b = build_row_blocks(rows, rp);
+    std::vector<int4> lr;
+    std::vector<int4> b = build_row_blocks(rows, rp, &lr);
+    int nslots = 0;
     for (const int4 &d : b) {
-        const bool vec = (d.y == 1 && d.w > kLongRow);
-        if (!vec && (d.w > kStreamW || d.y > kStreamRows || d.y < 1)) throw std::runtime_error("bad row block");
+        const bool vec = (d.y <= 1 && d.w > kLongRow);
+        if (d.y == 0) {
+            if (!vec || d.w > kSplitRow || d.x != nslots++) throw std::runtime_error("bad split-row block");
+        } else if (!vec && (d.w > kStreamW || d.y > kStreamRows || d.y < 1)) {
+            throw std::runtime_error("bad row block");
+        }
     }
     blk.alloc(b.size());
     blk.upload(b.data(), b.size());
+    if (!lr.empty()) {
+        longrows.alloc(lr.size());
+        longrows.upload(lr.data(), lr.size());
+        long_partial.alloc_zero(static_cast<size_t>(nslots) * 2);
+        view.longrows = longrows.p;
+        view.nlong = static_cast<int>(lr.size());
+        view.long_partial = long_partial.p;
+    }
     view.rows = rows;
     view.cols = cols;
     view.nnz = nnz;

@@ -38,14 +38,15 @@ struct TraceRow {  // same layout as hprlp_trace_row in include/hprlp_amd.h
 struct DeviceMatrix {
     DBuf<int> rowptr, col;
     DBuf<double> val;
-    DBuf<int4> blk;
+    DBuf<int4> blk, longrows;
+    DBuf<double> long_partial;
     DeviceTiled tiled;  // optional column-tiled copy for large matrices with column locality (tiled.h)
     CsrDev view;
     void upload(int rows, int cols, const int *rp, const int *ci, const double *v);
     void refresh_tiled(hipStream_t s);  // re-gather the tiled values from the CSR values (after scaling)
 };
 
-std::vector<int4> build_row_blocks(int rows, const int *rowptr);
+std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows);
 
 struct Solver {
     HPRLP_parameters prm;

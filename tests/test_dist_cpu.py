@@ -52,3 +52,32 @@ def test_partition_edge_cases():
     assert L.hprlp_partition(10, 4, 3, C.byref(off), C.byref(cnt)) == 3 and (off.value, cnt.value) == (9, 1)
     assert L.hprlp_partition(10, 0, 0, C.byref(off), C.byref(cnt)) < 0
     assert L.hprlp_partition(10, 2, 2, C.byref(off), C.byref(cnt)) < 0
+
+
+def test_threaded_host_transpose_equals_sequential():
+    """Matrices above 4M nonzeros are transposed by 8 threads (host_model.cpp); the result must be the
+    stable counting sort of reference src/utils.cu:203-232, i.e. identical to the oracle's."""
+    import ctypes as C
+
+    import numpy as np
+
+    import bench_helpers as bh
+    from conftest import hprlp
+    from dist_worker import Shard, arr
+    from oracle import oracle as O
+    m = n = 260_000
+    rp, ci, v = bh.gen_banded(m, n, 17, 3000, seed=9)
+    assert len(v) > 4_000_000
+    z = np.zeros
+    model = hprlp.Model.from_csr(m, n, rp, ci, v, z(m), z(m), z(n), z(n), z(n))
+    L = hprlp.lib()
+    sh = Shard()
+    L.hprlp_extract_shard.argtypes = [C.POINTER(hprlp.CLPInfo), C.c_int, C.c_int, C.POINTER(Shard)]
+    assert L.hprlp_extract_shard(model._ptr, 0, 1, C.byref(sh)) == 0
+    trp, tci, tv = O.transpose(m, n, rp, ci, v)
+    assert np.array_equal(arr(sh.AT_rowptr, n + 1, np.int32), trp)
+    nz = int(trp[-1])
+    assert np.array_equal(arr(sh.AT_col, nz, np.int32), tci) and np.array_equal(arr(sh.AT_val, nz, np.float64), tv)
+    L.hprlp_free_shard.argtypes = [C.POINTER(Shard)]
+    L.hprlp_free_shard(C.byref(sh))
+    model.free()

@@ -151,3 +151,38 @@ def test_independent_kkt_on_c3(gpu):
     assert abs(r.primal_obj - lp["obj_star"]) <= 1e-5 * (1 + abs(lp["obj_star"]))
     assert (r.x >= lp["l"] - 1e-9).all() and (r.x <= lp["u"] + 1e-9).all()
     model.free()
+
+
+def test_dense_rows_and_columns_are_split(gpu):
+    """A row with 9000 nonzeros and a column with 5000 (both above the 4096 split threshold): chunked over
+    several waves, finished by k_long_finish; compared with the oracle step by step and with HiGHS."""
+    from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
+    rng = np.random.default_rng(8)
+    m, n = 6000, 12000
+    A = sparse.random(m, n, density=0.0004, random_state=5, format="lil")
+    cols = np.sort(rng.choice(n, size=9000, replace=False))
+    A[17, cols] = rng.uniform(0.5, 1.5, size=9000)
+    rows = np.sort(rng.choice(m, size=5000, replace=False))
+    A[rows, 33] = rng.uniform(0.5, 1.5, size=5000).reshape(-1, 1)
+    A = sparse.csr_matrix(A); A.sort_indices()
+    assert np.diff(A.indptr).max() >= 9000 and np.diff(sparse.csc_matrix(A).indptr).max() >= 5000
+    x0 = rng.uniform(0, 1, n)
+    b = A @ x0
+    AL = np.full(m, -INF); AU = b + 0.1
+    c = rng.uniform(-1, 1, n); l = np.zeros(n); u = np.full(n, 2.0)
+    model = hprlp.Model.from_csr(m, n, A.indptr, A.indices, A.data, AL, AU, l, u, c)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+    ref = O.ScaledLP(m, n, A.indptr, A.indices, A.data, AL, AU, l, u, c, O.Params.default(use_CR_scaling=0))
+    s.scale()
+    adopt_gpu_data(s, ref)
+    st = run_steps(s, ref, 0.7, 1.2, [(12, True), (3, True)])
+    for name in NAMES_N + NAMES_M:
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-10, atol=1e-12, err_msg=name)   # tree/chunk order
+    got = s.residuals(16, True)
+    assert np.isfinite(got["kkt"]) and np.isfinite(got["weighted_norm"])
+    s.close()
+    r = model.solve(hprlp.Parameters(stop_tol=1e-6, use_presolve=False))
+    assert r.status == "OPTIMAL"
+    want = highs(A, AL, AU, l, u, c)
+    assert abs(r.primal_obj - want) <= 1e-4 * (1 + abs(want))
+    model.free()

@@ -55,7 +55,7 @@ def test_tiled_equals_stream_kernel_end_to_end(gpu, force_tiled):
     """Same LP solved with the tiled and with the stream kernel: same iteration count, same optimum."""
     m = n = 20000
     lp, model = build(m, n, 10, 300)
-    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False, max_iter=20000)
+    prm = hprlp.Parameters(stop_tol=1e-4, use_presolve=False, max_iter=3000)
     r_tiled = model.solve(prm)
     os.environ["HPRLP_NO_TILED"] = "1"
     r_stream = model.solve(prm)
