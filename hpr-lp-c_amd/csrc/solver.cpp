@@ -22,6 +22,11 @@ constexpr int kMaxGraphIters = 64;
 std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows) {
     std::vector<int4> blk;
     blk.reserve(static_cast<size_t>(rows) / 8 + 16);
+    // block shape: at most cap_rows rows and cap_nnz nonzeros per wave (tuning knobs; the kernel needs
+    // rows <= kStreamRows and nonzeros <= kStreamW)
+    int cap_rows = kStreamRows, cap_nnz = kStreamW;
+    if (const char *e = std::getenv("HPRLP_STREAM_ROWS")) cap_rows = std::min(kStreamRows, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("HPRLP_STREAM_NNZ")) cap_nnz = std::min(kStreamW, std::max(kLongRow, std::atoi(e)));
     int r = 0, slots = 0;
     while (r < rows) {
         const int len = rowptr[r + 1] - rowptr[r];
@@ -42,9 +47,9 @@ std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4
         }
         const int start = r;
         int nz = 0;
-        while (r < rows && r - start < kStreamRows) {
+        while (r < rows && r - start < cap_rows) {
             const int l2 = rowptr[r + 1] - rowptr[r];
-            if (l2 > kLongRow || nz + l2 > kStreamW) break;
+            if (l2 > kLongRow || (nz + l2 > cap_nnz && r > start)) break;
             nz += l2;
             ++r;
         }
