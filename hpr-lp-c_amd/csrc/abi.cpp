@@ -1,11 +1,15 @@
 // abi.cpp -- extern "C" boundary: the reference's solve entry points (include/HPRLP.h) and the
 // step-level extension (include/hprlp_amd.h).  Every entry point catches exceptions.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <iomanip>
 #include <iostream>
 
 #include "hprlp_amd.h"
 #include "dist.h"
+#include "presolve.h"
 #include "solver.h"
 #include "version.h"
 
@@ -80,9 +84,11 @@ extern "C" HPRLP_results HPRLP_main_solve(const LP_info_cpu *model, const HPRLP_
     }
 }
 
-// reference src/HPRLP.cu:493-524.  The embedded PSLP presolve (reference src/pslp_integration.cpp) is
-// a CPU component outside the accelerated path: use_presolve is accepted and
-// the model is solved as given.
+// reference src/HPRLP.cu:493-524.  With use_presolve (the default) the model is first reduced on the
+// host (presolve.h -- our own in-process presolver where the reference forks a PSLP worker,
+// src/pslp_integration.cpp:628-713), the reduced model goes through HPRLP_main_solve and the result
+// is mapped back to the original dimensions and checked against the original model
+// (src/pslp_integration.cpp:715-787).  If the presolver declines, the original model is solved.
 extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters *param) {
     if (!model) {
         std::cerr << "[error] Null model pointer" << std::endl;
@@ -90,7 +96,94 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
     }
     HPRLP_parameters dflt;
     const HPRLP_parameters *p = param ? param : &dflt;
-    return HPRLP_main_solve(model, p);
+    if (!p->use_presolve) return HPRLP_main_solve(model, p);
+
+    Presolve pre;
+    bool reduced = false;
+    try {
+        std::cout << "Doing presolve..." << std::endl;
+        reduced = pre.run(model);
+        std::cout << "Presolve time: " << pre.stats().seconds << " seconds" << std::endl;
+    } catch (const std::exception &e) {
+        std::cerr << "[warn] presolve failed (" << e.what() << "); solving original model" << std::endl;
+        reduced = false;
+    }
+    if (!reduced) {
+        std::cout << "Presolve left the model unchanged; solving original model" << std::endl;
+        return HPRLP_main_solve(model, p);
+    }
+    const Presolve::Stats &st = pre.stats();
+    std::cout << "Presolve reduced problem: (" << model->m << ", " << model->n << ") -> (" << pre.reduced()->m << ", "
+              << pre.reduced()->n << ")  [fixed cols " << st.fixed_cols << ", empty cols " << st.empty_cols
+              << ", singleton rows " << st.singleton_rows << ", empty rows " << st.empty_rows << ", redundant rows "
+              << st.redundant_rows << "]" << std::endl;
+    HPRLP_results r = HPRLP_main_solve(pre.reduced(), p);
+    if (!(r.x && r.y && r.z)) return r;
+    double *x = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->n, 1)));
+    double *y = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->m, 1)));
+    double *z = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->n, 1)));
+    if (!x || !y || !z) {
+        std::free(x); std::free(y); std::free(z);
+        std::free(r.x); std::free(r.y); std::free(r.z);
+        std::cerr << "[error] out of memory in postsolve" << std::endl;
+        return make_error_result("ERROR");
+    }
+    pre.postsolve(r.x, r.y, r.z, x, y, z);
+    std::free(r.x); std::free(r.y); std::free(r.z);
+    r.x = x; r.y = y; r.z = z;
+    if (std::strcmp(r.status, "OPTIMAL") == 0) {
+        const OriginalKkt k = original_kkt(model, x, y, z);
+        const double err = std::max(k.primal_feas, std::max(k.dual_feas, k.gap));
+        if (err <= p->stop_tol) {
+            std::cout << "Postsolve original KKT check passed" << std::endl;
+        } else {
+            std::cout << "Warning: postsolve original KKT check failed (the primal solution and objective are reliable)\n"
+                      << "  Primal Residual: " << k.primal_feas << "  Dual Residual: " << k.dual_feas
+                      << "  Relative Gap: " << k.gap << "  (tolerance " << p->stop_tol << ")" << std::endl;
+        }
+    } else {
+        std::cout << "Skipping postsolve original KKT check since the reduced solution is not optimal" << std::endl;
+    }
+    return r;
+}
+
+// presolve as separate steps (host only; used by the CPU tests and by callers that want the maps)
+struct hprlp_presolve {
+    Presolve p;
+};
+extern "C" hprlp_presolve *hprlp_presolve_run(const LP_info_cpu *model) {
+    hprlp_presolve *h = nullptr;
+    try {
+        h = new hprlp_presolve();
+        if (h->p.run(model)) return h;
+        set_last_error("presolve left the model unchanged");
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+    }
+    delete h;
+    return nullptr;
+}
+extern "C" const LP_info_cpu *hprlp_presolve_reduced(const hprlp_presolve *h) { return h ? h->p.reduced() : nullptr; }
+extern "C" int hprlp_presolve_stats(const hprlp_presolve *h, int out[8]) {
+    if (!h || !out) return -1;
+    const Presolve::Stats &s = h->p.stats();
+    out[0] = h->p.reduced()->m; out[1] = h->p.reduced()->n; out[2] = s.fixed_cols; out[3] = s.empty_cols;
+    out[4] = s.singleton_rows; out[5] = s.empty_rows; out[6] = s.redundant_rows; out[7] = s.passes;
+    return 0;
+}
+extern "C" int hprlp_presolve_postsolve(const hprlp_presolve *h, const double *xr, const double *yr, const double *zr,
+                                        double *x, double *y, double *z) {
+    if (!h || !xr || !yr || !zr || !x || !y || !z) return -1;
+    h->p.postsolve(xr, yr, zr, x, y, z);
+    return 0;
+}
+extern "C" void hprlp_presolve_free(hprlp_presolve *h) { delete h; }
+extern "C" int hprlp_original_kkt(const LP_info_cpu *model, const double *x, const double *y, const double *z,
+                                  double out[5]) {
+    if (!model || !model->A || !x || !y || !z || !out) return -1;
+    const OriginalKkt k = original_kkt(model, x, y, z);
+    out[0] = k.primal_feas; out[1] = k.dual_feas; out[2] = k.gap; out[3] = k.primal_obj; out[4] = k.dual_obj;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

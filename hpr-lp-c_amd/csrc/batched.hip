@@ -90,6 +90,45 @@ struct HalfArgs {
     double *partials;
 };
 
+// the half-step update of one (row, problem) element given the SpMM row sum s
+template <bool XHALF, bool CHECK, int NACC>
+__device__ __forceinline__ void half_update(const HalfArgs &a, size_t t, double s, double p_i, double p_lo, double p_hi,
+                                            double p_last, double p_cost, double sig, double fact1, double f1,
+                                            double f2, double (&acc)[NACC]) {
+    if (XHALF) {
+        const double xi = p_i;
+        const double zt = xi + sig * (s - p_cost);
+        const double xb = fmin(fmax(zt, p_lo), p_hi);
+        const double xh = 2.0 * xb - xi;
+        a.P_hat[t] = xh;
+        a.P[t] = f2 * xh + f1 * p_last;
+        if (CHECK) {
+            const double zb = (xb - zt) / sig, dx = xb - xh;
+            a.delta[t] = dx;
+            a.aux[t] = zb;
+            a.bar[t] = xb;
+            acc[0] += p_cost * xb;
+            acc[1 % NACC] += xb * zb;
+            acc[2 % NACC] += dx * dx;
+        }
+    } else {
+        const double yi = p_i;
+        const double v = s - fact1 * yi;
+        const double d = fmax(p_lo - v, fmin(p_hi - v, 0.0));
+        const double yb = d / fact1;
+        const double yh = 2.0 * yb - yi;
+        a.P[t] = f2 * yh + f1 * p_last;
+        if (CHECK) {
+            const double dy = yb - yh, yo = v + d;
+            a.delta[t] = dy;
+            a.bar[t] = yb;
+            a.aux[t] = yo;
+            acc[0] += yo * yb;
+            acc[1 % NACC] += dy * dy;
+        }
+    }
+}
+
 template <bool XHALF, bool CHECK>
 __global__ void __launch_bounds__(256) kb_half(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                const double *__restrict__ val, int Bp, HalfArgs a) {
@@ -123,37 +162,79 @@ __global__ void __launch_bounds__(256) kb_half(int rows, const int *__restrict__
         double s = 0.0;
         const int e = rowptr[r + 1];
         for (int p = rowptr[r]; p < e; ++p) s += val[p] * a.V[static_cast<size_t>(col[p]) * Bp + k];
-        if (XHALF) {
-            const double xi = p_i;
-            const double zt = xi + sig * (s - p_cost);
-            const double xb = fmin(fmax(zt, p_lo), p_hi);
-            const double xh = 2.0 * xb - xi;
-            a.P_hat[t] = xh;
-            a.P[t] = f2 * xh + f1 * p_last;
-            if (CHECK) {
-                const double zb = (xb - zt) / sig, dx = xb - xh;
-                a.delta[t] = dx;
-                a.aux[t] = zb;
-                a.bar[t] = xb;
-                acc[0] += p_cost * xb;
-                acc[1] += xb * zb;
-                acc[2 % NACC] += dx * dx;
+        half_update<XHALF, CHECK, NACC>(a, t, s, p_i, p_lo, p_hi, p_last, p_cost, sig, fact1, f1, f2, acc);
+    }
+    if (CHECK) block_store_per_problem<NACC>(acc, g, k, true, a.partials);
+}
+
+// Bp >= 64 (a wave = 64 problems of ONE row): the row index is wave-uniform, so row pointers, column
+// indices and values come through the scalar cache, and a wave works on kRowsPerWave consecutive rows
+// at once -- their nonzeros are one contiguous CSR range -- with all panel loads and up to 8 gathers
+// in flight before the first use.  Each row is still summed in CSR order.
+constexpr int kRowsPerWave = 4;
+
+template <bool XHALF, bool CHECK>
+__global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                 const double *__restrict__ val, int Bp, HalfArgs a) {
+    constexpr int RW = kRowsPerWave, G = 8;
+    static_assert(RW == 4, "the row select below is written for 4 rows");
+    const Geo g = make_geo(Bp);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.y * 64 + lane;
+    constexpr int NACC = CHECK ? (XHALF ? 3 : 2) : 1;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+
+    const bool act = a.ctl.active[k] != 0;
+    const int kk = XHALF ? a.ctl.kx[k] : a.ctl.ky[k];
+    const double sig = a.ctl.sigma[k];
+    const double f1 = 1.0 / (static_cast<double>(kk) + 2.0), f2 = 1.0 - f1;
+    const double fact1 = a.lambda_max * sig;
+    if (blockIdx.x == 0 && wave == 0) {
+        if (XHALF) a.ctl.ky[k] = kk;
+        else if (act) a.ctl.kx[k] = kk + 1;
+    }
+    const double *__restrict__ V = a.V + k;
+    for (int rb = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * RW); rb < rows; rb += gridDim.x * 4 * RW) {
+        int pb[RW + 1];
+#pragma unroll
+        for (int i = 0; i <= RW; ++i) pb[i] = rowptr[min(rb + i, rows)];
+        double p_i[RW], p_lo[RW], p_hi[RW], p_last[RW], p_cost[RW], s[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const size_t t = static_cast<size_t>(min(rb + i, rows - 1)) * Bp + k;
+            p_i[i] = a.P[t], p_lo[i] = a.lo[t], p_hi[i] = a.hi[t], p_last[i] = a.last[t];
+            p_cost[i] = XHALF ? a.cost[t] : 0.0;
+            s[i] = 0.0;
+        }
+        const int pend = pb[RW];
+        for (int p = pb[0]; p < pend; p += G) {
+            double gv[G], av[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int q = min(p + u, pend - 1);
+                av[u] = val[q];
+                gv[u] = V[static_cast<size_t>(col[q]) * Bp];
             }
-        } else {
-            const double yi = p_i;
-            const double v = s - fact1 * yi;
-            const double d = fmax(p_lo - v, fmin(p_hi - v, 0.0));
-            const double yb = d / fact1;
-            const double yh = 2.0 * yb - yi;
-            a.P[t] = f2 * yh + f1 * p_last;
-            if (CHECK) {
-                const double dy = yb - yh, yo = v + d;
-                a.delta[t] = dy;
-                a.bar[t] = yb;
-                a.aux[t] = yo;
-                acc[0] += yo * yb;
-                acc[1 % NACC] += dy * dy;
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int q = p + u;
+                if (q < pend) {
+                    const double prod = av[u] * gv[u];
+                    if (q < pb[1]) s[0] += prod;
+                    else if (q < pb[2]) s[1] += prod;
+                    else if (q < pb[3]) s[2] += prod;
+                    else s[3] += prod;
+                }
             }
+        }
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < RW; ++i)
+                if (rb + i < rows)
+                    half_update<XHALF, CHECK, NACC>(a, static_cast<size_t>(rb + i) * Bp + k, s[i], p_i[i], p_lo[i], p_hi[i],
+                                                    p_last[i], p_cost[i], sig, fact1, f1, f2, acc);
         }
     }
     if (CHECK) block_store_per_problem<NACC>(acc, g, k, true, a.partials);
@@ -278,17 +359,32 @@ struct BFin {
 };
 // grid (ceil(Bp/64), nacc): a block sums one accumulator for 64 problems; its 4 waves stride over the
 // producer blocks (lane = problem: coalesced), then combine in a fixed order
-__global__ void __launch_bounds__(256) kb_finalize(const double *partials, int nblocks, int Bp, BFin f, double *SC) {
-    __shared__ double red[4][64];
+__global__ void __launch_bounds__(1024) kb_finalize(const double *partials, int nblocks, int Bp, BFin f, double *SC) {
+    // 16 waves, four independent load chains per wave; fixed combination order => deterministic
+    __shared__ double red[16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 64 + lane, i = blockIdx.y;
-    double v = 0.0;
-    if (k < Bp)
-        for (int b = wave; b < nblocks; b += 4) v += partials[(static_cast<size_t>(b) * f.nacc + i) * Bp + k];
-    red[wave][lane] = v;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    if (k < Bp) {
+        const double *__restrict__ p = partials + static_cast<size_t>(i) * Bp + k;
+        const size_t st = static_cast<size_t>(f.nacc) * Bp;
+        int b = wave;
+        for (; b + 48 < nblocks; b += 64) {
+            v0 += p[b * st];
+            v1 += p[(b + 16) * st];
+            v2 += p[(b + 32) * st];
+            v3 += p[(b + 48) * st];
+        }
+        for (; b < nblocks; b += 16) v0 += p[b * st];
+    }
+    red[wave][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
-    if (wave == 0 && k < Bp)
-        SC[static_cast<size_t>(f.slot[i]) * Bp + k] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (wave == 0 && k < Bp) {
+        double v = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) v += red[w][lane];
+        SC[static_cast<size_t>(f.slot[i]) * Bp + k] = v;
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -328,7 +424,7 @@ void finalize(BatchWS &w, int nblocks, std::initializer_list<int> slots) {
     BFin f{};
     f.nacc = 0;
     for (int s : slots) f.slot[f.nacc++] = s;
-    hipLaunchKernelGGL(kb_finalize, dim3((w.Bp + 63) / 64, f.nacc), dim3(256), 0, w.stream, w.partials.p, nblocks, w.Bp, f,
+    hipLaunchKernelGGL(kb_finalize, dim3((w.Bp + 63) / 64, f.nacc), dim3(1024), 0, w.stream, w.partials.p, nblocks, w.Bp, f,
                        w.SC.p);
 }
 
@@ -337,18 +433,27 @@ void launch_half_pair(BatchWS &w, bool check) {
     HalfArgs xa{w.Y.p, w.X.p, w.Xh.p, w.L.p, w.U.p, w.C.p, w.lastX.p, w.Xb.p, w.Zb.p, w.DX.p, w.ctl, w.lambda_max, w.partials.p};
     HalfArgs ya{w.Xh.p, w.Y.p, nullptr, w.AL.p, w.AU.p, nullptr, w.lastY.p, w.Yb.p, w.Yobj.p, w.DY.p, w.ctl, w.lambda_max, w.partials.p};
     const dim3 gxd(w.gx, w.kchunks), gyd(w.gy, w.kchunks), blk(256);
+    const bool wide = w.Bp >= 64;  // a wave = one row: kb_half64
     if (check) {
-        hipLaunchKernelGGL((kb_half<true, true>), gxd, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
+        if (wide) hipLaunchKernelGGL((kb_half64<true, true>), gxd, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
+        else hipLaunchKernelGGL((kb_half<true, true>), gxd, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
         finalize(w, w.gx, {B_CX, B_XZ, B_DX2});
-        hipLaunchKernelGGL((kb_half<false, true>), gyd, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
+        if (wide) hipLaunchKernelGGL((kb_half64<false, true>), gyd, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
+        else hipLaunchKernelGGL((kb_half<false, true>), gyd, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
         finalize(w, w.gy, {B_YOBJ_Y, B_DY2});
     } else {
         // no reduction partials in the normal variant: one pass over the rows, as many workgroups as rows need
         const Geo g = make_geo(w.Bp);
-        const dim3 fx((AT.rows + g.rows_per_block - 1) / g.rows_per_block, w.kchunks);
-        const dim3 fy((A.rows + g.rows_per_block - 1) / g.rows_per_block, w.kchunks);
-        hipLaunchKernelGGL((kb_half<true, false>), fx, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
-        hipLaunchKernelGGL((kb_half<false, false>), fy, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
+        const int rpb = wide ? 4 * kRowsPerWave : g.rows_per_block;
+        const dim3 fx((AT.rows + rpb - 1) / rpb, w.kchunks);
+        const dim3 fy((A.rows + rpb - 1) / rpb, w.kchunks);
+        if (wide) {
+            hipLaunchKernelGGL((kb_half64<true, false>), fx, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
+            hipLaunchKernelGGL((kb_half64<false, false>), fy, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
+        } else {
+            hipLaunchKernelGGL((kb_half<true, false>), fx, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
+            hipLaunchKernelGGL((kb_half<false, false>), fy, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
+        }
     }
 }
 

@@ -46,6 +46,7 @@ enum Slot : int {
 struct CsrDev {
     int rows = 0, cols = 0;
     int nnz = 0;
+    int nt = 1;  // stream the matrix with nontemporal loads (large matrices); 0: keep it in L2 between launches
     const int *rowptr = nullptr;
     const int *col = nullptr;
     double *val = nullptr;

@@ -136,10 +136,18 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
                     const int q0 = min(j0, last), q1 = min(j1, last), q2 = min(j2, last), q3 = min(j3, last);
                     // the matrix is read once per launch: nontemporal loads keep it from evicting the
                     // gathered vector from L2 (measured +8 % on the 200M-nnz banded matrix)
-                    double a0 = __builtin_nontemporal_load(val + q0), a1 = __builtin_nontemporal_load(val + q1),
-                           a2 = __builtin_nontemporal_load(val + q2), a3 = __builtin_nontemporal_load(val + q3);
-                    int c0 = __builtin_nontemporal_load(col + q0), c1 = __builtin_nontemporal_load(col + q1),
+                    // a matrix that fits in the L2s is read with the default policy so that it stays there
+                    double a0, a1, a2, a3;
+                    int c0, c1, c2, c3;
+                    if (A.nt) {
+                        a0 = __builtin_nontemporal_load(val + q0), a1 = __builtin_nontemporal_load(val + q1);
+                        a2 = __builtin_nontemporal_load(val + q2), a3 = __builtin_nontemporal_load(val + q3);
+                        c0 = __builtin_nontemporal_load(col + q0), c1 = __builtin_nontemporal_load(col + q1);
                         c2 = __builtin_nontemporal_load(col + q2), c3 = __builtin_nontemporal_load(col + q3);
+                    } else {
+                        a0 = val[q0], a1 = val[q1], a2 = val[q2], a3 = val[q3];
+                        c0 = col[q0], c1 = col[q1], c2 = col[q2], c3 = col[q3];
+                    }
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
                         const double *__restrict__ g = epi.gv[v];

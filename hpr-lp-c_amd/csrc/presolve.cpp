@@ -1,0 +1,312 @@
+// presolve.cpp -- in-process LP presolve / postsolve (design and scope: presolve.h).
+#include "presolve.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+
+#include "HPRLP.h"
+#include "common.h"
+
+namespace hprlp {
+namespace {
+
+constexpr double kFeasTol = 1e-9;  // a crossing of bounds beyond this (relative) is left to the solver
+constexpr int kMaxPasses = 50;
+
+inline bool fin(double v) { return std::isfinite(v); }
+inline double rel(double v) { return kFeasTol * (1.0 + std::abs(v)); }
+
+}  // namespace
+
+Presolve::~Presolve() {
+    if (reduced_) free_model(reduced_);
+}
+
+bool Presolve::run(const LP_info_cpu *model) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!model || !model->A || model->m <= 0 || model->n <= 0) return false;
+    org_ = model;
+    m_ = model->m;
+    n_ = model->n;
+    const int m = m_, n = n_;
+    const int *rp = model->A->rowPtr, *ci = model->A->colIndex;
+    const double *av = model->A->value;
+    const long nnz = rp[m];
+    csr_transpose_host(m, n, nnz, rp, ci, av, trp_, tci_, tv_);
+
+    std::vector<double> AL(model->AL, model->AL + m), AU(model->AU, model->AU + m);
+    std::vector<double> l(model->l, model->l + n), u(model->u, model->u + n);
+    std::vector<char> row_alive(m, 1), col_alive(n, 1);
+    std::vector<int> row_cnt(m), col_cnt(n);
+    for (int i = 0; i < m; ++i) row_cnt[i] = rp[i + 1] - rp[i];
+    for (int j = 0; j < n; ++j) col_cnt[j] = trp_[j + 1] - trp_[j];
+    // explicit zeros do not count as structure
+    for (int i = 0; i < m; ++i)
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            if (av[k] == 0.0) {
+                --row_cnt[i];
+                --col_cnt[ci[k]];
+            }
+    double offset = 0.0;
+    bool give_up = false;
+
+    auto fix_column = [&](int j, double v, Kind kind) {
+        for (int k = trp_[j]; k < trp_[j + 1]; ++k) {
+            const int i = tci_[k];
+            if (!row_alive[i] || tv_[k] == 0.0) continue;
+            const double s = tv_[k] * v;
+            if (fin(AL[i])) AL[i] -= s;
+            if (fin(AU[i])) AU[i] -= s;
+            --row_cnt[i];
+        }
+        offset += model->c[j] * v;
+        col_alive[j] = 0;
+        stack_.push_back(Record{kind, -1, j, 0.0, v, l[j], u[j], v, v});
+        if (kind == FixedCol) ++stats_.fixed_cols;
+        else ++stats_.empty_cols;
+    };
+    auto drop_row = [&](int i, Kind kind) {
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            if (col_alive[ci[k]] && av[k] != 0.0) --col_cnt[ci[k]];
+        row_alive[i] = 0;
+        if (kind != SingletonRow) stack_.push_back(Record{kind, i, -1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0});
+    };
+
+    bool changed = true;
+    while (changed && !give_up && stats_.passes < kMaxPasses) {
+        changed = false;
+        ++stats_.passes;
+        // ---- columns whose bounds coincide
+        for (int j = 0; j < n && !give_up; ++j) {
+            if (!col_alive[j]) continue;
+            if (l[j] > u[j]) {
+                if (l[j] - u[j] > rel(l[j])) give_up = true;  // infeasible bounds: the solver reports it
+                else l[j] = u[j] = 0.5 * (l[j] + u[j]);
+            }
+            if (!give_up && fin(l[j]) && l[j] == u[j]) {
+                fix_column(j, l[j], FixedCol);
+                changed = true;
+            }
+        }
+        // ---- rows
+        for (int i = 0; i < m && !give_up; ++i) {
+            if (!row_alive[i]) continue;
+            if (row_cnt[i] == 0) {
+                if (AL[i] > rel(AL[i]) || AU[i] < -rel(AU[i])) {
+                    give_up = true;
+                    break;
+                }
+                drop_row(i, EmptyRow);
+                ++stats_.empty_rows;
+                changed = true;
+                continue;
+            }
+            if (row_cnt[i] == 1) {
+                int j = -1;
+                double a = 0.0;
+                for (int k = rp[i]; k < rp[i + 1]; ++k)
+                    if (col_alive[ci[k]] && av[k] != 0.0) {
+                        j = ci[k];
+                        a = av[k];
+                        break;
+                    }
+                double lo = a > 0 ? AL[i] / a : AU[i] / a;
+                double up = a > 0 ? AU[i] / a : AL[i] / a;
+                if (std::isnan(lo) || std::isnan(up)) continue;  // 0 * inf style input: leave the row alone
+                const double l_new = std::max(l[j], lo), u_new = std::min(u[j], up);
+                if (l_new > u_new && l_new - u_new > rel(l_new)) {
+                    give_up = true;
+                    break;
+                }
+                stack_.push_back(Record{SingletonRow, i, j, a, 0.0, l[j], u[j], l_new, u_new});
+                l[j] = l_new;
+                u[j] = std::max(u_new, l_new);
+                stack_.back().u_new = u[j];
+                drop_row(i, SingletonRow);
+                ++stats_.singleton_rows;
+                changed = true;
+                continue;
+            }
+            // activity bounds: a row that no point of the box can violate carries no information
+            if (!fin(AL[i]) && !fin(AU[i])) {
+                drop_row(i, RedundantRow);
+                ++stats_.redundant_rows;
+                changed = true;
+                continue;
+            }
+            double lo_act = 0.0, up_act = 0.0;
+            bool lo_inf = false, up_inf = false;
+            for (int k = rp[i]; k < rp[i + 1] && !(lo_inf && up_inf); ++k) {
+                const int j = ci[k];
+                const double a = av[k];
+                if (!col_alive[j] || a == 0.0) continue;
+                const double bl = a > 0 ? l[j] : u[j], bu = a > 0 ? u[j] : l[j];
+                if (fin(bl)) lo_act += a * bl;
+                else lo_inf = true;
+                if (fin(bu)) up_act += a * bu;
+                else up_inf = true;
+            }
+            const bool low_ok = !fin(AL[i]) || (!lo_inf && lo_act >= AL[i]);
+            const bool upp_ok = !fin(AU[i]) || (!up_inf && up_act <= AU[i]);
+            if (low_ok && upp_ok) {
+                drop_row(i, RedundantRow);
+                ++stats_.redundant_rows;
+                changed = true;
+            }
+        }
+        // ---- columns that no row uses any more
+        for (int j = 0; j < n && !give_up; ++j) {
+            if (!col_alive[j] || col_cnt[j] != 0) continue;
+            const double c = model->c[j];
+            double v;
+            if (c > 0) v = l[j];
+            else if (c < 0) v = u[j];
+            else v = fin(l[j]) ? l[j] : (fin(u[j]) ? u[j] : 0.0);
+            if (!fin(v)) continue;  // unbounded direction: keep the column, the solver sees it
+            fix_column(j, v, EmptyCol);
+            changed = true;
+        }
+    }
+    if (give_up) return false;
+
+    // ---- assemble the reduced model
+    std::vector<int> new_col(n, -1);
+    for (int j = 0; j < n; ++j)
+        if (col_alive[j]) {
+            new_col[j] = static_cast<int>(col_of_.size());
+            col_of_.push_back(j);
+        }
+    for (int i = 0; i < m; ++i)
+        if (row_alive[i]) row_of_.push_back(i);
+    const int rm = static_cast<int>(row_of_.size()), rn = static_cast<int>(col_of_.size());
+    stats_.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rm == 0 || rn == 0) return false;       // nothing left for the iteration: solve the original
+    if (rm == m && rn == n) return false;       // nothing removed
+    std::vector<int> rrp(rm + 1, 0), rci;
+    std::vector<double> rv, rAL(rm), rAU(rm), rl(rn), ru(rn), rc(rn);
+    rci.reserve(nnz);
+    rv.reserve(nnz);
+    for (int r = 0; r < rm; ++r) {
+        const int i = row_of_[r];
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            if (col_alive[ci[k]]) {  // explicit zeros of live columns are kept: same sparsity pattern
+                rci.push_back(new_col[ci[k]]);
+                rv.push_back(av[k]);
+            }
+        rrp[r + 1] = static_cast<int>(rci.size());
+        rAL[r] = AL[i];
+        rAU[r] = AU[i];
+    }
+    for (int q = 0; q < rn; ++q) {
+        rl[q] = l[col_of_[q]];
+        ru[q] = u[col_of_[q]];
+        rc[q] = model->c[col_of_[q]];
+    }
+    reduced_ = model_from_csr(rm, rn, static_cast<long>(rci.size()), rrp.data(), rci.data(), rv.data(), rAL.data(),
+                              rAU.data(), rl.data(), ru.data(), rc.data(), model->obj_constant + offset);
+    stats_.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return reduced_ != nullptr;
+}
+
+void Presolve::postsolve(const double *xr, const double *yr, const double *zr, double *x, double *y, double *z) const {
+    std::fill(x, x + n_, 0.0);
+    std::fill(y, y + m_, 0.0);
+    std::fill(z, z + n_, 0.0);
+    for (size_t q = 0; q < col_of_.size(); ++q) {
+        x[col_of_[q]] = xr[q];
+        z[col_of_[q]] = zr[q];
+    }
+    for (size_t r = 0; r < row_of_.size(); ++r) y[row_of_[r]] = yr[r];
+    // undo the reductions last-in first-out; rows not yet restored carry y = 0, and whenever a row
+    // dual is set the reduced cost of its column is updated, so z = c - A^T y holds at the end
+    for (size_t s = stack_.size(); s-- > 0;) {
+        const Record &r = stack_[s];
+        switch (r.kind) {
+            case FixedCol:
+            case EmptyCol: {
+                double red = org_->c[r.j];
+                for (int k = trp_[r.j]; k < trp_[r.j + 1]; ++k) red -= tv_[k] * y[tci_[k]];
+                x[r.j] = r.v;
+                z[r.j] = red;
+                break;
+            }
+            case SingletonRow: {
+                // the row became the bound l_new / u_new of column j: if that bound is the one the
+                // reduced cost leans on and the row (not the old bound) supplied it, the multiplier
+                // belongs to the row
+                const double zj = z[r.j];
+                double yi = 0.0;
+                if (zj > 0.0 && r.l_new > r.l_old) yi = zj / r.a;
+                else if (zj < 0.0 && r.u_new < r.u_old) yi = zj / r.a;
+                if (yi != 0.0) {
+                    y[r.i] = yi;
+                    z[r.j] = 0.0;
+                }
+                break;
+            }
+            case EmptyRow:
+            case RedundantRow:
+                y[r.i] = 0.0;
+                break;
+        }
+    }
+}
+
+OriginalKkt original_kkt(const LP_info_cpu *model, const double *x, const double *y, const double *z) {
+    // same definitions as the reference's check on the original model (src/pslp_integration.cpp:458-580):
+    // duals are first projected onto the sign their finite bounds allow
+    const int m = model->m, n = model->n;
+    const int *rp = model->A->rowPtr, *ci = model->A->colIndex;
+    const double *av = model->A->value;
+    auto project = [](double v, double lo, double hi) {
+        const bool lo_inf = std::isinf(lo) && lo < 0, hi_inf = std::isinf(hi) && hi > 0;
+        if (lo_inf && hi_inf) return 0.0;
+        if (hi_inf) return std::max(v, 0.0);
+        if (lo_inf) return std::min(v, 0.0);
+        return v;
+    };
+    std::vector<double> aty(n, 0.0);
+    double rhs2 = 0.0, row_viol2 = 0.0, d_lin = 0.0;
+    for (int i = 0; i < m; ++i) {
+        const double yp = project(y[i], model->AL[i], model->AU[i]);
+        double ax = 0.0;
+        for (int k = rp[i]; k < rp[i + 1]; ++k) {
+            ax += av[k] * x[ci[k]];
+            aty[ci[k]] += av[k] * yp;
+        }
+        const double lo = fin(model->AL[i]) ? std::abs(model->AL[i]) : 0.0, hi = fin(model->AU[i]) ? std::abs(model->AU[i]) : 0.0;
+        rhs2 += std::max(lo, hi) * std::max(lo, hi);
+        double viol = 0.0;
+        if (fin(model->AL[i]) && ax < model->AL[i]) viol = std::max(viol, model->AL[i] - ax);
+        if (fin(model->AU[i]) && ax > model->AU[i]) viol = std::max(viol, ax - model->AU[i]);
+        row_viol2 += viol * viol;
+        const double support = yp >= 0.0 ? (fin(model->AL[i]) ? model->AL[i] : 0.0) : (fin(model->AU[i]) ? model->AU[i] : 0.0);
+        d_lin += yp * support;
+    }
+    double c2 = 0.0, box_viol2 = 0.0, dual2 = 0.0, p_lin = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double zp = project(z[j], model->l[j], model->u[j]);
+        c2 += model->c[j] * model->c[j];
+        double viol = 0.0;
+        if (fin(model->l[j]) && x[j] < model->l[j]) viol = std::max(viol, model->l[j] - x[j]);
+        if (fin(model->u[j]) && x[j] > model->u[j]) viol = std::max(viol, x[j] - model->u[j]);
+        box_viol2 += viol * viol;
+        const double res = model->c[j] - aty[j] - zp;
+        dual2 += res * res;
+        p_lin += model->c[j] * x[j];
+        const double support = zp >= 0.0 ? (fin(model->l[j]) ? model->l[j] : 0.0) : (fin(model->u[j]) ? model->u[j] : 0.0);
+        d_lin += zp * support;
+    }
+    OriginalKkt k;
+    k.primal_feas = std::max(std::sqrt(row_viol2), std::sqrt(box_viol2)) / (1.0 + std::sqrt(rhs2));
+    k.dual_feas = std::sqrt(dual2) / (1.0 + std::sqrt(c2));
+    k.gap = std::abs(d_lin - p_lin) / (1.0 + std::abs(d_lin) + std::abs(p_lin));
+    k.primal_obj = p_lin + model->obj_constant;
+    k.dual_obj = d_lin + model->obj_constant;
+    return k;
+}
+
+}  // namespace hprlp

@@ -100,6 +100,9 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     view.val = val.p;
     view.blk = blk.p;
     view.nblk = static_cast<int>(b.size());
+    // nontemporal matrix loads only when the matrix cannot stay in the eight 4 MiB L2s anyway
+    view.nt = static_cast<size_t>(nnz) * 12 > (static_cast<size_t>(16) << 20);
+    if (const char *e = std::getenv("HPRLP_NT")) view.nt = std::atoi(e) != 0;
     // column-tiled copy: only for matrices large enough to fill the chip with 8192-row super-blocks
     // and with enough column locality (HPRLP_NO_TILED=1 disables; thresholds overridable for tests)
     const char *no = std::getenv("HPRLP_NO_TILED");

@@ -116,6 +116,14 @@ def lib():
     L.hprlp_solver_get_scalars.argtypes = [C.c_void_p, c_dbl_p]
     L.hprlp_solver_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
     L.hprlp_solver_time_iterations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]
+    L.hprlp_presolve_run.restype = C.c_void_p
+    L.hprlp_presolve_run.argtypes = [C.POINTER(CLPInfo)]
+    L.hprlp_presolve_reduced.restype = C.POINTER(CLPInfo)
+    L.hprlp_presolve_reduced.argtypes = [C.c_void_p]
+    L.hprlp_presolve_stats.argtypes = [C.c_void_p, c_int_p]
+    L.hprlp_presolve_postsolve.argtypes = [C.c_void_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]
+    L.hprlp_presolve_free.argtypes = [C.c_void_p]
+    L.hprlp_original_kkt.argtypes = [C.POINTER(CLPInfo), c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]
     _lib = L
     return L
 
@@ -239,6 +247,46 @@ class Model:
         if self._ptr:
             lib().free_model(self._ptr)
             self._ptr = None
+
+
+class Presolved:
+    """Host-side presolve of a model (include/hprlp_amd.h hprlp_presolve_*): `reduced` is a Model view owned by
+    this object; postsolve() maps a reduced primal-dual solution back.  Raises if the model is left unchanged."""
+
+    def __init__(self, model):
+        self.model = model
+        self.h = lib().hprlp_presolve_run(model._ptr)
+        if not self.h:
+            raise RuntimeError(last_error())
+        self.reduced = Model(lib().hprlp_presolve_reduced(self.h))
+        out = (C.c_int * 8)()
+        lib().hprlp_presolve_stats(self.h, out)
+        keys = ("m", "n", "fixed_cols", "empty_cols", "singleton_rows", "empty_rows", "redundant_rows", "passes")
+        self.stats = dict(zip(keys, [int(v) for v in out]))
+
+    def postsolve(self, xr, yr, zr):
+        xr, yr, zr = _as(xr, np.float64), _as(yr, np.float64), _as(zr, np.float64)
+        x, y, z = np.zeros(self.model.n), np.zeros(self.model.m), np.zeros(self.model.n)
+        P = lambda a: a.ctypes.data_as(c_dbl_p)
+        if lib().hprlp_presolve_postsolve(self.h, P(xr), P(yr), P(zr), P(x), P(y), P(z)) != 0:
+            raise RuntimeError("postsolve failed")
+        return x, y, z
+
+    def free(self):
+        if self.h:
+            self.reduced._ptr = None  # owned by the presolve object
+            lib().hprlp_presolve_free(self.h)
+            self.h = None
+
+
+def original_kkt(model, x, y, z):
+    """Relative primal / dual infeasibility and gap of (x, y, z) on the model as given."""
+    x, y, z = _as(x, np.float64), _as(y, np.float64), _as(z, np.float64)
+    out = np.zeros(5)
+    P = lambda a: a.ctypes.data_as(c_dbl_p)
+    if lib().hprlp_original_kkt(model._ptr, P(x), P(y), P(z), P(out)) != 0:
+        raise RuntimeError("original_kkt failed")
+    return dict(primal_feas=out[0], dual_feas=out[1], gap=out[2], primal_obj=out[3], dual_obj=out[4])
 
 
 def solve(A, AL, AU, l, u, c, param=None):

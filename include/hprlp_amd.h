@@ -107,6 +107,22 @@ int hprlp_dist_unique_id(void *out, int bytes);
 hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
                                        const void *unique_id, int id_bytes);
 
+/* ---- presolve / postsolve as separate host-side steps (what solve() does around the iteration when
+ * use_presolve is set; replaces the reference's forked PSLP worker, src/pslp_integration.cpp:628-787).
+ * hprlp_presolve_run returns NULL when the model is left unchanged or looks infeasible/unbounded. */
+typedef struct hprlp_presolve hprlp_presolve;
+hprlp_presolve *hprlp_presolve_run(const LP_info_cpu *model);
+const LP_info_cpu *hprlp_presolve_reduced(const hprlp_presolve *p); /* owned by p */
+/* out = {reduced m, reduced n, fixed cols, empty cols, singleton rows, empty rows, redundant rows, passes} */
+int hprlp_presolve_stats(const hprlp_presolve *p, int out[8]);
+/* (xr, yr, zr) of the reduced model -> (x, y, z) in the original dimensions */
+int hprlp_presolve_postsolve(const hprlp_presolve *p, const double *xr, const double *yr, const double *zr, double *x,
+                             double *y, double *z);
+void hprlp_presolve_free(hprlp_presolve *p);
+/* out = {primal infeasibility, dual infeasibility, gap (all relative), primal objective, dual objective} on the
+ * model as given (reference compute_original_kkt_metrics, src/pslp_integration.cpp:499-580) */
+int hprlp_original_kkt(const LP_info_cpu *model, const double *x, const double *y, const double *z, double out[5]);
+
 #ifdef __cplusplus
 }
 #endif

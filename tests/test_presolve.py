@@ -1,0 +1,216 @@
+"""Presolve / postsolve around solve() (hpr-lp-c_amd/csrc/presolve.cpp).
+
+CPU tests: the reduced model and the postsolve map are checked with an exact LP solver (HiGHS via scipy) --
+same optimum as the original, and the postsolved primal-dual triple satisfies the KKT conditions of the
+ORIGINAL model.  The presolver the reference vendors (PSLP v0.0.8, built unchanged into oracle/_ref by
+`make -C oracle refpslp`) is run beside ours on the same LPs as the reference point.
+GPU test: solve() with use_presolve on and off gives the same optimum in the original dimensions."""
+import numpy as np
+import pytest
+from scipy import sparse
+from scipy.optimize import linprog
+
+from conftest import hprlp, lpgen
+from oracle import pslp_ref
+
+INF = np.inf
+
+
+def highs(m, n, rp, ci, v, AL, AU, l, u, c):
+    """Exact optimum and duals in our convention (z = c - A^T y, y_i > 0 <=> row at AL)."""
+    A = sparse.csr_matrix((v, ci, rp), shape=(m, n))
+    eq = np.isfinite(AL) & (AL == AU)
+    up = np.isfinite(AU) & ~eq
+    lo = np.isfinite(AL) & ~eq
+    A_ub = sparse.vstack([A[up], -A[lo]]) if (up.any() or lo.any()) else None
+    b_ub = np.concatenate([AU[up], -AL[lo]]) if A_ub is not None else None
+    A_eq = A[eq] if eq.any() else None
+    b_eq = AL[eq] if eq.any() else None
+    bounds = [(None if not np.isfinite(a) else a, None if not np.isfinite(b) else b) for a, b in zip(l, u)]
+    r = linprog(c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=bounds, method="highs")
+    assert r.status == 0, r.message
+    y = np.zeros(m)
+    if A_ub is not None:
+        mu = r.ineqlin.marginals
+        nu_ = int(up.sum())
+        y[up] += mu[:nu_]
+        y[lo] += -mu[nu_:]
+    if A_eq is not None:
+        y[eq] = r.eqlin.marginals
+    z = r.lower.marginals + r.upper.marginals
+    return r.fun, r.x, y, z
+
+
+def structured_lp(seed, m0=60, n0=90):
+    """A planted LP decorated with everything the presolver removes: fixed columns, singleton rows (some binding),
+    empty rows, redundant rows, empty columns."""
+    rng = np.random.default_rng(seed)
+    base = lpgen.planted_lp(m0, n0, 6 * m0, seed)
+    A = sparse.csr_matrix((base["values"], base["colind"], base["rowptr"]), shape=(m0, n0)).tolil()
+    AL, AU = base["AL"].copy(), base["AU"].copy()
+    l, u, c = base["l"].copy(), base["u"].copy(), base["c"].copy()
+    xs = base["x_star"]
+    # fixed columns at their planted value
+    for j in rng.choice(n0, size=6, replace=False):
+        l[j] = u[j] = xs[j]
+    rows = [A]
+    extra_AL, extra_AU = [], []
+
+    def add_row(cols, vals, lo, hi):
+        r = sparse.lil_matrix((1, n0))
+        for cc, vv in zip(cols, vals):
+            r[0, cc] = vv
+        rows.append(r)
+        extra_AL.append(lo)
+        extra_AU.append(hi)
+
+    # singleton rows: loose ones, ones that are active at the planted optimum, and equalities
+    for j in rng.choice(n0, size=8, replace=False):
+        a = rng.choice([-2.0, 0.5, 3.0])
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            add_row([j], [a], -INF if a > 0 else a * (xs[j] + 5.0), a * (xs[j] + 5.0) if a > 0 else INF)  # x_j <= xs+5
+        elif kind == 1:
+            t = xs[j]  # x_j >= planted value: active at the optimum, which stays optimal
+            add_row([j], [a], a * t if a > 0 else -INF, INF if a > 0 else a * t)
+        else:
+            add_row([j], [a], a * xs[j], a * xs[j])
+    add_row([], [], -1.0, 2.0)  # empty row, consistent
+    add_row([], [], -INF, 0.0)
+    # redundant rows: activity range inside the row bounds (boxed columns only)
+    boxed = np.where(np.isfinite(l) & np.isfinite(u))[0]
+    if len(boxed) >= 3:
+        cols = boxed[:3]
+        vals = np.array([1.0, -2.0, 0.5])
+        lo_act = sum(min(a * l[j], a * u[j]) for a, j in zip(vals, cols))
+        up_act = sum(max(a * l[j], a * u[j]) for a, j in zip(vals, cols))
+        add_row(cols, vals, lo_act - 1.0, up_act + 1.0)
+        add_row(cols, vals, -INF, up_act)
+    A2 = sparse.vstack(rows).tocsr()
+    # empty columns appended: positive cost at a finite lower bound, negative cost at a finite upper bound, zero cost
+    extra_cols = 3
+    A2 = sparse.hstack([A2, sparse.csr_matrix((A2.shape[0], extra_cols))]).tocsr()
+    l = np.concatenate([l, [1.0, -INF, -INF]])
+    u = np.concatenate([u, [INF, 4.0, INF]])
+    c = np.concatenate([c, [2.0, -1.5, 0.0]])
+    A2.sort_indices()
+    AL = np.concatenate([AL, extra_AL])
+    AU = np.concatenate([AU, extra_AU])
+    m, n = A2.shape
+    return dict(m=m, n=n, rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), values=A2.data.copy(),
+                AL=AL, AU=AU, l=l, u=u, c=c)
+
+
+def make_model(lp):
+    return hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"],
+                                lp["u"], lp["c"])
+
+
+def reduced_arrays(pre):
+    red = pre.reduced
+    rp, ci, v = red.csr()
+    vec = red.vectors()
+    return red.m, red.n, rp, ci, v, vec["AL"], vec["AU"], vec["l"], vec["u"], vec["c"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_reduced_model_has_same_optimum_and_postsolve_satisfies_original_kkt(seed):
+    lp = structured_lp(seed)
+    model = make_model(lp)
+    f0, x0, y0, z0 = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    pre = hprlp.Presolved(model)
+    st = pre.stats
+    assert st["m"] < lp["m"] and st["n"] < lp["n"]
+    assert st["fixed_cols"] >= 6 and st["singleton_rows"] >= 8 and st["empty_rows"] >= 2 and st["empty_cols"] >= 3
+    # (the two redundant rows turn into singleton rows when two of their three columns happen to be fixed)
+    assert st["redundant_rows"] + st["singleton_rows"] >= 10 and lp["m"] - st["m"] >= 12
+    rm, rn, rp, ci, v, AL, AU, l, u, c = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp, ci, v, AL, AU, l, u, c)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-8 * (1 + abs(f0))
+    x, y, z = pre.postsolve(xr, yr, zr)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert k["primal_feas"] <= 1e-9 and k["dual_feas"] <= 1e-9 and k["gap"] <= 1e-9, k
+    assert abs(k["primal_obj"] - f0) <= 1e-8 * (1 + abs(f0))
+    # the KKT metric itself: the exact solver's own primal-dual pair passes it on the original model
+    k0 = hprlp.original_kkt(model, x0, y0, z0)
+    assert max(k0["primal_feas"], k0["dual_feas"], k0["gap"]) <= 1e-9
+    pre.free(); model.free()
+
+
+def test_binding_singleton_row_gets_the_multiplier():
+    """min 2*x0 + x1  s.t.  x0 + x1 >= 2 (row 0),  2*x0 >= 3 (row 1, singleton, binding),  x >= 0.
+    Optimum x = (1.5, 0.5), y = (1, 0.5), z = 0: the reduced cost that column 0 shows at its presolved bound
+    1.5 belongs to the singleton row."""
+    rp = np.array([0, 2, 3], np.int32); ci = np.array([0, 1, 0], np.int32); v = np.array([1.0, 1.0, 2.0])
+    model = hprlp.Model.from_csr(2, 2, rp, ci, v, [2.0, 3.0], [INF, INF], [0.0, 0.0], [INF, INF], [2.0, 1.0])
+    pre = hprlp.Presolved(model)
+    assert pre.stats["singleton_rows"] == 1 and pre.reduced.m == 1
+    assert pre.reduced.vectors()["l"][0] == 1.5
+    rm, rn, rp2, ci2, v2, AL, AU, l, u, c = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp2, ci2, v2, AL, AU, l, u, c)
+    np.testing.assert_allclose(zr, [1.0, 0.0], atol=1e-12)
+    x, y, z = pre.postsolve(xr, yr, zr)
+    np.testing.assert_allclose(x, [1.5, 0.5], atol=1e-12)
+    np.testing.assert_allclose(y, [1.0, 0.5], atol=1e-12)
+    np.testing.assert_allclose(z, [0.0, 0.0], atol=1e-12)
+    pre.free(); model.free()
+
+
+def test_presolve_declines(model_mps_arrays):
+    """Nothing to remove (the reference's model.mps) and infeasible input: the caller keeps the original model."""
+    a = model_mps_arrays
+    model = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"])
+    with pytest.raises(RuntimeError):
+        hprlp.Presolved(model)
+    model.free()
+    rp = np.array([0, 1, 2], np.int32); ci = np.array([0, 0], np.int32); v = np.array([1.0, 1.0])
+    bad = hprlp.Model.from_csr(2, 1, rp, ci, v, [2.0, -INF], [INF, 1.0], [0.0], [INF], [1.0])  # x >= 2 and x <= 1
+    with pytest.raises(RuntimeError):
+        hprlp.Presolved(bad)
+    bad.free()
+
+
+@pytest.mark.skipif(not pslp_ref.available(), reason="oracle/_ref/libpslp_ref.so not built (make -C oracle refpslp)")
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_against_the_reference_presolver(seed):
+    """PSLP (the reference's presolver) and ours on the same LP: both reduced models have the original optimum and
+    both postsolves give a KKT point of the original model.  PSLP removes at least as much as we do."""
+    lp = structured_lp(seed)
+    model = make_model(lp)
+    f0, *_ = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    ref = pslp_ref.RefPresolve(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    pre = hprlp.Presolved(model)
+    assert ref.status == 1  # REDUCED
+    assert ref.rm <= pre.reduced.m and ref.rn <= pre.reduced.n
+    if ref.rm > 0 and ref.rn > 0:
+        fr, xr, yr, zr = highs(ref.rm, ref.rn, ref.Ap, ref.Ai, ref.Ax, ref.lhs, ref.rhs, ref.lbs, ref.ubs, ref.c)
+    else:
+        xr, yr, zr = np.zeros(ref.rn), np.zeros(ref.rm), np.zeros(ref.rn)
+    xp, yp, zp = ref.postsolve(xr, yr, zr)
+    kp = hprlp.original_kkt(model, xp, yp, zp)
+    # PSLP's obj_offset counts columns given with l == u twice (v0.0.8), so the comparison goes through c.x
+    assert abs(kp["primal_obj"] - f0) <= 1e-7 * (1 + abs(f0))
+    assert kp["primal_feas"] <= 1e-8
+    rm, rn, rp, ci, v, AL, AU, l, u, c = reduced_arrays(pre)
+    fo, xo, yo, zo = highs(rm, rn, rp, ci, v, AL, AU, l, u, c)
+    x, y, z = pre.postsolve(xo, yo, zo)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert abs(k["primal_obj"] - kp["primal_obj"]) <= 1e-7 * (1 + abs(f0))
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-9
+    ref.close(); pre.free(); model.free()
+
+
+@pytest.mark.gpu
+def test_solve_with_presolve_matches_solve_without(gpu):
+    lp = structured_lp(11, m0=300, n0=500)
+    model = make_model(lp)
+    f0, *_ = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    on = model.solve(hprlp.Parameters(stop_tol=1e-8, use_presolve=True))
+    off = model.solve(hprlp.Parameters(stop_tol=1e-8, use_presolve=False))
+    assert on.status == "OPTIMAL" and off.status == "OPTIMAL"
+    assert len(on.x) == lp["n"] and len(on.y) == lp["m"] and len(on.z) == lp["n"]
+    assert abs(on.primal_obj - f0) <= 1e-6 * (1 + abs(f0))
+    assert abs(off.primal_obj - f0) <= 1e-6 * (1 + abs(f0))
+    k = hprlp.original_kkt(model, on.x, on.y, on.z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-6, k
+    model.free()

@@ -8,13 +8,13 @@ def _load(name, rel):
 H = _load("hprlp_amd", "hpr-lp-c_amd/hprlp.py"); G = _load("hprlp_lpgen", "hpr-lp-c_amd/lpgen.py")
 os.dup2(2, 1)
 lps = {"c2": G.c2_25fv47_like(), "c3": G.c3_pds20_like()}
-for rows, nnz in [(64, 512), (32, 512), (16, 512), (8, 512), (64, 256), (16, 256)]:
-    os.environ["HPRLP_STREAM_ROWS"] = str(rows); os.environ["HPRLP_STREAM_NNZ"] = str(nnz)
+for rows, nnz, nt in [(64, 512, 1), (64, 512, 0), (64, 256, 1), (64, 256, 0), (32, 256, 0)]:
+    os.environ["HPRLP_STREAM_ROWS"] = str(rows); os.environ["HPRLP_STREAM_NNZ"] = str(nnz); os.environ["HPRLP_NT"] = str(nt)
     for key, lp in lps.items():
         model = H.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
         s = H.Solver(model, H.Parameters(use_presolve=False)); s.scale(); lam, _ = s.power_iteration(); s.init(-1.0, lam * 1.01)
         info = s.info()
         g = s.time_iterations(200, 2000, 0); e = s.time_iterations(50, 500, 1)
-        print(f"rows<={rows:3d} nnz<={nnz:3d} {key}: blocks A/AT {info['blocks_A']}/{info['blocks_AT']}  graph {g['total_ms']/2000*1e3:6.2f} us/iter   "
+        print(f"rows<={rows:3d} nnz<={nnz:3d} nt={nt} {key}: blocks A/AT {info['blocks_A']}/{info['blocks_AT']}  graph {g['total_ms']/2000*1e3:6.2f} us/iter   "
               f"eager x {e['xhalf_ms']/500*1e3:6.2f} y {e['yhalf_ms']/500*1e3:6.2f} us", file=sys.stderr)
         s.close(); model.free()
