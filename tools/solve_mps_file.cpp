@@ -24,7 +24,7 @@ static void usage(const char *prog) {
               << "      --ruiz <true/false>    Ruiz scaling (default: true)\n"
               << "      --pock <true/false>    Pock-Chambolle scaling (default: true)\n"
               << "      --bc <true/false>      bounds/cost scaling (default: true)\n"
-              << "      --presolve <true/false>  accepted; this build solves the model as given\n"
+              << "      --presolve <true/false>  enable/disable the host presolve (default: true)\n"
               << "  -h, --help                 show this help and exit\n";
 }
 
