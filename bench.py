@@ -41,6 +41,7 @@ WORKLOADS = {
     # name: (m, n, per_row, band)
     "c5": (10_000_000, 10_000_000, 20, 100_000),
     "c5_eighth": (1_250_000, 10_000_000, 20, 100_000),
+    "c5_quarter": (2_500_000, 10_000_000, 20, 100_000),
     "c5_small": (1_000_000, 1_000_000, 20, 10_000),
     "c5_tiny": (100_000, 100_000, 20, 1_000),
 }
@@ -226,17 +227,11 @@ def main():
             raise RuntimeError(H.last_error())
         tu = torch.from_numpy(uid)
         dist.broadcast(tu, src=0)
-        H.lib().hprlp_solver_create_dist.restype = C.c_void_p
-        H.lib().hprlp_solver_create_dist.argtypes = [C.POINTER(H.CLPInfo), C.POINTER(H.CParameters), C.c_int, C.c_int,
-                                                     C.c_void_p, C.c_int]
-        s = H.Solver.__new__(H.Solver)
-        s.model = model
-        cp = prm.to_c()
-        s.h = H.lib().hprlp_solver_create_dist(model._ptr, C.byref(cp), rank, world, uid.ctypes.data_as(C.c_void_p), 128)
-        if not s.h:
-            raise RuntimeError("hprlp_solver_create_dist failed: " + H.last_error())
+        s = H.Solver.create_dist(model, prm, rank, world, uid)
+        dinfo = s.dist_info()
     else:
         s = H.Solver(model, prm)
+        dinfo = None
     model.free()
     s.scale()
     lam, pw_it = s.power_iteration()
@@ -288,8 +283,13 @@ def main():
             "n_gpus": P, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 5: banded-random CSR LP {m}x{n}, nnz={nnz} "
-                                   f"({'row-partitioned over %d GPUs, 2 RCCL all-gathers per iteration' % P if P > 1 else 'one GPU'})",
+                                   f"({'row-partitioned over %d GPUs, 2 RCCL exchanges per iteration' % P if P > 1 else 'one GPU'})",
                        "m": m, "n": n, "nnz": nnz, "parallelism": f"rowpart{P}",
+                       "exchange": None if dinfo is None else {
+                           "kind_m": "neighbour send/recv" if dinfo["m_sparse"] else "all-gather",
+                           "kind_n": "neighbour send/recv" if dinfo["n_sparse"] else "all-gather",
+                           "rank0_entries_received_per_iteration": (dinfo["m_received"] if dinfo["m_sparse"] else m - m // P)
+                                                                   + (dinfo["n_received"] if dinfo["n_sparse"] else n - n // P)},
                        "bytes_per_iteration_algorithmic": bytes_per_iteration(m, n, nnz)},
             "roofline": {"bound": "hbm", "kernel": ("k_tiled_fused" if tiled & 2 else "k_spmv_fused") + "<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -216,8 +216,28 @@ extern "C" hprlp_solver *hprlp_solver_create(const LP_info_cpu *model, const HPR
     }
 }
 
-extern "C" hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank,
-                                                  int size, const void *unique_id, int id_bytes) {
+struct hprlp_local_group {
+    LocalGroup *g = nullptr;
+};
+extern "C" hprlp_local_group *hprlp_local_group_create(int size) {
+    try {
+        auto *h = new hprlp_local_group();
+        h->g = make_local_group(size);
+        return h;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return nullptr;
+    }
+}
+extern "C" void hprlp_local_group_destroy(hprlp_local_group *h) {
+    if (!h) return;
+    free_local_group(h->g);
+    delete h;
+}
+
+// rank `rank` of `size`: RCCL communicator from unique_id, or (group != NULL) the in-process group
+static hprlp_solver *create_sharded(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
+                                    const void *unique_id, int id_bytes, hprlp_local_group *group) {
     if (!model) {
         set_last_error("null model");
         return nullptr;
@@ -231,8 +251,13 @@ extern "C" hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, cons
         if (hprlp_extract_shard(model, rank, size, &sh) != 0) throw std::runtime_error(last_error_cstr());
         h = new hprlp_solver();
         h->s.verbose = false;
-        // a unique id given with size 1 builds a one-rank RCCL communicator (exercises the collective path)
-        if (size > 1 || (unique_id && id_bytes >= 128)) h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
+        HIP_CHECK(hipSetDevice(p->device_number));
+        if (group) {
+            h->comm = make_local_comm(group->g, rank);
+        } else if (size > 1 || (unique_id && id_bytes >= 128)) {
+            // a unique id given with size 1 builds a one-rank RCCL communicator (exercises the collective path)
+            h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
+        }
         h->s.setup_shard(sh.m, sh.n, sh.row_off, sh.m_loc, sh.col_off, sh.n_loc, sh.A_rowptr, sh.A_col, sh.A_val,
                          sh.AT_rowptr, sh.AT_col, sh.AT_val, sh.AL, sh.AU, sh.l, sh.u, sh.c, sh.obj_constant, p, h->comm);
         hprlp_free_shard(&sh);
@@ -247,6 +272,30 @@ extern "C" hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, cons
         }
         return nullptr;
     }
+}
+
+extern "C" hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank,
+                                                  int size, const void *unique_id, int id_bytes) {
+    return create_sharded(model, param, rank, size, unique_id, id_bytes, nullptr);
+}
+
+extern "C" hprlp_solver *hprlp_solver_create_local(const LP_info_cpu *model, const HPRLP_parameters *param, int rank,
+                                                   int size, hprlp_local_group *group) {
+    if (!group) {
+        set_last_error("null local group");
+        return nullptr;
+    }
+    return create_sharded(model, param, rank, size, nullptr, 0, group);
+}
+
+// out = {halo_m sparse?, entries sent, entries received, halo_n sparse?, sent, received, requests m, requests n}
+extern "C" int hprlp_solver_dist_info(hprlp_solver *h, long out[8]) {
+    if (!h || !out) return -1;
+    const Solver &s = h->s;
+    out[0] = s.halo_m.sparse; out[1] = s.halo_m.nsend; out[2] = s.halo_m.nrecv;
+    out[3] = s.halo_n.sparse; out[4] = s.halo_n.nsend; out[5] = s.halo_n.nrecv;
+    out[6] = s.halo_m.total_requests; out[7] = s.halo_n.total_requests;
+    return 0;
 }
 
 extern "C" void hprlp_solver_destroy(hprlp_solver *h) {

@@ -13,8 +13,12 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <iostream>
+#include <mutex>
+#include <vector>
 
 #include "hprlp_amd.h"
 #include "solver.h"
@@ -30,6 +34,10 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -52,6 +60,10 @@ RcclApi &rccl() {
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     return api;
 }
@@ -71,9 +83,126 @@ struct RcclComm : Comm {
     void allreduce_sum(double *buf, int count, hipStream_t s) override {
         check(rccl().AllReduce(buf, buf, static_cast<size_t>(count), ncclDouble, ncclSum, comm, s), "allreduce");
     }
+    void exchange(const P2P *ops, int nops, hipStream_t s) override {
+        // one group: every send/recv of the list is posted before any has to complete (no ordering deadlock)
+        check(rccl().GroupStart(), "group start");
+        for (int i = 0; i < nops; ++i) {
+            const P2P &o = ops[i];
+            if (o.send_bytes) check(rccl().Send(o.send, o.send_bytes, ncclInt8, o.peer, comm, s), "send");
+            if (o.recv_bytes) check(rccl().Recv(o.recv, o.recv_bytes, ncclInt8, o.peer, comm, s), "recv");
+        }
+        check(rccl().GroupEnd(), "group end");
+    }
 };
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// in-process group (see dist.h): host barriers + device-to-device copies on the caller's stream
+// ------------------------------------------------------------------------------------------------
+struct LocalGroup {
+    int size = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    long generation = 0;
+    bool broken = false;
+    std::vector<double *> bufs;
+    std::vector<const P2P *> ops;
+    std::vector<int> nops;
+    std::vector<std::vector<double>> host;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) throw std::runtime_error("local group: another rank failed");
+        const long gen = generation;
+        if (++waiting == size) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+            return;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; })) {
+            broken = true;
+            cv.notify_all();
+            throw std::runtime_error("local group: barrier timed out (a rank is missing)");
+        }
+        if (broken) throw std::runtime_error("local group: another rank failed");
+    }
+};
+
+namespace {
+struct LocalComm : Comm {
+    LocalGroup *g = nullptr;
+    void allgather_inplace(double *buf, size_t chunk, hipStream_t s) override {
+        HIP_CHECK(hipStreamSynchronize(s));
+        g->bufs[rank] = buf;
+        g->barrier();
+        for (int p = 0; p < size; ++p)
+            if (p != rank)
+                HIP_CHECK(hipMemcpyAsync(buf + p * chunk, g->bufs[p] + p * chunk, chunk * sizeof(double),
+                                         hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        g->barrier();
+    }
+    void allreduce_sum(double *buf, int count, hipStream_t s) override {
+        std::vector<double> &mine = g->host[rank];
+        mine.resize(count);
+        HIP_CHECK(hipMemcpyAsync(mine.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        g->barrier();
+        std::vector<double> sum(count, 0.0);
+        for (int p = 0; p < size; ++p)  // rank order: every rank gets the same bits
+            for (int i = 0; i < count; ++i) sum[i] += g->host[p][i];
+        g->barrier();
+        HIP_CHECK(hipMemcpyAsync(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    void exchange(const P2P *ops, int nops, hipStream_t s) override {
+        HIP_CHECK(hipStreamSynchronize(s));
+        g->ops[rank] = ops;
+        g->nops[rank] = nops;
+        g->barrier();
+        for (int i = 0; i < nops; ++i) {
+            const P2P &o = ops[i];
+            if (!o.recv_bytes) continue;
+            const P2P *match = nullptr;
+            for (int k = 0; k < g->nops[o.peer]; ++k)
+                if (g->ops[o.peer][k].peer == rank && g->ops[o.peer][k].send_bytes) match = &g->ops[o.peer][k];
+            if (!match || match->send_bytes != o.recv_bytes) {
+                {
+                    std::lock_guard<std::mutex> lk(g->mu);
+                    g->broken = true;
+                }
+                g->cv.notify_all();
+                throw std::runtime_error("local group: unmatched receive");
+            }
+            HIP_CHECK(hipMemcpyAsync(o.recv, match->send, o.recv_bytes, hipMemcpyDeviceToDevice, s));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        g->barrier();
+    }
+};
+}  // namespace
+
+LocalGroup *make_local_group(int size) {
+    if (size < 1) throw std::runtime_error("local group size must be positive");
+    auto *g = new LocalGroup();
+    g->size = size;
+    g->bufs.assign(size, nullptr);
+    g->ops.assign(size, nullptr);
+    g->nops.assign(size, 0);
+    g->host.resize(size);
+    return g;
+}
+void free_local_group(LocalGroup *g) { delete g; }
+Comm *make_local_comm(LocalGroup *g, int rank) {
+    if (!g || rank < 0 || rank >= g->size) throw std::runtime_error("bad local group / rank");
+    auto *c = new LocalComm();
+    c->g = g;
+    c->rank = rank;
+    c->size = g->size;
+    return c;
+}
 
 void rccl_get_unique_id(void *out, size_t bytes) {
     if (bytes < sizeof(ncclUniqueId)) throw std::runtime_error("unique-id buffer too small");

@@ -156,6 +156,10 @@ void launch_unscale(int n, int m, const double *x_bar, const double *y_bar, cons
                     const double *col_norm, const double *row_norm, double b_scale, double c_scale, double *xo,
                     double *yo, double *zo, hipStream_t s);
 
+// multi-GPU neighbour exchange: dst[k] = src[idx[k]] before the sends, dst[idx[k]] = src[k] after the receives
+void launch_pack(const double *src, const int *idx, double *dst, int n, hipStream_t s);
+void launch_scatter(double *dst, const int *idx, const double *src, int n, hipStream_t s);
+
 constexpr int kReduceBlocks = 512;  // grid of the plain vector reductions
 
 }  // namespace hprlp

@@ -923,4 +923,23 @@ void launch_unscale(int n, int m, const double *x_bar, const double *y_bar, cons
                        col_norm, row_norm, b_scale, c_scale, xo, yo, zo);
 }
 
+// ------------------------------------------------------------------------------------------------
+// multi-GPU neighbour exchange (HaloPlan, solver.h): the index lists are sorted, so both kernels walk
+// the big vector monotonically
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_pack(const double *__restrict__ src, const int *__restrict__ idx,
+                                                  double *__restrict__ dst, int n) {
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) dst[i] = src[idx[i]];
+}
+__global__ void __launch_bounds__(kThreads) k_scatter(double *__restrict__ dst, const int *__restrict__ idx,
+                                                     const double *__restrict__ src, int n) {
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) dst[idx[i]] = src[i];
+}
+void launch_pack(const double *src, const int *idx, double *dst, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_pack, dim3(vec_grid(n)), dim3(kThreads), 0, s, src, idx, dst, n);
+}
+void launch_scatter(double *dst, const int *idx, const double *src, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_scatter, dim3(vec_grid(n)), dim3(kThreads), 0, s, dst, idx, src, n);
+}
+
 }  // namespace hprlp

@@ -103,13 +103,15 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     // nontemporal matrix loads only when the matrix cannot stay in the eight 4 MiB L2s anyway
     view.nt = static_cast<size_t>(nnz) * 12 > (static_cast<size_t>(16) << 20);
     if (const char *e = std::getenv("HPRLP_NT")) view.nt = std::atoi(e) != 0;
-    // column-tiled copy: only for matrices large enough to fill the chip with 8192-row super-blocks
+    // column-tiled copy: only for matrices with at least one 8192-row super-block per CU
     // and with enough column locality (HPRLP_NO_TILED=1 disables; thresholds overridable for tests)
     const char *no = std::getenv("HPRLP_NO_TILED");
     if (!(no && no[0] == '1')) {
         const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
         const char *md = std::getenv("HPRLP_TILED_MIN_DENSE");
-        const int min_rows = mr ? std::atoi(mr) : 512 * kTileRows;
+        // measured on shard-shaped matrices of the banded benchmark: 305 super-blocks 0.31 ms tiled vs
+        // 0.38 ms stream, 153 super-blocks 0.21 ms both -> one super-block per CU is the break-even
+        const int min_rows = mr ? std::atoi(mr) : 256 * kTileRows;
         const double min_dense = md ? std::atof(md) : 0.5;
         TiledHost th;
         if (build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense)) {
@@ -213,6 +215,11 @@ void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int c
     u.alloc(n_loc); u.upload(u_, n_loc);
     c.alloc(n_loc); c.upload(c_, n_loc);
     alloc_work();
+    if (comm) {
+        // length-m vectors are read through the columns of the A^T shard, length-n ones through those of A
+        halo_m.build(comm, ATci, ATrp[n_loc], m, chunk_m, stream);
+        halo_n.build(comm, Aci, Arp[m_loc], n, chunk_n, stream);
+    }
     HIP_CHECK(hipDeviceSynchronize());
     setup_time = time_since(t0);
 }
@@ -220,10 +227,85 @@ void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int c
 // ------------------------------------------------------------------------------------------------
 // collectives (no-ops on one GPU)
 // ------------------------------------------------------------------------------------------------
+void HaloPlan::build(Comm *comm, const int *cols, long nnz, int total, int chunk, hipStream_t s) {
+    const int P = comm->size, r = comm->rank;
+    sparse = false;
+    if (P <= 1) return;
+    // entries of the gathered vector that this shard's column indices name, by owning rank
+    std::vector<char> need(static_cast<size_t>(total), 0);
+    for (long k = 0; k < nnz; ++k) need[cols[k]] = 1;
+    std::vector<int> want;            // concatenated over peers, ascending inside a peer
+    std::vector<long> want_off(P + 1, 0);
+    for (int p = 0; p < P; ++p) {
+        if (p != r) {
+            const int lo = std::min(total, p * chunk), hi = std::min(total, (p + 1) * chunk);
+            for (int j = lo; j < hi; ++j)
+                if (need[j]) want.push_back(j);
+        }
+        want_off[p + 1] = static_cast<long>(want.size());
+    }
+    // request counts of everybody: cnt[a*P + b] = entries rank a wants from rank b
+    std::vector<double> cnt(static_cast<size_t>(P) * P, 0.0);
+    for (int p = 0; p < P; ++p) cnt[static_cast<size_t>(r) * P + p] = static_cast<double>(want_off[p + 1] - want_off[p]);
+    DBuf<double> dcnt(static_cast<size_t>(P) * P);
+    dcnt.upload(cnt.data(), cnt.size());
+    comm->allgather_inplace(dcnt.p, static_cast<size_t>(P), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    dcnt.download(cnt.data(), cnt.size());
+    total_requests = 0;
+    for (double v : cnt) total_requests += static_cast<long>(v);
+    const double dense = static_cast<double>(P - 1) * static_cast<double>(total);
+    sparse = static_cast<double>(total_requests) <= 0.5 * dense;
+    if (const char *e = std::getenv("HPRLP_DIST_EXCHANGE")) {  // "sparse" / "allgather": same value on every rank
+        if (e[0] == 's') sparse = true;
+        if (e[0] == 'a') sparse = false;
+    }
+    if (!sparse) return;
+
+    nrecv = static_cast<int>(want.size());
+    recv_idx.alloc(want.size());
+    recv_idx.upload(want.data(), want.size());
+    std::vector<long> send_off(P + 1, 0);
+    for (int p = 0; p < P; ++p) send_off[p + 1] = send_off[p] + static_cast<long>(cnt[static_cast<size_t>(p) * P + r]);
+    nsend = static_cast<int>(send_off[P]);
+    send_idx.alloc(static_cast<size_t>(nsend));
+    // tell every peer which of its entries we read (our request list becomes its send list)
+    std::vector<P2P> idx_ops;
+    for (int p = 0; p < P; ++p) {
+        if (p == r) continue;
+        const size_t nw = static_cast<size_t>(want_off[p + 1] - want_off[p]), ns = static_cast<size_t>(send_off[p + 1] - send_off[p]);
+        if (nw || ns) idx_ops.push_back(P2P{p, recv_idx.p + want_off[p], nw * sizeof(int), send_idx.p + send_off[p], ns * sizeof(int)});
+    }
+    comm->exchange(idx_ops.data(), static_cast<int>(idx_ops.size()), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    {   // the kernels index without bounds checks: every requested entry must lie in our own slice
+        std::vector<int> chk(static_cast<size_t>(nsend));
+        send_idx.download(chk.data(), chk.size());
+        const int lo = std::min(total, r * chunk), hi = std::min(total, (r + 1) * chunk);
+        for (int v : chk)
+            if (v < lo || v >= hi) throw std::runtime_error("halo plan: a peer requested an entry this rank does not own");
+    }
+    sendbuf.alloc_zero(static_cast<size_t>(nsend));
+    recvbuf.alloc_zero(static_cast<size_t>(nrecv));
+    ops.clear();
+    for (int p = 0; p < P; ++p) {
+        if (p == r) continue;
+        const size_t nw = static_cast<size_t>(want_off[p + 1] - want_off[p]), ns = static_cast<size_t>(send_off[p + 1] - send_off[p]);
+        if (nw || ns) ops.push_back(P2P{p, sendbuf.p + send_off[p], ns * sizeof(double), recvbuf.p + want_off[p], nw * sizeof(double)});
+    }
+}
+
 void Solver::gather(double *gbuf, bool is_m) {
     if (!comm) return;  // (a one-rank communicator still runs the collective: used to test the RCCL path)
-    const size_t chunk = static_cast<size_t>(is_m ? m_pad : n_pad) / comm->size;
-    comm->allgather_inplace(gbuf, chunk, stream);
+    HaloPlan &h = is_m ? halo_m : halo_n;
+    if (!h.sparse) {
+        const size_t chunk = static_cast<size_t>(is_m ? m_pad : n_pad) / comm->size;
+        comm->allgather_inplace(gbuf, chunk, stream);
+        return;
+    }
+    launch_pack(gbuf, h.send_idx.p, h.sendbuf.p, h.nsend, stream);
+    comm->exchange(h.ops.data(), static_cast<int>(h.ops.size()), stream);
+    launch_scatter(gbuf, h.recv_idx.p, h.recvbuf.p, h.nrecv, stream);
 }
 
 void Solver::fetch_scalars() {

@@ -7,11 +7,10 @@
 #include <memory>
 
 #include "common.h"
+#include "dist.h"
 #include "kernels.h"
 
 namespace hprlp {
-
-struct Comm;  // collective layer (dist.cpp); nullptr on one GPU
 
 struct Residuals {  // reference HPRLP_residuals, include/structs.h:255-263
     double err_Rp = 0, err_Rd = 0, primal_obj = 0, dual_obj = 0, rel_gap = 0;
@@ -48,6 +47,22 @@ struct DeviceMatrix {
 
 std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows);
 
+// How one kind of gathered vector (length-m: read through the columns of the A^T shard; length-n:
+// through the columns of the A shard) reaches this rank after a half-step.  Dense coupling: one
+// in-place all-gather.  Sparse coupling (the shards name less than half of the remote entries, e.g.
+// banded or block-angular LPs): every rank packs exactly the entries each peer's column indices
+// name, one grouped send/recv moves them, a scatter kernel drops them into the full-length vector.
+// The choice is made from the all-gathered request counts, so every rank takes the same branch.
+struct HaloPlan {
+    bool sparse = false;
+    int nsend = 0, nrecv = 0;
+    long total_requests = 0;  // over all ranks (info)
+    DBuf<int> send_idx, recv_idx;  // positions in the gathered vector, grouped by peer, ascending
+    DBuf<double> sendbuf, recvbuf;
+    std::vector<P2P> ops;
+    void build(Comm *comm, const int *cols, long nnz, int total, int chunk, hipStream_t s);
+};
+
 struct Solver {
     HPRLP_parameters prm;
     int m = 0, n = 0;          // global sizes
@@ -60,6 +75,7 @@ struct Solver {
     Comm *comm = nullptr;
 
     DeviceMatrix A, AT;  // A: m_loc x n (global columns); AT: n_loc x m (global columns)
+    HaloPlan halo_m, halo_n;  // exchange of length-m / length-n gathered vectors (multi-GPU only)
     DBuf<double> AL, AU, l, u, c, row_norm, col_norm;
     // local work vectors
     DBuf<double> x, last_x, z_bar, last_y, y_obj, y_temp;

@@ -348,7 +348,56 @@ class Solver:
         self.h = L.hprlp_solver_create_dist(model._ptr, C.byref(cp), rank, size, uid, 0 if unique_id is None else 128)
         if not self.h:
             raise RuntimeError("hprlp_solver_create_dist failed: " + last_error())
+        self._set_local_sizes(rank, size)
         return self
+
+    def _set_local_sizes(self, rank, size):
+        """run()/get() of a sharded solver return this rank's slices: rows [row_off, row_off+m_loc), ..."""
+        off, cnt = C.c_int(), C.c_int()
+        lib().hprlp_partition(self.model.m, size, rank, C.byref(off), C.byref(cnt))
+        self.row_off, self.m_loc = off.value, cnt.value
+        lib().hprlp_partition(self.model.n, size, rank, C.byref(off), C.byref(cnt))
+        self.col_off, self.n_loc = off.value, cnt.value
+
+    @classmethod
+    def create_local(cls, model, param, rank, size, group):
+        """Rank `rank` of a `size`-rank solve whose ranks are host threads of this process (hprlp_solver_create_local);
+        `group` comes from local_group(size).  Call from the rank's own thread."""
+        L = lib()
+        L.hprlp_solver_create_local.restype = C.c_void_p
+        L.hprlp_solver_create_local.argtypes = [C.POINTER(CLPInfo), C.POINTER(CParameters), C.c_int, C.c_int, C.c_void_p]
+        self = cls.__new__(cls)
+        self.model = model
+        cp = (param or Parameters()).to_c()
+        self.h = L.hprlp_solver_create_local(model._ptr, C.byref(cp), rank, size, group)
+        if not self.h:
+            raise RuntimeError("hprlp_solver_create_local failed: " + last_error())
+        self._set_local_sizes(rank, size)
+        return self
+
+    @staticmethod
+    def local_group(size):
+        L = lib()
+        L.hprlp_local_group_create.restype = C.c_void_p
+        L.hprlp_local_group_create.argtypes = [C.c_int]
+        g = L.hprlp_local_group_create(size)
+        if not g:
+            raise RuntimeError(last_error())
+        return C.c_void_p(g)
+
+    @staticmethod
+    def free_local_group(group):
+        L = lib()
+        L.hprlp_local_group_destroy.argtypes = [C.c_void_p]
+        L.hprlp_local_group_destroy(group)
+
+    def dist_info(self):
+        L = lib()
+        L.hprlp_solver_dist_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        out = (C.c_long * 8)()
+        self._chk(L.hprlp_solver_dist_info(self.h, out))
+        keys = ("m_sparse", "m_sent", "m_received", "n_sparse", "n_sent", "n_received", "m_requests", "n_requests")
+        return dict(zip(keys, [int(v) for v in out]))
 
     @staticmethod
     def dist_unique_id():
@@ -428,7 +477,7 @@ class Solver:
         trace = (CTraceRow * max_trace)()
         nt = C.c_int(0)
         self._chk(lib().hprlp_solver_run(self.h, C.byref(res), trace, max_trace, C.byref(nt)))
-        r = Results(res, self.model.m, self.model.n)
+        r = Results(res, getattr(self, "m_loc", self.model.m), getattr(self, "n_loc", self.model.n))
         r.trace = [{f: getattr(trace[i], f) for f, _ in CTraceRow._fields_} for i in range(nt.value)]
         return r
 

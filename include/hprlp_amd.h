@@ -106,6 +106,20 @@ int hprlp_dist_unique_id(void *out, int bytes);
  * get_vector/run then return this rank's slices; scalars/residuals are global. */
 hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
                                        const void *unique_id, int id_bytes);
+/* How the fresh slices travel: if the shards' column indices name at most half of the remote entries
+ * (banded / block-structured LPs) each rank sends exactly the entries its peers read (pack kernel, one grouped
+ * RCCL send/recv, scatter kernel); otherwise one in-place all-gather.  HPRLP_DIST_EXCHANGE=sparse|allgather
+ * overrides (same value on every rank).
+ * out = {m-vectors sparse?, entries sent, received, n-vectors sparse?, sent, received, all ranks' requests m, n} */
+int hprlp_solver_dist_info(hprlp_solver *s, long out[8]);
+/* The same multi-rank solver with `size` ranks as host THREADS of one process on one GPU, exchanging through
+ * device copies and host barriers instead of RCCL: lets the sharded path run on a one-GPU box (tests). Every
+ * rank's thread must make the same sequence of solver calls. */
+typedef struct hprlp_local_group hprlp_local_group;
+hprlp_local_group *hprlp_local_group_create(int size);
+void hprlp_local_group_destroy(hprlp_local_group *g);
+hprlp_solver *hprlp_solver_create_local(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
+                                        hprlp_local_group *group);
 
 /* ---- presolve / postsolve as separate host-side steps (what solve() does around the iteration when
  * use_presolve is set; replaces the reference's forked PSLP worker, src/pslp_integration.cpp:628-787).

@@ -37,3 +37,101 @@ def test_one_rank_rccl_path_equals_plain_solver(gpu):
     assert (f0.status, f0.iter) == (f1.status, f1.iter) and f0.primal_obj == f1.primal_obj
     assert f0.status == "OPTIMAL" and abs(f0.primal_obj - lp["obj_star"]) <= 1e-5 * (1 + abs(lp["obj_star"]))
     model.free()
+
+
+def run_ranks(model, prm, world, steps):
+    """`world` ranks of the sharded solver as threads of this process on the one GPU (hprlp_solver_create_local)."""
+    import threading
+    group = hprlp.Solver.local_group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            s = hprlp.Solver.create_local(model, prm, rank, world, group)
+            s.scale()
+            lam, it = s.power_iteration()
+            s.init(-1.0, lam * 1.01)
+            s.iterate(steps, True)
+            res = s.residuals(steps + 1, True)
+            state = {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}
+            r = s.run()
+            out[rank] = dict(lam=lam, it=it, res=res, state=state, run=r, info=s.dist_info(),
+                             off=(s.row_off, s.m_loc, s.col_off, s.n_loc))
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            err[rank] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    hprlp.Solver.free_local_group(group)
+    assert all(e is None for e in err), err
+    return out
+
+
+def single(model, prm, steps):
+    s = hprlp.Solver(model, prm)
+    s.scale()
+    lam, it = s.power_iteration()
+    s.init(-1.0, lam * 1.01)
+    s.iterate(steps, True)
+    res = s.residuals(steps + 1, True)
+    state = {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}
+    r = s.run()
+    s.close()
+    return dict(lam=lam, it=it, res=res, state=state, run=r)
+
+
+def check_against_single(ref, ranks, m, n, obj_star):
+    for o in ranks:
+        row_off, m_loc, col_off, n_loc = o["off"]
+        assert o["it"] == ref["it"] and abs(o["lam"] - ref["lam"]) <= 1e-12 * ref["lam"]
+        for k in ("x", "x_bar", "z_bar"):
+            np.testing.assert_allclose(o["state"][k][:n_loc], ref["state"][k][col_off:col_off + n_loc], rtol=1e-9, atol=1e-12, err_msg=k)
+        for k in ("y", "y_bar"):
+            np.testing.assert_allclose(o["state"][k][:m_loc], ref["state"][k][row_off:row_off + m_loc], rtol=1e-9, atol=1e-12, err_msg=k)
+        for k in ref["res"]:
+            assert abs(o["res"][k] - ref["res"][k]) <= 1e-9 * (1 + abs(ref["res"][k])), k
+        assert o["run"].status == ref["run"].status == "OPTIMAL"
+        assert abs(o["run"].primal_obj - obj_star) <= 1e-5 * (1 + abs(obj_star))
+        assert abs(o["run"].iter - ref["run"].iter) <= 0.1 * ref["run"].iter + 150
+    # the slices of the ranks tile the solution
+    x = np.concatenate([o["run"].x[:o["off"][3]] for o in ranks])
+    y = np.concatenate([o["run"].y[:o["off"][1]] for o in ranks])
+    assert len(x) == n and len(y) == m
+    np.testing.assert_allclose(x, ref["run"].x, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solver_with_allgather_equals_single_gpu(gpu, world):
+    """Unstructured LP: the shards read most remote entries, so the plan keeps the all-gather."""
+    lp = lpgen.planted_lp(401, 653, 4000, 92)  # sizes not divisible by the world size
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+    ref = single(model, prm, 37)
+    ranks = run_ranks(model, prm, world, 37)
+    assert all(o["info"]["m_sparse"] == 0 and o["info"]["n_sparse"] == 0 for o in ranks)
+    check_against_single(ref, ranks, lp["m"], lp["n"], lp["obj_star"])
+    model.free()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_solver_with_neighbour_exchange_equals_single_gpu(gpu, world):
+    """Banded LP: every rank needs a halo and a few far entries only -> pack / grouped send-recv / scatter."""
+    import bench_helpers as bh
+    m = n = 6001
+    lp = bh.banded_lp(m, n, 8, 150)
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+    ref = single(model, prm, 23)
+    ranks = run_ranks(model, prm, world, 23)
+    chunk = -(-n // world)
+    for o in ranks:
+        assert o["info"]["m_sparse"] == 1 and o["info"]["n_sparse"] == 1
+        assert 0 < o["info"]["n_received"] < 0.6 * (n - chunk) and 0 < o["info"]["n_sent"]
+    assert sum(o["info"]["n_sent"] for o in ranks) == sum(o["info"]["n_received"] for o in ranks) == ranks[0]["info"]["n_requests"]
+    check_against_single(ref, ranks, m, n, lp["obj_star"])
+    model.free()

@@ -1,5 +1,6 @@
 """The column-tiled fused kernel (hpr-lp-c_amd/csrc/tiled.h) against the oracle.  The tiled path is
-normally reserved for matrices with >= 4M rows; HPRLP_TILED_MIN_ROWS forces it on a small banded LP."""
+normally reserved for matrices with >= 2M rows (one super-block per CU); HPRLP_TILED_MIN_ROWS forces it on a
+small banded LP."""
 import os
 
 import numpy as np
