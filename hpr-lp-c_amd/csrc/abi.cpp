@@ -463,7 +463,8 @@ extern "C" int hprlp_solver_info(hprlp_solver *h, long out[8]) {
     out[0] = s.m; out[1] = s.n; out[2] = s.A.view.nnz;
     out[3] = s.A.view.nblk; out[4] = s.AT.view.nblk;
     out[5] = s.A.view.grid(); out[6] = s.AT.view.grid();
-    out[7] = (s.A.view.tiled.valid ? 1 : 0) + (s.AT.view.tiled.valid ? 2 : 0);  // bit0: A tiled, bit1: A^T tiled
+    // bit0: A tiled, bit1: A^T tiled, bit2: normal iterations run in the single-workgroup small-LP kernel
+    out[7] = (s.A.view.tiled.valid ? 1 : 0) + (s.AT.view.tiled.valid ? 2 : 0) + (s.use_small && !s.comm ? 4 : 0);
     return 0;
     GUARD_END(-1)
 }

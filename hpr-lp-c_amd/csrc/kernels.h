@@ -156,6 +156,24 @@ void launch_unscale(int n, int m, const double *x_bar, const double *y_bar, cons
                     const double *col_norm, const double *row_norm, double b_scale, double c_scale, double *xo,
                     double *yo, double *zo, hipStream_t s);
 
+// ---- small-LP path (small.hip): `count` normal iterations in one single-workgroup launch -----------
+constexpr int kSmallMaxK = 12;     // matrix entries per thread (1024 threads) -> nnz <= 12288
+constexpr int kSmallMaxR = 2;      // rows per thread -> m, n <= 2048
+constexpr int kSmallMaxRow = 256;  // longest row / column (its owner thread sums it sequentially)
+struct SmallArgs {
+    int m, n, nnz;
+    const int *A_rowptr, *AT_rowptr;
+    const double *AT_val;          // the matrix is read once, in A^T order
+    const int *ent_ij;             // per A^T entry: row i of A | column j << 16
+    const int *ent_posA;           // per A^T entry: position of the same entry in the CSR order of A
+    const int *order_x, *order_y;  // rows of A^T / of A sorted by length, longest first (n / m entries)
+    double *x, *x_hat, *y;
+    const double *l, *u, *c, *last_x, *AL, *AU, *last_y;
+    Ctrl *ctrl;
+};
+bool small_path_fits(int m, int n, long nnz, int max_row_A, int max_row_AT);
+void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s);
+
 // multi-GPU neighbour exchange: dst[k] = src[idx[k]] before the sends, dst[idx[k]] = src[k] after the receives
 void launch_pack(const double *src, const int *idx, double *dst, int n, hipStream_t s);
 void launch_scatter(double *dst, const int *idx, const double *src, int n, hipStream_t s);

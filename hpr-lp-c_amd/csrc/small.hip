@@ -1,0 +1,210 @@
+// small.hip -- the HPR normal iterations of a SMALL LP (Netlib scale: nnz < 12288, m, n <= 2048,
+// rows and columns of at most 256 nonzeros) as ONE persistent 1024-thread workgroup that runs `count`
+// whole iterations per launch with everything on the chip.
+//
+// Why: on such an LP the regular path (k_spmv_fused, one launch per half-step) spends ~4 us per launch
+// on the kernel boundary and three dependent trips to memory (tools/latency_probe.py: 8 us per
+// iteration on config 2 whatever the block shape) for ~25 waves of work.  Here
+//   * the matrix lives in REGISTERS, once: thread t owns entries [t*K, (t+1)*K) of A^T in CSR order as
+//     {value, row i, column j, position of the same entry in the CSR order of A};
+//   * y, x_hat and the products of the current half-step live in LDS;
+//   * a row's data (x, c, l, u, last_x / y, AL, AU, last_y) lives in the registers of its owner thread;
+//     rows are dealt to threads sorted by length, so the 64 lanes of a wave sum rows of similar length.
+// A half-step is: every thread writes its products into LDS at their CSR position (of A^T for the
+// x-half, of A for the y-half) -> LDS barrier -> every row owner adds its row's products in CSR order
+// and applies the update -> LDS barrier.  No global memory is touched between the first and the last
+// iteration of a launch.  Per row the arithmetic is the stream mode's (products summed sequentially in
+// CSR order from 0; same update formulas as XEpi<false>/YEpi<false>::apply in kernels.hip), so the
+// iterates are bit-identical to the regular kernels' (tests/test_gpu_small.py).
+// Replaces, for this problem class, reference update_zx_normal_gpu / update_y_normal_gpu +
+// advance_halpern_factors (src/main_iterate.cu:434-481,68-70) and the graph replay around them
+// (src/HPRLP.cu:99-114,290-303).
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace hprlp {
+
+namespace {
+
+constexpr int NT = 1024;
+
+// Product q lives at prod[pad(q)]: one spare slot per 32 keeps the lanes' stride-K writes (K = 8: 64-byte
+// stride, 16 lanes on one bank pair) and the row owners' reads off the same LDS banks.
+__device__ __forceinline__ int pad(int q) { return q + (q >> 5); }
+
+// Sum of products [q0, q0+np) in index order.  The LDS reads are issued four at a time so that a long row
+// costs one LDS latency per four entries instead of one per entry; the additions stay sequential.
+__device__ __forceinline__ double seq_sum(const double *prod, int q0, int np) {
+    double s = 0.0;
+    int p = q0;
+    const int end = q0 + np;
+    for (; p + 4 <= end; p += 4) {
+        const double a0 = prod[pad(p)], a1 = prod[pad(p + 1)], a2 = prod[pad(p + 2)], a3 = prod[pad(p + 3)];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    if (p + 2 <= end) {
+        const double a0 = prod[pad(p)], a1 = prod[pad(p + 1)];
+        s += a0; s += a1;
+        p += 2;
+    }
+    if (p < end) s += prod[pad(p)];
+    return s;
+}
+
+// Returns w unchanged but opaque to the optimiser: LDS addresses derived from the packed per-entry words must be
+// recomputed in every iteration (2 ALU ops) instead of being hoisted out of the iteration loop into 4 more
+// registers per matrix entry -- that hoisting is what made the 12-entries-per-thread variant spill.
+__device__ __forceinline__ unsigned int fresh(unsigned int w) {
+    asm volatile("" : "+v"(w));
+    return w;
+}
+
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int KMAX, int R>
+__global__ void __launch_bounds__(NT) k_small_iterations(SmallArgs a, int K, int count) {
+    static_assert(KMAX % 2 == 0, "positions are packed in pairs");
+    __shared__ double prod[NT * KMAX + NT * KMAX / 32 + 1];
+    __shared__ double ys[NT * R];
+    __shared__ double xh[NT * R];
+    const int t = threadIdx.x;
+
+    // ---- this thread's matrix entries (A^T order): value, i | j << 16, position in A order (packed in pairs)
+    double v[KMAX];
+    unsigned int ij[KMAX], pa[KMAX / 2];
+    const int e0 = t * K;
+#pragma unroll
+    for (int k = 0; k < KMAX; k += 2) {
+        const int q0 = e0 + k, q1 = q0 + 1;
+        const bool on0 = k < K && q0 < a.nnz, on1 = k + 1 < K && q1 < a.nnz;
+        v[k] = on0 ? a.AT_val[q0] : 0.0;
+        v[k + 1] = on1 ? a.AT_val[q1] : 0.0;
+        ij[k] = on0 ? static_cast<unsigned int>(a.ent_ij[q0]) : 0u;
+        ij[k + 1] = on1 ? static_cast<unsigned int>(a.ent_ij[q1]) : 0u;
+        // entries beyond the end park their products in the last slot of prod, which no row reads (nnz < NT*KMAX)
+        const unsigned int park = static_cast<unsigned int>(NT * KMAX - 1);
+        const unsigned int p0 = on0 ? static_cast<unsigned int>(a.ent_posA[q0]) : park;
+        const unsigned int p1 = on1 ? static_cast<unsigned int>(a.ent_posA[q1]) : park;
+        pa[k >> 1] = p0 | (p1 << 16);
+    }
+
+    // ---- rows owned by this thread: slots t + NT*q of the rows sorted by length
+    double xi[R], ci[R], li[R], ui[R], lx[R], yi[R], lo[R], hi[R], ly[R];
+    unsigned int xseg[R], yseg[R];  // first product | count << 16 (first < 12288, count <= 256)
+    unsigned int own[R];            // row j of A^T | row i of A << 16 (0xffff: none)
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int slot = t + NT * q;
+        const bool on = slot < a.n, oni = slot < a.m;
+        const int j = on ? a.order_x[slot] : 0, i = oni ? a.order_y[slot] : 0;
+        own[q] = static_cast<unsigned int>(on ? j : 0xffff) | (static_cast<unsigned int>(oni ? i : 0xffff) << 16);
+        xi[q] = on ? a.x[j] : 0.0;
+        ci[q] = on ? a.c[j] : 0.0;
+        li[q] = on ? a.l[j] : 0.0;
+        ui[q] = on ? a.u[j] : 0.0;
+        lx[q] = on ? a.last_x[j] : 0.0;
+        const int xs = on ? a.AT_rowptr[j] : 0, xe = on ? a.AT_rowptr[j + 1] : 0;
+        xseg[q] = static_cast<unsigned int>(xs) | (static_cast<unsigned int>(xe - xs) << 16);
+        yi[q] = oni ? a.y[i] : 0.0;
+        lo[q] = oni ? a.AL[i] : 0.0;
+        hi[q] = oni ? a.AU[i] : 0.0;
+        ly[q] = oni ? a.last_y[i] : 0.0;
+        const int ysb = oni ? a.A_rowptr[i] : 0, ye = oni ? a.A_rowptr[i + 1] : 0;
+        yseg[q] = static_cast<unsigned int>(ysb) | (static_cast<unsigned int>(ye - ysb) << 16);
+        if (oni) ys[i] = yi[q];
+        if (on) xh[j] = 0.0;
+    }
+    const double sigma = a.ctrl->sigma, fact1 = a.ctrl->lam_sigma, fact2 = a.ctrl->inv_lam_sigma;
+    const int k0 = a.ctrl->kx;
+    __syncthreads();
+
+    for (int it = 0; it < count; ++it) {
+        const double f1 = 1.0 / (static_cast<double>(k0 + it) + 2.0), f2 = 1.0 - f1;
+        // ---- x-half: products of A^T y in A^T order (this thread's own consecutive slots)
+#pragma unroll
+        for (int k = 0; k < KMAX; k += 2) {
+            const double g0 = ys[fresh(ij[k]) & 0xffffu], g1 = ys[fresh(ij[k + 1]) & 0xffffu];
+            const int qq = static_cast<int>(fresh(static_cast<unsigned int>(e0))) + k;
+            if (k < K) prod[pad(qq)] = v[k] * g0;
+            if (k + 1 < K) prod[pad(qq + 1)] = v[k + 1] * g1;
+        }
+        lds_sync();
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const double s = seq_sum(prod, static_cast<int>(xseg[q] & 0xffffu), static_cast<int>(xseg[q] >> 16));
+            // same operations as XEpi<false>::apply
+            const double gc = s - ci[q];
+            const double zt = xi[q] + sigma * gc;
+            const double xb = fmin(ui[q], fmax(li[q], zt));
+            const double h = 2.0 * xb - xi[q];
+            xi[q] = f2 * h + f1 * lx[q];
+            if ((own[q] & 0xffffu) != 0xffffu) xh[own[q] & 0xffffu] = h;
+        }
+        lds_sync();
+        // ---- y-half: products of A x_hat, scattered to their position in the CSR order of A
+        // (the y-half of iteration k uses the same Halpern factors)
+#pragma unroll
+        for (int k = 0; k < KMAX; k += 2) {
+            const double g0 = xh[fresh(ij[k]) >> 16], g1 = xh[fresh(ij[k + 1]) >> 16];
+            const unsigned int pp = fresh(pa[k >> 1]);
+            prod[pad(static_cast<int>(pp & 0xffffu))] = v[k] * g0;
+            prod[pad(static_cast<int>(pp >> 16))] = v[k + 1] * g1;
+        }
+        lds_sync();
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const double s = seq_sum(prod, static_cast<int>(yseg[q] & 0xffffu), static_cast<int>(yseg[q] >> 16));
+            // same operations as YEpi<false>::apply
+            const double w = s - fact1 * yi[q];
+            const double d = fmax(lo[q] - w, fmin(hi[q] - w, 0.0));
+            const double yb = fact2 * d;
+            const double yh = 2.0 * yb - yi[q];
+            yi[q] = f2 * yh + f1 * ly[q];
+            if ((own[q] >> 16) != 0xffffu) ys[own[q] >> 16] = yi[q];
+        }
+        lds_sync();
+    }
+
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const unsigned int j = own[q] & 0xffffu, i = own[q] >> 16;
+        if (j != 0xffffu) {
+            a.x[j] = xi[q];
+            a.x_hat[j] = xh[j];
+        }
+        if (i != 0xffffu) a.y[i] = yi[q];
+    }
+    if (t == 0 && count > 0) {
+        a.ctrl->kx = k0 + count;
+        a.ctrl->ky = k0 + count - 1;
+    }
+}
+
+template <int KMAX, int R>
+void launch_kr(const SmallArgs &a, int count, hipStream_t s) {
+    const int K = (a.nnz + NT - 1) / NT;
+    hipLaunchKernelGGL((k_small_iterations<KMAX, R>), dim3(1), dim3(NT), 0, s, a, K, count);
+}
+
+}  // namespace
+
+bool small_path_fits(int m, int n, long nnz, int max_row_A, int max_row_AT) {
+    return m >= 1 && n >= 1 && m <= NT * kSmallMaxR && n <= NT * kSmallMaxR && nnz >= 1 &&
+           nnz < static_cast<long>(NT) * kSmallMaxK && max_row_A <= kSmallMaxRow && max_row_AT <= kSmallMaxRow;
+}
+
+void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s) {
+    if (count <= 0) return;
+    // instantiated by entries / rows per thread so that small problems do not carry the registers of big ones
+    const int K = (a.nnz + NT - 1) / NT;
+    const int R = (std::max(a.m, a.n) + NT - 1) / NT;
+    if (K <= 4 && R <= 1) launch_kr<4, 1>(a, count, s);
+    else if (K <= 4) launch_kr<4, 2>(a, count, s);
+    else if (K <= 8 && R <= 1) launch_kr<8, 1>(a, count, s);
+    else if (K <= 8) launch_kr<8, 2>(a, count, s);
+    else if (R <= 1) launch_kr<12, 1>(a, count, s);
+    else launch_kr<12, 2>(a, count, s);
+}
+
+}  // namespace hprlp

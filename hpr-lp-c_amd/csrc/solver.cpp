@@ -24,9 +24,11 @@ std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4
     blk.reserve(static_cast<size_t>(rows) / 8 + 16);
     // block shape: at most cap_rows rows and cap_nnz nonzeros per wave (tuning knobs; the kernel needs
     // rows <= kStreamRows and nonzeros <= kStreamW)
-    int cap_rows = kStreamRows, cap_nnz = kStreamW;
+    // measured (tools/latency_probe.py, config 3): launch-latency-bound matrices run 9 % faster with twice
+    // as many, half as long blocks (256: 15.9 us/iteration, 512: 17.4, 128: 16.0); large ones stream best at 512
+    int cap_rows = kStreamRows, cap_nnz = (rows > 0 && rowptr[rows] < (1 << 22)) ? kStreamW / 2 : kStreamW;
     if (const char *e = std::getenv("HPRLP_STREAM_ROWS")) cap_rows = std::min(kStreamRows, std::max(1, std::atoi(e)));
-    if (const char *e = std::getenv("HPRLP_STREAM_NNZ")) cap_nnz = std::min(kStreamW, std::max(kLongRow, std::atoi(e)));
+    if (const char *e = std::getenv("HPRLP_STREAM_NNZ")) cap_nnz = std::min(kStreamW, std::max(16, std::atoi(e)));
     int r = 0, slots = 0;
     while (r < rows) {
         const int len = rowptr[r + 1] - rowptr[r];
@@ -174,6 +176,35 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
         std::vector<double> tv;
         csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
         AT.upload(n, m, trp.data(), tci.data(), tv.data());
+        for (int i = 0; i < m; ++i) max_row_A = std::max(max_row_A, As->rowPtr[i + 1] - As->rowPtr[i]);
+        for (int j = 0; j < n; ++j) max_row_AT = std::max(max_row_AT, trp[j + 1] - trp[j]);
+        const char *ns = std::getenv("HPRLP_NO_SMALL");
+        use_small = !(ns && ns[0] == '1') && small_path_fits(m, n, nnz, max_row_A, max_row_AT);
+        if (use_small) {
+            auto by_length = [](int rows, const int *rp, DBuf<int> &out) {
+                std::vector<int> ord(rows);
+                for (int i = 0; i < rows; ++i) ord[i] = i;
+                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return rp[a + 1] - rp[a] > rp[b + 1] - rp[b]; });
+                out.alloc(rows);
+                out.upload(ord.data(), rows);
+            };
+            by_length(n, trp.data(), small_order_x);
+            by_length(m, As->rowPtr, small_order_y);
+            // the transpose is stable in row order: the k-th entry of A (row i, column j) is the next free
+            // slot of row j of A^T
+            std::vector<int> next(trp.begin(), trp.end() - 1), ij(static_cast<size_t>(nnz)), posA(static_cast<size_t>(nnz));
+            for (int i = 0; i < m; ++i)
+                for (int k = As->rowPtr[i]; k < As->rowPtr[i + 1]; ++k) {
+                    const int j = As->colIndex[k], q = next[j]++;
+                    if (tci[q] != i) throw std::runtime_error("small path: transpose is not stable");
+                    ij[q] = i | (j << 16);
+                    posA[q] = k;
+                }
+            small_ij.alloc(ij.size());
+            small_ij.upload(ij.data(), ij.size());
+            small_posA.alloc(posA.size());
+            small_posA.upload(posA.data(), posA.size());
+        }
     }
     AL.alloc(m); AL.upload(model->AL, m);
     AU.alloc(m); AU.upload(model->AU, m);
@@ -538,6 +569,13 @@ hipGraphExec_t Solver::graph_for(int len) {
 
 void Solver::run_normal(int count) {
     if (count <= 0) return;
+    if (use_small && !comm) {
+        // Netlib-scale LP: all `count` iterations in one single-workgroup launch, matrices in registers (small.hip)
+        const SmallArgs a{m, n, A.view.nnz, A.view.rowptr, AT.view.rowptr, AT.view.val, small_ij.p, small_posA.p,
+                          small_order_x.p, small_order_y.p, x.p, x_hat, y, l.p, u.p, c.p, last_x.p, AL.p, AU.p, last_y.p, ctrl.p};
+        launch_small_iterations(a, count, stream);
+        return;
+    }
     if (!use_graph) {
         for (int i = 0; i < count; ++i) launch_normal_pair();
         return;

@@ -94,6 +94,10 @@ struct Solver {
     double setup_time = 0, scaling_time = 0, power_time = 0;
     int power_iters = 0;
     bool use_graph = true;
+    bool use_small = false;  // Netlib-scale LP on one GPU: normal iterations run in the single-workgroup kernel (small.hip)
+    int max_row_A = 0, max_row_AT = 0;
+    DBuf<int> small_order_x, small_order_y;  // rows of A^T / A sorted by length (row ownership in small.hip)
+    DBuf<int> small_ij, small_posA;          // per A^T entry: i | j << 16, position in the CSR order of A
 
     std::map<int, hipGraphExec_t> graphs;
     TraceRow *trace = nullptr;

@@ -1,0 +1,115 @@
+"""The single-workgroup small-LP kernel (hpr-lp-c_amd/csrc/small.hip): `count` normal HPR iterations in one
+launch with both matrices in registers.  It must produce bit-identical iterates to the regular per-half-step
+kernels and to the oracle (same per-row arithmetic), and hand the state back correctly to the check-variant
+kernels that run between its launches."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import hprlp, lpgen
+from oracle import oracle as O
+from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
+
+pytestmark = pytest.mark.gpu
+
+VECS = ("x", "x_hat", "y", "last_x", "last_y")
+
+
+def make(lp):
+    return hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"],
+                                lp["u"], lp["c"])
+
+
+def iterate_states(model, prm, plan, no_small):
+    old = os.environ.get("HPRLP_NO_SMALL")
+    os.environ["HPRLP_NO_SMALL"] = "1" if no_small else "0"
+    try:
+        s = hprlp.Solver(model, prm)
+        assert bool(s.info()["tiled"] & 4) == (not no_small)
+        s.scale()
+        lam, _ = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        out = []
+        for normal, check in plan:
+            s.iterate(normal, check)
+            out.append({k: s.get(k) for k in VECS})
+            out[-1]["k"] = (s.scalars()["kx"], s.scalars()["ky"])
+        res = s.residuals(sum(a + (1 if b else 0) for a, b in plan), True)
+        s.close()
+        return out, res
+    finally:
+        if old is None:
+            os.environ.pop("HPRLP_NO_SMALL", None)
+        else:
+            os.environ["HPRLP_NO_SMALL"] = old
+
+
+# (m, n, nnz): one row per thread / two rows per thread / the 512-thread variant (more than 8 entries per thread)
+@pytest.mark.parametrize("shape", [(300, 500, 2500), (600, 1500, 3500), (500, 1000, 7500), (821, 1571, 7000),
+                                   (821, 1571, 10700), (1900, 2040, 11500)])
+def test_small_kernel_equals_regular_kernels_bit_for_bit(gpu, shape):
+    m, n, nnz = shape
+    lp = lpgen.planted_lp(m, n, nnz, 5, dense_col_frac=0.01)
+    model = make(lp)
+    prm = hprlp.Parameters(use_presolve=False)
+    plan = [(1, False), (7, True), (64, False), (149, True), (3, False)]
+    small, res_s = iterate_states(model, prm, plan, no_small=False)
+    regular, res_r = iterate_states(model, prm, plan, no_small=True)
+    for a, b in zip(small, regular):
+        assert a["k"] == b["k"]
+        for k in VECS:
+            assert np.array_equal(a[k], b[k]), k
+    for k in res_r:
+        assert res_s[k] == res_r[k], k
+    model.free()
+
+
+def test_small_kernel_matches_oracle(gpu):
+    m, n = 400, 650
+    lp = lpgen.planted_lp(m, n, 4000, 8, dense_col_frac=0.01)
+    model = make(lp)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+    assert s.info()["tiled"] & 4
+    ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                     O.Params.default(use_CR_scaling=0))
+    s.scale()
+    adopt_gpu_data(s, ref)
+    st = run_steps(s, ref, 0.7, 1.3, [(23, True), (5, True), (40, False)])
+    for name in NAMES_N + NAMES_M:
+        assert np.array_equal(s.get(name), st[name]), name
+    s.close(); model.free()
+
+
+def test_whole_solve_on_the_small_path(gpu):
+    lp = lpgen.c2_25fv47_like()
+    model = make(lp)
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+    os.environ["HPRLP_NO_SMALL"] = "1"
+    try:
+        r_reg = model.solve(prm)
+    finally:
+        os.environ.pop("HPRLP_NO_SMALL", None)
+    r_small = model.solve(prm)
+    assert r_small.status == r_reg.status == "OPTIMAL"
+    assert r_small.iter == r_reg.iter and r_small.primal_obj == r_reg.primal_obj
+    assert np.array_equal(r_small.x, r_reg.x) and np.array_equal(r_small.y, r_reg.y)
+    assert abs(r_small.primal_obj - lp["obj_star"]) <= 1e-5 * (1 + abs(lp["obj_star"]))
+    model.free()
+
+
+def test_rows_too_long_for_the_small_path_fall_back(gpu):
+    """A 300-entry row exceeds the per-thread sequential sum limit (256): the regular kernels take over."""
+    from scipy import sparse
+    rng = np.random.default_rng(3)
+    lp = lpgen.planted_lp(200, 600, 1500, 6)
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(200, 600)).tolil()
+    for j in rng.choice(600, size=300, replace=False):
+        A[0, j] = 1.0
+    A = A.tocsr(); A.sort_indices()
+    x = np.abs(lp["x_star"]) + 0.1
+    b = A @ x
+    model = hprlp.Model.from_csr(200, 600, A.indptr, A.indices, A.data, b - 1.0, b + 1.0, np.zeros(600), np.full(600, 10.0), lp["c"])
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    assert not (s.info()["tiled"] & 4)
+    s.close(); model.free()

@@ -8,7 +8,7 @@ def _load(name, rel):
 H = _load("hprlp_amd", "hpr-lp-c_amd/hprlp.py"); G = _load("hprlp_lpgen", "hpr-lp-c_amd/lpgen.py")
 os.dup2(2, 1)
 lps = {"c2": G.c2_25fv47_like(), "c3": G.c3_pds20_like()}
-for rows, nnz, nt in [(64, 512, 1), (64, 512, 0), (64, 256, 1), (64, 256, 0), (32, 256, 0)]:
+for rows, nnz, nt in [(64, 512, 1), (64, 256, 1), (64, 128, 1), (64, 64, 1), (32, 64, 1), (64, 32, 1)]:
     os.environ["HPRLP_STREAM_ROWS"] = str(rows); os.environ["HPRLP_STREAM_NNZ"] = str(nnz); os.environ["HPRLP_NT"] = str(nt)
     for key, lp in lps.items():
         model = H.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
