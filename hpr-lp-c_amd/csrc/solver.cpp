@@ -60,19 +60,33 @@ std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4
     return blk;
 }
 
+// HPRLP_TIMING=1: wall time of the set-up phases on stderr
+struct PhaseTimer {
+    bool on;
+    clock_type::time_point t0;
+    PhaseTimer() : on(std::getenv("HPRLP_TIMING") != nullptr), t0(time_now()) {}
+    void tick(const char *what) {
+        if (on) std::cerr << "[timing] " << what << ": " << time_since(t0) << " s" << std::endl;
+        t0 = time_now();
+    }
+};
+
 void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, const double *v) {
+    PhaseTimer pt;
     const int nnz = rp[rows];
     // the kernels index without bounds checks: refuse anything that could fault on the device
     for (int i = 0; i < rows; ++i)
         if (rp[i + 1] < rp[i]) throw std::runtime_error("row pointer array is not monotone");
     for (int k = 0; k < nnz; ++k)
         if (ci[k] < 0 || ci[k] >= cols) throw std::runtime_error("column index out of range");
+    pt.tick("  validate indices");
     rowptr.alloc(static_cast<size_t>(rows) + 1);
     rowptr.upload(rp, static_cast<size_t>(rows) + 1);
     col.alloc(nnz);
     col.upload(ci, nnz);
     val.alloc(nnz);
     val.upload(v, nnz);
+    pt.tick("  upload CSR");
     std::vector<int4> lr;
     std::vector<int4> b = build_row_blocks(rows, rp, &lr);
     int nslots = 0;
@@ -86,6 +100,7 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     }
     blk.alloc(b.size());
     blk.upload(b.data(), b.size());
+    pt.tick("  row blocks");
     if (!lr.empty()) {
         longrows.alloc(lr.size());
         longrows.upload(lr.data(), lr.size());
@@ -116,11 +131,14 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
         const int min_rows = mr ? std::atoi(mr) : 256 * kTileRows;
         const double min_dense = md ? std::atof(md) : 0.5;
         TiledHost th;
-        if (build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense)) {
+        const bool ok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense);
+        pt.tick("  build tiled copy (host)");
+        if (ok) {
             tiled.upload(th);
             view.tiled = tiled.view;
             launch_tiled_refresh(tiled, val.p, nullptr);
             HIP_CHECK(hipDeviceSynchronize());
+            pt.tick("  upload tiled copy");
         }
     }
 }
@@ -170,12 +188,16 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     const sparseMatrix *As = model->A;
     if (!As || As->row != m || As->col != n) throw std::runtime_error("model matrix dimensions inconsistent");
     const long nnz = As->numElements;
+    PhaseTimer pt;
     A.upload(m, n, As->rowPtr, As->colIndex, As->value);
+    pt.tick("A upload total");
     {   // explicit A^T built on the host, stable in row order (reference src/preprocess.cu:78-82)
         std::vector<int> trp, tci;
         std::vector<double> tv;
         csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
+        pt.tick("host transpose");
         AT.upload(n, m, trp.data(), tci.data(), tv.data());
+        pt.tick("A^T upload total");
         for (int i = 0; i < m; ++i) max_row_A = std::max(max_row_A, As->rowPtr[i + 1] - As->rowPtr[i]);
         for (int j = 0; j < n; ++j) max_row_AT = std::max(max_row_AT, trp[j + 1] - trp[j]);
         const char *ns = std::getenv("HPRLP_NO_SMALL");
