@@ -460,6 +460,7 @@ extern "C" int hprlp_solver_get_scalars(hprlp_solver *h, double out[16]) {
 extern "C" int hprlp_solver_info(hprlp_solver *h, long out[8]) {
     GUARD_BEGIN
     Solver &s = h->s;
+    s.finish_tiling();  // report the kernels that will actually run
     out[0] = s.m; out[1] = s.n; out[2] = s.A.view.nnz;
     out[3] = s.A.view.nblk; out[4] = s.AT.view.nblk;
     out[5] = s.A.view.grid(); out[6] = s.AT.view.grid();

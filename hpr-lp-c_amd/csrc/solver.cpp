@@ -71,7 +71,7 @@ struct PhaseTimer {
     }
 };
 
-void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, const double *v) {
+void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, const double *v, std::shared_ptr<void> keep) {
     PhaseTimer pt;
     const int nnz = rp[rows];
     // the kernels index without bounds checks: refuse anything that could fault on the device
@@ -130,17 +130,31 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
         // 0.38 ms stream, 153 super-blocks 0.21 ms both -> one super-block per CU is the break-even
         const int min_rows = mr ? std::atoi(mr) : 256 * kTileRows;
         const double min_dense = md ? std::atof(md) : 0.5;
-        TiledHost th;
-        const bool ok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense);
-        pt.tick("  build tiled copy (host)");
-        if (ok) {
-            tiled.upload(th);
-            view.tiled = tiled.view;
-            launch_tiled_refresh(tiled, val.p, nullptr);
-            HIP_CHECK(hipDeviceSynchronize());
-            pt.tick("  upload tiled copy");
+        if (rows >= min_rows && rows > 0 && nnz > 0) {
+            planned_grid = ((rows + kTileRows - 1) / kTileRows + 7) / 8 * 8;
+            tiling = std::async(std::launch::async, [=]() -> std::shared_ptr<TiledHost> {
+                (void)keep;  // keeps the host arrays alive for the duration of the build
+                auto th = std::make_shared<TiledHost>();
+                return build_tiled(rows, cols, rp, ci, th.get(), min_rows, min_dense) ? th : nullptr;
+            });
         }
     }
+}
+
+void DeviceMatrix::finish_tiling(hipStream_t s) {
+    if (!tiling.valid()) return;
+    PhaseTimer pt;
+    std::shared_ptr<TiledHost> th = tiling.get();  // rethrows what the job threw
+    pt.tick("  wait for the tiled build");
+    if (!th) {
+        planned_grid = 0;
+        return;
+    }
+    tiled.upload(*th);
+    view.tiled = tiled.view;
+    launch_tiled_refresh(tiled, val.p, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    pt.tick("  upload tiled copy");
 }
 
 void DeviceMatrix::refresh_tiled(hipStream_t s) {
@@ -165,8 +179,8 @@ void Solver::alloc_work() {
     ctrl.alloc_zero(1);
     scal.alloc_zero(kNumScalars);
     scal_h.alloc(kNumScalars);
-    stride_x = std::max(AT.view.grid(), 1);
-    stride_y = std::max(A.view.grid(), 1);
+    stride_x = std::max(std::max(AT.view.grid(), AT.planned_grid), 1);  // either kernel's partials fit
+    stride_y = std::max(std::max(A.view.grid(), A.planned_grid), 1);
     part_x.alloc_zero(static_cast<size_t>(3) * stride_x);
     part_y.alloc_zero(static_cast<size_t>(2) * stride_y);
     part_r.alloc_zero(static_cast<size_t>(2) * std::max(stride_x, stride_y));
@@ -191,12 +205,17 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     PhaseTimer pt;
     A.upload(m, n, As->rowPtr, As->colIndex, As->value);
     pt.tick("A upload total");
-    {   // explicit A^T built on the host, stable in row order (reference src/preprocess.cu:78-82)
-        std::vector<int> trp, tci;
+    {   // explicit A^T built on the host, stable in row order (reference src/preprocess.cu:78-82); its index
+        // arrays are handed to the background job that builds the tiled copy of A^T
+        struct HostT {
+            std::vector<int> trp, tci;
+        };
+        auto ht = std::make_shared<HostT>();
+        std::vector<int> &trp = ht->trp, &tci = ht->tci;
         std::vector<double> tv;
         csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
         pt.tick("host transpose");
-        AT.upload(n, m, trp.data(), tci.data(), tv.data());
+        AT.upload(n, m, trp.data(), tci.data(), tv.data(), ht);
         pt.tick("A^T upload total");
         for (int i = 0; i < m; ++i) max_row_A = std::max(max_row_A, As->rowPtr[i + 1] - As->rowPtr[i]);
         for (int j = 0; j < n; ++j) max_row_AT = std::max(max_row_AT, trp[j + 1] - trp[j]);
@@ -234,8 +253,17 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     u.alloc(n); u.upload(model->u, n);
     c.alloc(n); c.upload(model->c, n);
     alloc_work();
+    // the tiled copy of A was built from the model's own arrays, which the caller may free once we return; the
+    // job of A^T owns its arrays and keeps running under scale()
+    A.finish_tiling(stream);
+    pt.tick("vectors, work space, tiled copy of A");
     HIP_CHECK(hipDeviceSynchronize());
     setup_time = time_since(t0);
+}
+
+void Solver::finish_tiling() {
+    if (A.tiling.valid()) A.finish_tiling(stream);
+    if (AT.tiling.valid()) AT.finish_tiling(stream);
 }
 
 void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int col_off_, int n_loc_, const int *Arp,
@@ -273,6 +301,7 @@ void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int c
         halo_m.build(comm, ATci, ATrp[n_loc], m, chunk_m, stream);
         halo_n.build(comm, Aci, Arp[m_loc], n, chunk_n, stream);
     }
+    finish_tiling();  // the shard arrays belong to the caller
     HIP_CHECK(hipDeviceSynchronize());
     setup_time = time_since(t0);
 }
@@ -462,7 +491,8 @@ void Solver::scale() {
     }
     norm_b = std::sqrt(bnorm_sq(this));
     norm_c = std::sqrt(reduce_sum_sq(c.p, n_loc));
-    A.refresh_tiled(stream);
+    finish_tiling();  // tiled copies still being built pick up the scaled values here ...
+    A.refresh_tiled(stream);  // ... finished ones are refreshed
     AT.refresh_tiled(stream);
     HIP_CHECK(hipMemsetAsync(gsm.p, 0, sizeof(double) * m_pad, stream));
     HIP_CHECK(hipMemsetAsync(gsn.p, 0, sizeof(double) * n_pad, stream));
@@ -476,6 +506,7 @@ void Solver::scale() {
 // host reads back only at the every-10th-iteration convergence check.
 // ------------------------------------------------------------------------------------------------
 double Solver::power_iteration(int max_iter, double tol, int *iters) {
+    finish_tiling();
     const auto t0 = time_now();
     double *q = gsm.p + row_off, *ATq = gsn.p + col_off, *z = sm1.p;
     {
@@ -540,6 +571,7 @@ void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
 }
 
 void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
+    finish_tiling();
     const double s0 = (norm_b > 1e-8 && norm_c > 1e-8) ? norm_b / norm_c : 1.0;
     set_sigma_lambda(s0, lambda_max, true);
 }
@@ -554,6 +586,7 @@ void Solver::launch_normal_pair() {
 }
 
 void Solver::step(bool check) {
+    finish_tiling();
     if (!check) {
         launch_normal_pair();
         return;
@@ -591,6 +624,7 @@ hipGraphExec_t Solver::graph_for(int len) {
 
 void Solver::run_normal(int count) {
     if (count <= 0) return;
+    finish_tiling();
     if (use_small && !comm) {
         // Netlib-scale LP: all `count` iterations in one single-workgroup launch, matrices in registers (small.hip)
         const SmallArgs a{m, n, A.view.nnz, A.view.rowptr, AT.view.rowptr, AT.view.val, small_ij.p, small_posA.p,
@@ -630,6 +664,7 @@ static double weighted_norm_from(Solver *s, double dot_adx_dy, double dy2, doubl
 }
 
 void Solver::compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs) {
+    finish_tiling();
     const int gx = AT.view.grid(), gyy = A.view.grid();
     const int rstride = std::max(stride_x, stride_y);
     gather(gyb.p, true);

@@ -3,6 +3,7 @@
 // (reference include/structs.h:127-277) without vendor-library handles.
 #pragma once
 
+#include <future>
 #include <map>
 #include <memory>
 
@@ -41,7 +42,13 @@ struct DeviceMatrix {
     DBuf<double> long_partial;
     DeviceTiled tiled;  // optional column-tiled copy for large matrices with column locality (tiled.h)
     CsrDev view;
-    void upload(int rows, int cols, const int *rp, const int *ci, const double *v);
+    // The tiled copy is built on the host (about a second per 2e8 nonzeros) by a background job started in
+    // upload(); until finish_tiling() has run every launch on this matrix uses the stream kernel.  `keep` is held
+    // by the job (the A^T arrays, which nobody else owns); rp / ci must stay valid until finish_tiling().
+    std::future<std::shared_ptr<TiledHost>> tiling;
+    int planned_grid = 0;  // grid of the tiled kernel if the build succeeds (sizes the reduction partials)
+    void upload(int rows, int cols, const int *rp, const int *ci, const double *v, std::shared_ptr<void> keep = nullptr);
+    void finish_tiling(hipStream_t s);  // wait for the job, upload the copy, fill its values from the CSR values
     void refresh_tiled(hipStream_t s);  // re-gather the tiled values from the CSR values (after scaling)
 };
 
@@ -129,6 +136,7 @@ struct Solver {
     double reduce_sum_sq(const double *v, int n_local);             // allreduced ||v||^2
     void gather(double *gbuf, bool is_m);                           // all-gather a length-m or length-n vector
     void allreduce_scalars();
+    void finish_tiling();  // adopt tiled copies whose background build is still pending (no-op otherwise)
 
    private:
     void alloc_work();
