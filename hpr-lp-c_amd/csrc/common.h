@@ -93,6 +93,9 @@ struct HBuf {
 // Host-side CSR transpose, stable in row order (reference src/utils.cu:203-232).
 void csr_transpose_host(int rows, int cols, long nnz, const int *rp, const int *ci, const double *v,
                         std::vector<int> &trp, std::vector<int> &tci, std::vector<double> &tv);
+// rows [c0, c1) of the transpose only
+void csr_transpose_range_host(int rows, int c0, int c1, const int *rp, const int *ci, const double *v,
+                              std::vector<int> &trp, std::vector<int> &tci, std::vector<double> &tv);
 
 // Deterministic start vector for the power iteration (spec in oracle/hpr_oracle.c; this is the
 // product's own implementation of the same counter RNG).

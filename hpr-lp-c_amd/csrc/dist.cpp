@@ -284,10 +284,11 @@ extern "C" int hprlp_extract_shard(const LP_info_cpu *model, int rank, int size,
         hprlp_partition(n, size, rank, &out->col_off, &out->n_loc);
         const int r0 = std::min(out->row_off, m), c0 = std::min(out->col_off, n);
         slice_rows(r0, out->m_loc, A->rowPtr, A->colIndex, A->value, &out->A_rowptr, &out->A_col, &out->A_val);
+        // this rank's rows of A^T = the entries of A whose column lies in its range: no full transpose
         std::vector<int> trp, tci;
         std::vector<double> tv;
-        csr_transpose_host(m, n, A->numElements, A->rowPtr, A->colIndex, A->value, trp, tci, tv);
-        slice_rows(c0, out->n_loc, trp.data(), tci.data(), tv.data(), &out->AT_rowptr, &out->AT_col, &out->AT_val);
+        csr_transpose_range_host(m, c0, c0 + out->n_loc, A->rowPtr, A->colIndex, A->value, trp, tci, tv);
+        slice_rows(0, out->n_loc, trp.data(), tci.data(), tv.data(), &out->AT_rowptr, &out->AT_col, &out->AT_val);
         out->AL = copy_out(model->AL + r0, out->m_loc);
         out->AU = copy_out(model->AU + r0, out->m_loc);
         out->l = copy_out(model->l + c0, out->n_loc);

@@ -18,63 +18,70 @@ const char *last_error_cstr() { return g_last_error.c_str(); }
 
 void csr_transpose_host(int rows, int cols, long nnz, const int *rp, const int *ci, const double *v,
                         std::vector<int> &trp, std::vector<int> &tci, std::vector<double> &tv) {
-    trp.assign(static_cast<size_t>(cols) + 1, 0);
-    tci.resize(static_cast<size_t>(nnz));
-    tv.resize(static_cast<size_t>(nnz));
-    // Large matrices: the same counting sort run by T threads over contiguous row ranges (thread t owns
-    // rows [t*chunk, ...)).  Per-thread column histograms give every thread its own write cursor per
-    // column, ordered by thread = ordered by row, so the result is identical to the sequential sort.
+    (void)nnz;
+    csr_transpose_range_host(rows, 0, cols, rp, ci, v, trp, tci, tv);
+}
+
+// Rows [c0, c1) of the transpose (= columns [c0, c1) of the matrix), stable in row order: a counting sort over the
+// entries whose column lies in the range.  Large matrices: T threads over contiguous row ranges, each with its own
+// column histogram, which gives every thread its own write cursor per column, ordered by thread = ordered by row,
+// so the result is identical to the sequential sort.  A rank of the row-partitioned solve calls this with its own
+// column range only (hprlp_extract_shard): no rank ever builds the whole transpose.
+void csr_transpose_range_host(int rows, int c0, int c1, const int *rp, const int *ci, const double *v,
+                              std::vector<int> &trp, std::vector<int> &tci, std::vector<double> &tv) {
+    const int nc = std::max(0, c1 - c0);
+    const long nnz = rp[rows];
+    trp.assign(static_cast<size_t>(nc) + 1, 0);
     int T = 1;
     if (nnz > 4000000) {
         T = static_cast<int>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
-        while (T > 1 && static_cast<size_t>(T) * static_cast<size_t>(cols) > 400000000UL) --T;
+        while (T > 1 && static_cast<size_t>(T) * static_cast<size_t>(nc) > 400000000UL) --T;
     }
-    if (T > 1) {
-        const int chunk = (rows + T - 1) / T;
-        std::vector<std::vector<int>> hist(static_cast<size_t>(T));
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t]() {
-                hist[t].assign(static_cast<size_t>(cols), 0);
-                const int r0 = std::min(rows, t * chunk), r1 = std::min(rows, r0 + chunk);
-                for (int k = rp[r0]; k < rp[r1]; ++k) hist[t][ci[k]]++;
-            });
-        for (auto &x : th) x.join();
-        th.clear();
-        long run = 0;
-        for (int j = 0; j < cols; ++j) {  // cursor of (column j, thread t) = start of column j + entries of earlier threads
-            trp[j] = static_cast<int>(run);
-            for (int t = 0; t < T; ++t) {
-                const int c = hist[t][j];
-                hist[t][j] = static_cast<int>(run);
-                run += c;
+    const int chunk = (rows + T - 1) / std::max(T, 1);
+    std::vector<std::vector<int>> hist(static_cast<size_t>(T));
+    auto count = [&](int t) {
+        hist[t].assign(static_cast<size_t>(nc), 0);
+        const int r0 = std::min(rows, t * chunk), r1 = std::min(rows, r0 + chunk);
+        for (int k = rp[r0]; k < rp[r1]; ++k) {
+            const int j = ci[k] - c0;
+            if (j >= 0 && j < nc) hist[t][j]++;
+        }
+    };
+    auto fill = [&](int t) {
+        const int r0 = std::min(rows, t * chunk), r1 = std::min(rows, r0 + chunk);
+        std::vector<int> &next = hist[t];
+        for (int i = r0; i < r1; ++i)
+            for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                const int j = ci[k] - c0;
+                if (j < 0 || j >= nc) continue;
+                const int pos = next[j]++;
+                tv[pos] = v[k];
+                tci[pos] = i;
             }
+    };
+    auto run = [&](auto &&fn) {
+        if (T == 1) {
+            fn(0);
+            return;
         }
-        trp[cols] = static_cast<int>(run);
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t]() {
-                const int r0 = std::min(rows, t * chunk), r1 = std::min(rows, r0 + chunk);
-                std::vector<int> &next = hist[t];
-                for (int i = r0; i < r1; ++i)
-                    for (int k = rp[i]; k < rp[i + 1]; ++k) {
-                        const int pos = next[ci[k]]++;
-                        tv[pos] = v[k];
-                        tci[pos] = i;
-                    }
-            });
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
         for (auto &x : th) x.join();
-        return;
-    }
-    for (long k = 0; k < nnz; ++k) trp[ci[k] + 1]++;
-    for (int j = 0; j < cols; ++j) trp[j + 1] += trp[j];
-    std::vector<int> next(trp.begin(), trp.end() - 1);
-    for (int i = 0; i < rows; ++i) {
-        for (int k = rp[i]; k < rp[i + 1]; ++k) {
-            const int pos = next[ci[k]]++;
-            tv[pos] = v[k];
-            tci[pos] = i;
+    };
+    run(count);
+    long total = 0;
+    for (int j = 0; j < nc; ++j) {  // cursor of (column j, thread t) = start of column j + entries of earlier threads
+        trp[j] = static_cast<int>(total);
+        for (int t = 0; t < T; ++t) {
+            const int c = hist[t][j];
+            hist[t][j] = static_cast<int>(total);
+            total += c;
         }
     }
+    trp[nc] = static_cast<int>(total);
+    tci.resize(static_cast<size_t>(total));
+    tv.resize(static_cast<size_t>(total));
+    run(fill);
 }
 
 static inline uint64_t splitmix64(uint64_t x) {

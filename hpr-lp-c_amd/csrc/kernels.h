@@ -174,6 +174,11 @@ struct SmallArgs {
 bool small_path_fits(int m, int n, long nnz, int max_row_A, int max_row_AT);
 void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s);
 
+// device CSR -> device CSR of the transpose, stable in row order (transpose.hip); all pointers are device memory,
+// trp has cols+1 entries, tci / tv nnz
+void device_transpose(int rows, int cols, long nnz, const int *rowptr, const int *col, const double *val, int *trp,
+                      int *tci, double *tv, hipStream_t s);
+
 // multi-GPU neighbour exchange: dst[k] = src[idx[k]] before the sends, dst[idx[k]] = src[k] after the receives
 void launch_pack(const double *src, const int *idx, double *dst, int n, hipStream_t s);
 void launch_scatter(double *dst, const int *idx, const double *src, int n, hipStream_t s);

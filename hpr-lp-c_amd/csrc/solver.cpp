@@ -87,6 +87,14 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     val.alloc(nnz);
     val.upload(v, nnz);
     pt.tick("  upload CSR");
+    describe(rows, cols, rp, ci, std::move(keep));
+}
+
+// Row blocks, kernel views and the background job for the tiled copy, for a matrix whose CSR arrays are already in
+// rowptr / col / val on the device (rp / ci: the same index arrays on the host).
+void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep) {
+    PhaseTimer pt;
+    const int nnz = rp[rows];
     std::vector<int4> lr;
     std::vector<int4> b = build_row_blocks(rows, rp, &lr);
     int nslots = 0;
@@ -212,10 +220,28 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
         };
         auto ht = std::make_shared<HostT>();
         std::vector<int> &trp = ht->trp, &tci = ht->tci;
-        std::vector<double> tv;
-        csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
-        pt.tick("host transpose");
-        AT.upload(n, m, trp.data(), tci.data(), tv.data(), ht);
+        const char *hostt = std::getenv("HPRLP_HOST_TRANSPOSE");
+        const char *dmin = std::getenv("HPRLP_DEVICE_TRANSPOSE_MIN");  // nonzero threshold (tests lower it)
+        if (nnz > (dmin ? std::atol(dmin) : 4000000L) && !(hostt && hostt[0] == '1')) {
+            // large matrix: transpose on the device (transpose.hip), bring the index arrays back for the host-side
+            // consumers (tiled build, row statistics)
+            AT.rowptr.alloc(static_cast<size_t>(n) + 1);
+            AT.col.alloc(static_cast<size_t>(nnz));
+            AT.val.alloc(static_cast<size_t>(nnz));
+            device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
+            pt.tick("device transpose");
+            trp.resize(static_cast<size_t>(n) + 1);
+            tci.resize(static_cast<size_t>(nnz));
+            AT.rowptr.download(trp.data(), trp.size());
+            AT.col.download(tci.data(), tci.size());
+            pt.tick("download A^T indices");
+            AT.describe(n, m, trp.data(), tci.data(), ht);
+        } else {
+            std::vector<double> tv;
+            csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
+            pt.tick("host transpose");
+            AT.upload(n, m, trp.data(), tci.data(), tv.data(), ht);
+        }
         pt.tick("A^T upload total");
         for (int i = 0; i < m; ++i) max_row_A = std::max(max_row_A, As->rowPtr[i + 1] - As->rowPtr[i]);
         for (int j = 0; j < n; ++j) max_row_AT = std::max(max_row_AT, trp[j + 1] - trp[j]);

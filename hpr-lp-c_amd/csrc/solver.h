@@ -48,6 +48,7 @@ struct DeviceMatrix {
     std::future<std::shared_ptr<TiledHost>> tiling;
     int planned_grid = 0;  // grid of the tiled kernel if the build succeeds (sizes the reduction partials)
     void upload(int rows, int cols, const int *rp, const int *ci, const double *v, std::shared_ptr<void> keep = nullptr);
+    void describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep);  // after the arrays are on the device
     void finish_tiling(hipStream_t s);  // wait for the job, upload the copy, fill its values from the CSR values
     void refresh_tiled(hipStream_t s);  // re-gather the tiled values from the CSR values (after scaling)
 };

@@ -1,0 +1,88 @@
+"""Device-side set-up: the transpose built on the GPU (csrc/transpose.hip) must equal the
+host counting sort entry for entry (both are stable in row order), for ragged matrices with empty rows and columns,
+and the solve that follows must not notice the difference; the background build of the tiled copies must give the
+same iterates as a solver that never tiles."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import bench_helpers as bh
+from conftest import hprlp, lpgen
+
+pytestmark = pytest.mark.gpu
+
+
+def with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_device_transpose_equals_host_transpose(gpu):
+    rng = np.random.default_rng(12)
+    m, n = 3001, 4507
+    A = sparse.random(m, n, density=0.004, random_state=rng, format="lil", data_rvs=lambda k: rng.normal(size=k))
+    A[17, :] = 0.0          # empty row
+    A[:, 100:140] = 0.0     # empty columns
+    for j in rng.choice(n, size=300, replace=False):
+        A[5, j] = rng.normal()  # one long row
+    A = A.tocsr(); A.eliminate_zeros(); A.sort_indices()
+    x = rng.uniform(0, 1, size=n)
+    b = A @ x
+    model = hprlp.Model.from_csr(m, n, A.indptr, A.indices, A.data, b - 1, b + 1, np.zeros(n), np.full(n, 2.0), rng.normal(size=n))
+
+    def grab():
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        at = s.get("AT_val")
+        s.scale()
+        lam, it = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        s.iterate(20, True)
+        out = (at, s.get("AT_val"), s.get("x"), s.get("y"), lam, it)
+        s.close()
+        return out
+
+    host = with_env({"HPRLP_HOST_TRANSPOSE": "1"}, grab)
+    dev = with_env({"HPRLP_DEVICE_TRANSPOSE_MIN": "0", "HPRLP_HOST_TRANSPOSE": "0"}, grab)
+    AT = A.T.tocsr(); AT.sort_indices()
+    assert np.array_equal(host[0], AT.data) and np.array_equal(dev[0], AT.data)
+    for a, b_ in zip(host[1:4], dev[1:4]):
+        assert np.array_equal(a, b_)
+    assert host[4:] == dev[4:]
+    model.free()
+
+
+def test_background_tiling_gives_the_tiled_kernels_iterates(gpu):
+    """With the tiled copy forced on, the solver must behave as if the copy had been there from the start: same
+    iterates whether the build is adopted at the end of scale() (normal) or before anything runs (info() call)."""
+    m = n = 20000
+    lp = bh.banded_lp(m, n, 10, 300)
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+
+    def run(early):
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        if early:
+            assert s.info()["tiled"] & 3 == 3  # info() adopts pending builds
+        s.scale()
+        lam, it = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        s.iterate(30, True)
+        assert s.info()["tiled"] & 3 == 3
+        out = (s.get("x"), s.get("y"), lam, it)
+        s.close()
+        return out
+
+    env = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "0.0"}
+    a = with_env(env, lambda: run(False))
+    b = with_env(env, lambda: run(True))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    model.free()
