@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <thread>
 
 #include "HPRLP.h"
 #include "common.h"
@@ -25,6 +26,58 @@ Presolve::~Presolve() {
     if (reduced_) free_model(reduced_);
 }
 
+// Large models (more than kScanFirstNnz nonzeros): before paying for the transpose and the working copies, one
+// threaded scan counts what the first pass of the loop below would remove (fixed and empty columns, empty,
+// singleton and redundant rows).  Less than 0.1 % of the rows + columns: not worth a reduced copy of the model.
+constexpr long kScanFirstNnz = 10000000;
+
+bool Presolve::worth_it(const LP_info_cpu *model) const {
+    const int m = model->m, n = model->n;
+    const int *rp = model->A->rowPtr, *ci = model->A->colIndex;
+    const double *av = model->A->value, *l = model->l, *u = model->u, *AL = model->AL, *AU = model->AU;
+    const int T = static_cast<int>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+    const int chunk = (m + T - 1) / T;
+    std::vector<std::vector<int>> hist(static_cast<size_t>(T));
+    std::vector<long> rows_hit(static_cast<size_t>(T), 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+            std::vector<int> &h = hist[t];
+            h.assign(static_cast<size_t>(n), 0);
+            long hit = 0;
+            const int r0 = std::min(m, t * chunk), r1 = std::min(m, r0 + chunk);
+            for (int i = r0; i < r1; ++i) {
+                int cnt = 0;
+                double lo_act = 0.0, up_act = 0.0;
+                bool lo_inf = false, up_inf = false;
+                for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                    const double a = av[k];
+                    if (a == 0.0) continue;
+                    const int j = ci[k];
+                    ++cnt;
+                    ++h[j];
+                    const double bl = a > 0 ? l[j] : u[j], bu = a > 0 ? u[j] : l[j];
+                    if (fin(bl)) lo_act += a * bl;
+                    else lo_inf = true;
+                    if (fin(bu)) up_act += a * bu;
+                    else up_inf = true;
+                }
+                const bool redundant = (!fin(AL[i]) || (!lo_inf && lo_act >= AL[i])) && (!fin(AU[i]) || (!up_inf && up_act <= AU[i]));
+                if (cnt <= 1 || redundant) ++hit;
+            }
+            rows_hit[t] = hit;
+        });
+    for (auto &x : th) x.join();
+    long hit = 0;
+    for (long v : rows_hit) hit += v;
+    for (int j = 0; j < n; ++j) {
+        int c = 0;
+        for (int t = 0; t < T; ++t) c += hist[t][j];
+        if (c == 0 || (fin(l[j]) && l[j] == u[j])) ++hit;
+    }
+    return static_cast<double>(hit) >= 1e-3 * (static_cast<double>(m) + static_cast<double>(n));
+}
+
 bool Presolve::run(const LP_info_cpu *model) {
     const auto t0 = std::chrono::steady_clock::now();
     if (!model || !model->A || model->m <= 0 || model->n <= 0) return false;
@@ -35,6 +88,10 @@ bool Presolve::run(const LP_info_cpu *model) {
     const int *rp = model->A->rowPtr, *ci = model->A->colIndex;
     const double *av = model->A->value;
     const long nnz = rp[m];
+    if (nnz > kScanFirstNnz && !worth_it(model)) {
+        stats_.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return false;
+    }
     csr_transpose_host(m, n, nnz, rp, ci, av, trp_, tci_, tv_);
 
     std::vector<double> AL(model->AL, model->AL + m), AU(model->AU, model->AU + m);

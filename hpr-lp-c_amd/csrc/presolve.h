@@ -43,6 +43,7 @@ class Presolve {
     void postsolve(const double *xr, const double *yr, const double *zr, double *x, double *y, double *z) const;
 
    private:
+    bool worth_it(const LP_info_cpu *model) const;  // large models: is there enough to remove?
     enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow };
     struct Record {
         Kind kind;
