@@ -56,11 +56,17 @@ struct TiledDev {
 struct TiledHost {
     std::vector<int> sb_ptr, sb_mid;
     std::vector<TileStep> steps;
-    std::vector<uint32_t> tidx;
-    std::vector<int> tperm;
-    std::vector<int> rcol, rperm;
-    std::vector<uint16_t> rrow;
-    long dense_entries = 0;  // CSR entries that landed in staged tiles
+    // The entry arrays stay in the pieces the builder threads produced (one per contiguous range of super-blocks,
+    // in order); the device copy is their concatenation -- the steps already carry the concatenated offsets.
+    struct Piece {
+        std::vector<uint32_t> tidx;
+        std::vector<int> tperm;
+        std::vector<int> rcol, rperm;
+        std::vector<uint16_t> rrow;
+    };
+    std::vector<Piece> pieces;
+    size_t n_tile = 0, n_rem = 0;  // total entries over the pieces
+    long dense_entries = 0;        // CSR entries that landed in staged tiles
     long padding = 0;
 };
 
