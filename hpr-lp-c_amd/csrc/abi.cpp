@@ -488,6 +488,29 @@ extern "C" int hprlp_solver_time_iterations(hprlp_solver *h, int warmup, int ste
         HIP_CHECK(hipEventRecord(e1, s.stream));
         HIP_CHECK(hipEventSynchronize(e1));
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } else if (mode == 2) {
+        // the bare SpMVs of the path (A^T y into scratch, A x_hat into scratch): no half-step update, no state change
+        std::vector<hipEvent_t> ev(static_cast<size_t>(steps) * 3);
+        for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(e0, s.stream));
+        for (int i = 0; i < steps; ++i) {
+            HIP_CHECK(hipEventRecord(ev[3 * i], s.stream));
+            launch_spmv_plain(s.AT.view, s.gy.p, s.sn1.p, nullptr, false, nullptr, 0, s.stream);
+            HIP_CHECK(hipEventRecord(ev[3 * i + 1], s.stream));
+            launch_spmv_plain(s.A.view, s.gxh.p, s.sm1.p, nullptr, false, nullptr, 0, s.stream);
+            HIP_CHECK(hipEventRecord(ev[3 * i + 2], s.stream));
+        }
+        HIP_CHECK(hipEventRecord(e1, s.stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        for (int i = 0; i < steps; ++i) {
+            float a = 0, b = 0;
+            HIP_CHECK(hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
+            HIP_CHECK(hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
+            tx += a;
+            ty += b;
+        }
+        for (auto &e : ev) (void)hipEventDestroy(e);
     } else {
         std::vector<hipEvent_t> ev(static_cast<size_t>(steps) * 3);
         for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));

@@ -68,7 +68,8 @@ int hprlp_solver_info(hprlp_solver *s, long out[8]);
 
 /* Timed normal iterations for bench.py.  mode 0: graph replay as the product runs it; wall time by
  * HIP events around the whole batch.  mode 1: eager launches with an event pair around every kernel
- * on the solver's stream; xhalf_ms / yhalf_ms are the SUMS of the x-half / y-half kernel durations. */
+ * on the solver's stream; xhalf_ms / yhalf_ms are the SUMS of the x-half / y-half kernel durations.  mode 2: the
+ * bare SpMVs A^T y and A x_hat into scratch (no update, iterate untouched), timed like mode 1. */
 int hprlp_solver_time_iterations(hprlp_solver *s, int warmup, int steps, int mode, double *total_ms,
                                  double *xhalf_ms, double *yhalf_ms);
 
