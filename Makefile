@@ -12,7 +12,7 @@ CPP_SRCS := $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.hip.o,$(HIP_SRCS)) $(patsubst $(CSRC)/%.cpp,$(BUILD)/%.o,$(CPP_SRCS))
 HDRS := $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
 
-all: lib/libhprlp.so bin/solve_mps_file
+all: lib/libhprlp.so lib/libhprlp.a bin/solve_mps_file $(BUILD)/solve_mps_file
 
 $(BUILD)/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -25,6 +25,15 @@ $(BUILD)/%.o: $(CSRC)/%.cpp $(HDRS)
 lib/libhprlp.so: $(OBJS)
 	@mkdir -p lib
 	$(HIPCC) -shared -fPIC $(HIPFLAGS) -o $@ $(OBJS) -lz -ldl -Wl,--no-undefined
+
+# the reference's other two artefacts at their reference paths (reference Makefile:114,118): the static archive
+# (link it with hipcc: the objects carry gfx950 code) and build/solve_mps_file
+lib/libhprlp.a: $(OBJS)
+	@mkdir -p lib
+	rm -f $@ && ar rcs $@ $(OBJS)
+
+$(BUILD)/solve_mps_file: bin/solve_mps_file
+	cp $< $@
 
 bin/solve_mps_file: tools/solve_mps_file.cpp lib/libhprlp.so include/HPRLP.h
 	@mkdir -p bin
