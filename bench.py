@@ -102,11 +102,25 @@ def bytes_y_half(m, n, nnz):
     return 12 * nnz + 4 * (m + 1) + 8 * n + 40 * m
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(name, steps_budget_s=12.0):
     """Oracle (CPU port) timed on the host cores on a bounded sample of the same workload: the banded
     generator at 1/16 of the rows/columns (same nnz per row); work per iteration is linear in nnz,
-    so iterations/sec of the full workload = sample rate / 16."""
+    so iterations/sec of the full workload = sample rate / 16.  One OpenMP thread per CPU of the process' share
+    (an oversubscribed team would only measure the scheduler)."""
     from oracle import oracle as O
+    O.set_num_threads(host_cpu_share())
     m, n, per_row, band = WORKLOADS[name]
     shrink = 16 if m >= 1_000_000 else 1
     ms, ns = m // shrink, n // shrink

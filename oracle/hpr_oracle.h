@@ -114,6 +114,7 @@ double orc_time_iterations(int m, int n, const int *Arp, const int *Aci, const d
                            double sigma, double lambda_max, int iters, double *x, double *y);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n); /* OpenMP team size of the timed loops (bench.py: the process' CPU share) */
 
 #ifdef __cplusplus
 }

@@ -220,3 +220,7 @@ def solve_batched(m, n, rp, ci, v, B, Cmat, AL, AU, L, U, obj_constants=None, mo
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
