@@ -135,3 +135,29 @@ def test_sharded_solver_with_neighbour_exchange_equals_single_gpu(gpu, world):
     assert sum(o["info"]["n_sent"] for o in ranks) == sum(o["info"]["n_received"] for o in ranks) == ranks[0]["info"]["n_requests"]
     check_against_single(ref, ranks, m, n, lp["obj_star"])
     model.free()
+
+
+def test_sharded_solver_with_tiled_kernels_on_the_shards(gpu):
+    """Tiled kernels forced on the shards: they stage whole column tiles of the gathered vector, including entries
+    the neighbour exchange never delivers (no matrix entry reads them) -- the iterates must not notice."""
+    import os
+    import bench_helpers as bh
+    old = {k: os.environ.get(k) for k in ("HPRLP_TILED_MIN_ROWS", "HPRLP_TILED_MIN_DENSE")}
+    os.environ["HPRLP_TILED_MIN_ROWS"] = "1"
+    os.environ["HPRLP_TILED_MIN_DENSE"] = "0.0"
+    try:
+        m = n = 20000
+        lp = bh.banded_lp(m, n, 10, 300)
+        model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        prm = hprlp.Parameters(stop_tol=1e-5, use_presolve=False)
+        ref = single(model, prm, 23)
+        ranks = run_ranks(model, prm, 2, 23)
+        assert all(o["info"]["m_sparse"] == 1 and o["info"]["n_sparse"] == 1 for o in ranks)
+        check_against_single(ref, ranks, m, n, lp["obj_star"])
+        model.free()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
