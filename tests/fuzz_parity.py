@@ -1,0 +1,72 @@
+"""Randomised parity sweep (run by hand / by tests/test_gpu_fuzz.py): planted LPs of many shapes through the whole GPU
+solve and through the oracle's solve; same status and iteration count (up to a rare restart fork), objective within
+10*tol of the planted optimum.  Shapes cover the small-LP kernel, the stream kernel with long rows, and the tiled
+kernel (forced)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from conftest import hprlp, lpgen  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def one(m, n, nnz, seed, tol, env, max_iter=200000):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        lp = lpgen.planted_lp(m, n, nnz, seed, dense_col_frac=0.02 if seed % 2 else 0.0, free_frac=0.1 if seed % 3 == 0 else 0.0)
+        model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                     lp["l"], lp["u"], lp["c"])
+        r = model.solve(hprlp.Parameters(stop_tol=tol, use_presolve=False, max_iter=max_iter))
+        ref = O.solve(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                      params=O.Params.default(stop_tol=tol, max_iter=max_iter))
+        model.free()
+        rel = abs(r.primal_obj - lp["obj_star"]) / (1 + abs(lp["obj_star"]))
+        return dict(shape=(m, n, nnz, seed), status=(r.status, ref["status"]), iters=(r.iter, ref["iter"]), rel=rel,
+                    dobj=abs(r.primal_obj - ref["primal_obj"]) / (1 + abs(ref["primal_obj"])))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def sweep(count=36, tol=1e-6, max_iter=200000):
+    rng = np.random.default_rng(2026)
+    out = []
+    for t in range(count):
+        kind = t % 3
+        if kind == 0:    # small-LP kernel
+            m = int(rng.integers(20, 1500)); n = int(rng.integers(m, 2000)); nnz = int(min(11500, rng.integers(3 * m, 8 * m + 10)))
+            env = {}
+        elif kind == 1:  # stream kernel
+            m = int(rng.integers(500, 4000)); n = int(rng.integers(m, 6000)); nnz = int(rng.integers(13000, 40000))
+            env = {"HPRLP_NO_SMALL": "1"}
+        else:            # tiled kernel forced
+            m = int(rng.integers(3000, 9000)); n = int(rng.integers(m, 12000)); nnz = int(rng.integers(20000, 60000))
+            env = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "0.0"}
+        out.append(one(m, n, nnz, 100 + t, tol, env, max_iter))
+    return out
+
+
+def acceptable(r, tol):
+    """Same status, iteration counts equal up to a late restart fork, same objective as the oracle, and an OPTIMAL
+    objective within 100*tol of the planted one (the stopping test bounds the relative KKT error, not this)."""
+    same = r["status"][0] == r["status"][1] and abs(r["iters"][0] - r["iters"][1]) <= 0.1 * r["iters"][1] + 150
+    return same and (r["status"][0] != "OPTIMAL" or (r["rel"] <= 100 * tol and r["dobj"] <= 100 * tol))
+
+
+if __name__ == "__main__":
+    os.dup2(2, 1)
+    res = sweep()
+    bad = 0
+    for r in res:
+        ok = acceptable(r, 1e-6)
+        bad += not ok
+        print(("ok  " if ok else "BAD ") + str(r), file=sys.stderr)
+    print(f"{len(res) - bad}/{len(res)} ok, identical iteration counts: {sum(r['iters'][0] == r['iters'][1] for r in res)}", file=sys.stderr)
+    sys.exit(1 if bad else 0)

