@@ -27,7 +27,8 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
     struct Ent {
         int row, lcol, k;
     };
-    std::vector<std::vector<Ent>> bucket;
+    std::vector<Ent> ents;                 // dense entries of the current super-block, grouped by tile
+    std::vector<int> b_begin, b_cursor;    // per dense tile slot: first entry / fill cursor in `ents`
     std::vector<std::pair<int, int>> rem, rem_long;  // (local row, csr index)
     {   // one allocation per output array instead of doubling growth (page faults and copies dominate otherwise)
         const size_t r_lo = static_cast<size_t>(sb0) * R, r_hi = std::min<size_t>(static_cast<size_t>(rows), static_cast<size_t>(sb1) * R);
@@ -47,27 +48,40 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
         }
         std::sort(touched.begin(), touched.end());
         int nd = 0;
-        for (int tl : touched) slot[tl] = (cnt[tl] >= kTileDenseMin) ? nd++ : -1;
-        if (static_cast<int>(bucket.size()) < nd) bucket.resize(nd);
-        for (int i = 0; i < nd; ++i) bucket[i].clear();
+        b_begin.clear();
+        int dense_total = 0;
+        for (int tl : touched) {
+            if (cnt[tl] >= kTileDenseMin) {
+                slot[tl] = nd++;
+                b_begin.push_back(dense_total);
+                dense_total += cnt[tl];
+            } else {
+                slot[tl] = -1;
+            }
+        }
+        b_begin.push_back(dense_total);
+        b_cursor.assign(b_begin.begin(), b_begin.end() - 1);
+        if (ents.size() < static_cast<size_t>(dense_total)) ents.resize(static_cast<size_t>(dense_total));
         rem.clear();
         rem_long.clear();
         for (int r = r0; r < r1; ++r)
             for (int k = rp[r]; k < rp[r + 1]; ++k) {
                 const int tl = ci[k] / T;
-                if (slot[tl] >= 0) bucket[slot[tl]].push_back(Ent{r - r0, ci[k] - tl * T, k});
+                const int sl = slot[tl];
+                if (sl >= 0) ents[b_cursor[sl]++] = Ent{r - r0, ci[k] - tl * T, k};
                 else rem.emplace_back(r - r0, k);
             }
         const size_t first_step = L->steps.size();
         for (int tl : touched) {
             if (slot[tl] < 0) continue;
-            const std::vector<Ent> &b = bucket[slot[tl]];
+            const Ent *b = ents.data() + b_begin[slot[tl]];
+            const size_t bn = static_cast<size_t>(b_begin[slot[tl] + 1] - b_begin[slot[tl]]);
             const size_t tile_begin = L->tidx.size();
             size_t i = 0;
-            int last_row = b.empty() ? 0 : b[0].row;
-            while (i < b.size()) {
+            int last_row = bn == 0 ? 0 : b[0].row;
+            while (i < bn) {
                 size_t j = i;
-                while (j < b.size() && b[j].row == b[i].row) ++j;
+                while (j < bn && b[j].row == b[i].row) ++j;
                 const int len = static_cast<int>(j - i);
                 if (len > K) {  // long segment: remainder path keeps it whole
                     for (size_t q = i; q < j; ++q) rem_long.emplace_back(b[q].row, b[q].k);
