@@ -51,3 +51,27 @@ def model_mps_arrays():
     """The reference's only known-answer LP (reference data/model.mps, examples/c/example_direct_lp.c:20-33)."""
     return dict(m=2, n=2, rowptr=[0, 2, 4], colind=[0, 1, 0, 1], values=[1.0, 2.0, 3.0, 1.0],
                 AL=[-INF, -INF], AU=[10.0, 12.0], l=[0.0, 0.0], u=[INF, INF], c=[-3.0, -5.0])
+
+
+def _cpu_share():
+    """CPUs this process may really use (cgroup quota, else affinity mask)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The oracle's OpenMP team defaults to every hardware thread of the host (256 on the GPU box, whose quota is 16
+    CPUs): size it to the share, or the oracle-heavy tests mostly measure the scheduler."""
+    try:
+        from oracle import oracle as O
+        O.set_num_threads(_cpu_share())
+    except Exception:
+        pass
+    yield
