@@ -158,6 +158,10 @@ void DeviceMatrix::finish_tiling(hipStream_t s) {
         planned_grid = 0;
         return;
     }
+    if (pt.on)
+        std::cerr << "[timing]   tiled copy: " << th->sb_mid.size() << " super-blocks, " << th->steps.size() << " steps, "
+                  << th->dense_entries << " entries in tiles + " << th->padding << " padding, " << th->n_rem
+                  << " in the remainder list" << std::endl;
     tiled.upload(*th);
     view.tiled = tiled.view;
     launch_tiled_refresh(tiled, val.p, s);
