@@ -138,7 +138,30 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         // 0.38 ms stream, 153 super-blocks 0.21 ms both -> one super-block per CU is the break-even
         const int min_rows = mr ? std::atoi(mr) : 256 * kTileRows;
         const double min_dense = md ? std::atof(md) : 0.5;
-        if (rows >= min_rows && rows > 0 && nnz > 0) {
+        const char *ht = std::getenv("HPRLP_HOST_TILING");
+        const bool host_tiling = ht && ht[0] == '1';
+        if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
+            // built on the device from the device CSR arrays (tiled_build.hip); HPRLP_TILING_CHECK=1 also runs the
+            // host builder and compares every array
+            const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr);
+            if (pt.on)
+                std::cerr << "[timing]   tiled copy (device build): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, "
+                          << tiled.n_steps << " steps, " << tiled.dense_entries << " entries in tiles + " << tiled.padding
+                          << " padding, " << tiled.n_rem << " in the remainder list" << std::endl;
+            if (ok) {
+                view.tiled = tiled.view;
+                launch_tiled_refresh(tiled, val.p, nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
+            }
+            const char *chk = std::getenv("HPRLP_TILING_CHECK");
+            if (chk && chk[0] == '1' && ci) {
+                TiledHost th;
+                const bool hok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense);
+                if (hok != ok) throw std::runtime_error("tiling check: host and device builders disagree on acceptance");
+                if (ok) tiled.compare_with(th);
+            }
+            pt.tick("  build tiled copy (device)");
+        } else if (rows >= min_rows && rows > 0 && nnz > 0) {
             planned_grid = ((rows + kTileRows - 1) / kTileRows + 7) / 8 * 8;
             tiling = std::async(std::launch::async, [=]() -> std::shared_ptr<TiledHost> {
                 (void)keep;  // keeps the host arrays alive for the duration of the build
@@ -235,11 +258,16 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
             pt.tick("device transpose");
             trp.resize(static_cast<size_t>(n) + 1);
-            tci.resize(static_cast<size_t>(nnz));
             AT.rowptr.download(trp.data(), trp.size());
-            AT.col.download(tci.data(), tci.size());
+            // the column indices of A^T are only needed on the host by the host tiled builder (or its check)
+            const char *htile = std::getenv("HPRLP_HOST_TILING"), *chk = std::getenv("HPRLP_TILING_CHECK");
+            const bool need_tci = (htile && htile[0] == '1') || (chk && chk[0] == '1');
+            if (need_tci) {
+                tci.resize(static_cast<size_t>(nnz));
+                AT.col.download(tci.data(), tci.size());
+            }
             pt.tick("download A^T indices");
-            AT.describe(n, m, trp.data(), tci.data(), ht);
+            AT.describe(n, m, trp.data(), need_tci ? tci.data() : nullptr, ht);
         } else {
             std::vector<double> tv;
             csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);

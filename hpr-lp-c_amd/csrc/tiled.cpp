@@ -3,7 +3,10 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <thread>
+#include <type_traits>
 
 namespace hprlp {
 
@@ -258,6 +261,39 @@ void DeviceTiled::upload(const TiledHost &h) {
     view.rval = rval.p;
     view.rcol = rcol.p;
     view.rrow = rrow.p;
+}
+
+void DeviceTiled::compare_with(const TiledHost &h) const {
+    auto fail = [](const std::string &what) { throw std::runtime_error("tiling check: " + what); };
+    if (n_tile != static_cast<long>(h.n_tile)) fail("tile entries " + std::to_string(n_tile) + " vs " + std::to_string(h.n_tile));
+    if (n_rem != static_cast<long>(h.n_rem)) fail("remainder entries " + std::to_string(n_rem) + " vs " + std::to_string(h.n_rem));
+    if (dense_entries != h.dense_entries || padding != h.padding) fail("dense / padding totals");
+    auto same = [&](const char *name, const auto &dbuf, const auto &host) {
+        using T = typename std::decay<decltype(host[0])>::type;
+        std::vector<T> dev(host.size());
+        if (!host.empty()) HIP_CHECK(hipMemcpy(dev.data(), dbuf.p, host.size() * sizeof(T), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < host.size(); ++i)
+            if (std::memcmp(&dev[i], &host[i], sizeof(T)) != 0) fail(std::string(name) + " differs at " + std::to_string(i));
+    };
+    same("sb_ptr", sb_ptr, h.sb_ptr);
+    same("sb_mid", sb_mid, h.sb_mid);
+    if (static_cast<size_t>(n_steps) != h.steps.size()) fail("step count");
+    same("steps", steps, h.steps);
+    std::vector<uint32_t> a_tidx;
+    std::vector<int> a_tperm, a_rcol, a_rperm;
+    std::vector<uint16_t> a_rrow;
+    for (const TiledHost::Piece &pc : h.pieces) {
+        a_tidx.insert(a_tidx.end(), pc.tidx.begin(), pc.tidx.end());
+        a_tperm.insert(a_tperm.end(), pc.tperm.begin(), pc.tperm.end());
+        a_rcol.insert(a_rcol.end(), pc.rcol.begin(), pc.rcol.end());
+        a_rperm.insert(a_rperm.end(), pc.rperm.begin(), pc.rperm.end());
+        a_rrow.insert(a_rrow.end(), pc.rrow.begin(), pc.rrow.end());
+    }
+    same("tidx", tidx, a_tidx);
+    same("tperm", tperm, a_tperm);
+    same("rcol", rcol, a_rcol);
+    same("rperm", rperm, a_rperm);
+    same("rrow", rrow, a_rrow);
 }
 
 }  // namespace hprlp

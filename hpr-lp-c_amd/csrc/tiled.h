@@ -83,7 +83,15 @@ struct DeviceTiled {
     DBuf<double> tval, rval;
     TiledDev view;
     long n_tile = 0, n_rem = 0;
+    long dense_entries = 0, padding = 0;
+    int n_steps = 0;
     void upload(const TiledHost &h);
+    // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,
+    // too scattered, or too large for 32-bit entry offsets) and nothing is valid.
+    bool build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
+                         double min_dense_fraction, hipStream_t s);
+    // throws std::runtime_error naming the first difference between this (device-built) copy and the host builder's
+    void compare_with(const TiledHost &h) const;
 };
 
 // tval[e] = csr_val[tperm[e]] (0 for padding), rval likewise

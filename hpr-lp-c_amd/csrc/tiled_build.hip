@@ -1,0 +1,374 @@
+// tiled_build.hip -- the column-tiled matrix copy (tiled.h) built ON THE DEVICE from the device CSR arrays
+// (the set-up no longer waits for ~0.5 s of host work per 2e8-nonzero matrix, and the index
+// arrays of a device-built A^T never travel to the host).  The result is array-for-array identical to the host
+// builder's (tiled.cpp, kept as the reference and for matrices the device path declines): same packing rule --
+// entries of a (super-block, tile) pair in (row, CSR order), chunks of 4 that no row segment straddles, padding
+// that repeats the previous row, tiles cut into steps of <= 2048 entries, sparse tiles and segments longer than 4
+// in a remainder list in (row, CSR order) -- tests/test_gpu_setup.py compares the two.
+//
+// Pipeline (all on `s`): key = (super-block, tile, local row) per entry; STABLE radix sort of (key, entry index)
+// [hipCUB]; runs of equal (super-block, tile) by head flags + scan; one thread per run walks its entries once to
+// size the padded list (or to flag a sparse run / long segments for the remainder) and, after an exclusive scan
+// of the sizes, a second time to write tidx / tperm / the steps; remainder entries are the flagged entries in
+// original order [hipCUB select]; the per-super-block step tables (1221 entries on config 5) are finished on the host.
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "tiled.h"
+
+namespace hprlp {
+
+namespace {
+
+constexpr int R = kTileRows, T = kTileCols, K = kTileChunk;
+constexpr int kRowBits = 13;
+static_assert((1 << kRowBits) == R, "the key packs the local row in 13 bits");
+
+__device__ __forceinline__ int row_of_entry(const int *__restrict__ rowptr, int rows, int k) {
+    int lo = 0, hi = rows;  // rowptr[lo] <= k < rowptr[hi]
+    while (hi - lo > 1) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (rowptr[mid] <= k) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(kThreads) k_make_keys(long nnz, int rows, int tile_bits, const int *__restrict__ rowptr,
+                                                       const int *__restrict__ col, unsigned long long *__restrict__ key,
+                                                       int *__restrict__ idx) {
+    const long k = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (k >= nnz) return;
+    const int r = row_of_entry(rowptr, rows, static_cast<int>(k));
+    const unsigned long long sb = static_cast<unsigned long long>(r / R), rl = static_cast<unsigned long long>(r % R);
+    const unsigned long long tl = static_cast<unsigned long long>(col[k] / T);
+    key[k] = (sb << (tile_bits + kRowBits)) | (tl << kRowBits) | rl;
+    idx[k] = static_cast<int>(k);
+}
+
+__global__ void __launch_bounds__(kThreads) k_run_heads(long nnz, const unsigned long long *__restrict__ skey, int *__restrict__ head) {
+    const long p = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (p >= nnz) return;
+    head[p] = (p == 0 || (skey[p] >> kRowBits) != (skey[p - 1] >> kRowBits)) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kThreads) k_run_starts(long nnz, const int *__restrict__ head, const int *__restrict__ run_incl,
+                                                        int *__restrict__ run_start) {
+    const long p = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (p >= nnz) return;
+    if (head[p]) run_start[run_incl[p] - 1] = static_cast<int>(p);
+}
+
+// One walk of a run = the host builder's loop over one bucket (tiled.cpp).  PASS 1 sizes the padded list and flags
+// what goes to the remainder; PASS 2 writes the packed entries.
+template <int PASS>
+__device__ __forceinline__ int walk_run(int begin, int end, const unsigned long long *__restrict__ skey,
+                                        const int *__restrict__ sperm, const int *__restrict__ col, int col0,
+                                        char *__restrict__ flag_sorted, uint32_t *__restrict__ tidx, int *__restrict__ tperm,
+                                        int out0, int *dense, int *pad) {
+    int len_out = 0;  // entries emitted so far (position in the tile list)
+    int last_row = static_cast<int>(skey[begin] & (R - 1));
+    int i = begin;
+    while (i < end) {
+        const unsigned long long rkey = skey[i];
+        int j = i + 1;
+        while (j < end && skey[j] == rkey) ++j;
+        const int len = j - i, row = static_cast<int>(rkey & (R - 1));
+        if (len > K) {  // long segment: remainder
+            if (PASS == 1)
+                for (int q = i; q < j; ++q) flag_sorted[q] = 1;
+            i = j;
+            continue;
+        }
+        const int pos = len_out % K;
+        if (pos + len > K) {
+            for (int q = pos; q < K; ++q) {
+                if (PASS == 2) {
+                    tidx[out0 + len_out] = static_cast<uint32_t>(last_row);
+                    tperm[out0 + len_out] = -1;
+                }
+                ++len_out;
+                if (PASS == 1) ++*pad;
+            }
+        }
+        for (int q = i; q < j; ++q) {
+            if (PASS == 2) {
+                const int src = sperm[q];
+                tperm[out0 + len_out] = src;
+                tidx[out0 + len_out] = (static_cast<uint32_t>(col[src] - col0) << 16) | static_cast<uint32_t>(row);
+            }
+            ++len_out;
+        }
+        if (PASS == 1) *dense += len;
+        last_row = row;
+        i = j;
+    }
+    while (len_out % K) {
+        if (PASS == 2) {
+            tidx[out0 + len_out] = static_cast<uint32_t>(last_row);
+            tperm[out0 + len_out] = -1;
+        }
+        ++len_out;
+        if (PASS == 1) ++*pad;
+    }
+    return len_out;
+}
+
+__global__ void __launch_bounds__(kThreads) k_run_pass1(int nruns, const int *__restrict__ run_start,
+                                                       const unsigned long long *__restrict__ skey, char *__restrict__ flag_sorted,
+                                                       int *__restrict__ padded_len, int *__restrict__ nsteps,
+                                                       unsigned long long *__restrict__ totals) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= nruns) return;
+    const int begin = run_start[r], end = run_start[r + 1];
+    if (end - begin < kTileDenseMin) {
+        for (int q = begin; q < end; ++q) flag_sorted[q] = 1;
+        padded_len[r] = 0;
+        nsteps[r] = 0;
+        return;
+    }
+    int dense = 0, pad = 0;
+    const int len = walk_run<1>(begin, end, skey, nullptr, nullptr, 0, flag_sorted, nullptr, nullptr, 0, &dense, &pad);
+    padded_len[r] = len;
+    nsteps[r] = (len + kTileStepCap - 1) / kTileStepCap;
+    atomicAdd(&totals[0], static_cast<unsigned long long>(dense));
+    atomicAdd(&totals[1], static_cast<unsigned long long>(pad));
+}
+
+// first run whose super-block is >= sb, for sb = 0..nsb  (runs are sorted by (super-block, tile))
+__global__ void __launch_bounds__(kThreads) k_first_run_of_sb(int nsb, int nruns, int tile_bits, const int *__restrict__ run_start,
+                                                             const unsigned long long *__restrict__ skey, int *__restrict__ first_run) {
+    const int sb = blockIdx.x * kThreads + threadIdx.x;
+    if (sb > nsb) return;
+    int lo = 0, hi = nruns;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        const int rsb = static_cast<int>(skey[run_start[mid]] >> (tile_bits + kRowBits));
+        if (rsb < sb) lo = mid + 1;
+        else hi = mid;
+    }
+    first_run[sb] = lo;
+}
+
+__global__ void __launch_bounds__(kThreads) k_run_pass2(int nruns, int tile_bits, const int *__restrict__ run_start,
+                                                       const unsigned long long *__restrict__ skey, const int *__restrict__ sperm,
+                                                       const int *__restrict__ padded_len, const int *__restrict__ run_off,
+                                                       const int *__restrict__ run_step_off, const int *__restrict__ first_run,
+                                                       const int *__restrict__ sb_ptr, const int *__restrict__ col,
+                                                       uint32_t *__restrict__ tidx, int *__restrict__ tperm, TileStep *__restrict__ steps) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= nruns) return;
+    const int len = padded_len[r];
+    if (len == 0) return;
+    const int begin = run_start[r], end = run_start[r + 1], out0 = run_off[r];
+    const unsigned long long k0 = skey[begin];
+    const int tl = static_cast<int>((k0 >> kRowBits) & ((1ULL << tile_bits) - 1));
+    walk_run<2>(begin, end, skey, sperm, col, tl * T, nullptr, tidx, tperm, out0, nullptr, nullptr);
+    const int sb = static_cast<int>(k0 >> (tile_bits + kRowBits));
+    const int s0 = sb_ptr[sb] + (run_step_off[r] - run_step_off[first_run[sb]]);
+    for (int p = 0, j = 0; p < len; p += kTileStepCap, ++j)
+        steps[s0 + j] = TileStep{tl * T, out0 + p, out0 + min(len, p + kTileStepCap), 0};
+}
+
+__global__ void __launch_bounds__(kThreads) k_gather_int(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ dst) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ void __launch_bounds__(kThreads) k_scatter_flags(long nnz, const char *__restrict__ flag_sorted, const int *__restrict__ sperm,
+                                                           int *__restrict__ flag_orig) {
+    const long p = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (p >= nnz) return;
+    flag_orig[sperm[p]] = flag_sorted[p];
+}
+
+__global__ void __launch_bounds__(kThreads) k_rem_before(int nsb, int rows, const int *__restrict__ rowptr, const int *__restrict__ rem_prefix,
+                                                        int *__restrict__ rem_before) {
+    const int sb = blockIdx.x * kThreads + threadIdx.x;
+    if (sb > nsb) return;
+    const long r = static_cast<long>(sb) * R;
+    rem_before[sb] = rem_prefix[rowptr[r < rows ? r : rows]];
+}
+
+__global__ void __launch_bounds__(kThreads) k_fill_remainder(int n_rem, int rows, const int *__restrict__ rem_k, const int *__restrict__ rowptr,
+                                                            const int *__restrict__ col, int *__restrict__ rperm, int *__restrict__ rcol,
+                                                            uint16_t *__restrict__ rrow) {
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= n_rem) return;
+    const int k = rem_k[e];
+    rperm[e] = k;
+    rcol[e] = col[k];
+    rrow[e] = static_cast<uint16_t>(row_of_entry(rowptr, rows, k) % R);
+}
+
+__global__ void __launch_bounds__(kThreads) k_rem_steps(int nsb, const int *__restrict__ sb_mid, const int *__restrict__ rem_before,
+                                                       TileStep *__restrict__ steps) {
+    const int sb = blockIdx.x * kThreads + threadIdx.x;
+    if (sb >= nsb) return;
+    const int b = rem_before[sb], e = rem_before[sb + 1];
+    for (int p = b, j = 0; p < e; p += kTileRemCap, ++j) steps[sb_mid[sb] + j] = TileStep{0, p, min(e, p + kTileRemCap), 0};
+}
+
+inline unsigned grid_for(long n) { return static_cast<unsigned>((n + kThreads - 1) / kThreads); }
+
+}  // namespace
+
+bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
+                                  double min_dense_fraction, hipStream_t s) {
+    if (rows < min_rows || rows <= 0 || cols <= 0 || nnz <= 0 || nnz >= 2000000000L) return false;
+    const int nsb = (rows + R - 1) / R;
+    const int ntile = (cols + T - 1) / T;
+    int tile_bits = 1;
+    while ((1 << tile_bits) < ntile) ++tile_bits;
+    int sb_bits = 1;
+    while ((1 << sb_bits) < nsb) ++sb_bits;
+    const int key_bits = sb_bits + tile_bits + kRowBits;
+
+    DBuf<unsigned long long> key_in(static_cast<size_t>(nnz)), skey(static_cast<size_t>(nnz));
+    DBuf<int> idx_in(static_cast<size_t>(nnz)), sperm(static_cast<size_t>(nnz));
+    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, rows, tile_bits, rowptr, col, key_in.p, idx_in.p);
+    size_t tmp_bytes = 0;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), 0,
+                                                 key_bits, s));
+    {
+        DBuf<char> tmp(tmp_bytes + 16);
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), 0,
+                                                     key_bits, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    key_in.release();
+    idx_in.release();
+
+    // runs of equal (super-block, tile)
+    DBuf<int> head(static_cast<size_t>(nnz)), run_incl(static_cast<size_t>(nnz));
+    hipLaunchKernelGGL(k_run_heads, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, skey.p, head.p);
+    HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, head.p, run_incl.p, static_cast<int>(nnz), s));
+    {
+        DBuf<char> tmp(tmp_bytes + 16);
+        HIP_CHECK(hipcub::DeviceScan::InclusiveSum(tmp.p, tmp_bytes, head.p, run_incl.p, static_cast<int>(nnz), s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    int nruns = 0;
+    HIP_CHECK(hipMemcpy(&nruns, run_incl.p + (nnz - 1), sizeof(int), hipMemcpyDeviceToHost));
+    DBuf<int> run_start(static_cast<size_t>(nruns) + 1);
+    hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, head.p, run_incl.p, run_start.p);
+    {
+        const int end = static_cast<int>(nnz);
+        HIP_CHECK(hipMemcpyAsync(run_start.p + nruns, &end, sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    head.release();
+    run_incl.release();
+
+    // pass 1: sizes and remainder flags
+    DBuf<char> flag_sorted;
+    flag_sorted.alloc_zero(static_cast<size_t>(nnz));
+    DBuf<int> padded_len(static_cast<size_t>(nruns) + 1), nsteps(static_cast<size_t>(nruns) + 1);
+    DBuf<unsigned long long> totals;
+    totals.alloc_zero(2);
+    HIP_CHECK(hipMemsetAsync(padded_len.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
+    HIP_CHECK(hipMemsetAsync(nsteps.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
+    hipLaunchKernelGGL(k_run_pass1, dim3(grid_for(nruns)), dim3(kThreads), 0, s, nruns, run_start.p, skey.p, flag_sorted.p, padded_len.p,
+                       nsteps.p, totals.p);
+    unsigned long long tot[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (static_cast<double>(tot[0]) < min_dense_fraction * static_cast<double>(nnz) || tot[0] + tot[1] > 2000000000ULL) return false;
+    n_tile = static_cast<long>(tot[0] + tot[1]);
+
+    // offsets of the runs' entries and steps (exclusive scans over nruns + 1 elements: the last one is the total)
+    DBuf<int> run_off(static_cast<size_t>(nruns) + 1), run_step_off(static_cast<size_t>(nruns) + 1);
+    auto exclusive_scan = [&](const int *in, int *out, int count) {
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, count, s));
+        DBuf<char> tmp(bytes + 16);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, count, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    };
+    exclusive_scan(padded_len.p, run_off.p, nruns + 1);
+    exclusive_scan(nsteps.p, run_step_off.p, nruns + 1);
+
+    // remainder: flags back in original order, prefix sums, per-super-block boundaries
+    DBuf<int> flag_orig(static_cast<size_t>(nnz) + 1), rem_prefix(static_cast<size_t>(nnz) + 1);
+    HIP_CHECK(hipMemsetAsync(flag_orig.p + nnz, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_scatter_flags, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, flag_sorted.p, sperm.p, flag_orig.p);
+    exclusive_scan(flag_orig.p, rem_prefix.p, static_cast<int>(nnz) + 1);
+    int n_rem_i = 0;
+    HIP_CHECK(hipMemcpy(&n_rem_i, rem_prefix.p + nnz, sizeof(int), hipMemcpyDeviceToHost));
+    n_rem = n_rem_i;
+    flag_sorted.release();
+
+    // per-super-block tables: finished on the host (nsb + 1 entries)
+    DBuf<int> first_run(static_cast<size_t>(nsb) + 1), rem_before(static_cast<size_t>(nsb) + 1);
+    hipLaunchKernelGGL(k_first_run_of_sb, dim3(grid_for(nsb + 1)), dim3(kThreads), 0, s, nsb, nruns, tile_bits, run_start.p, skey.p,
+                       first_run.p);
+    hipLaunchKernelGGL(k_rem_before, dim3(grid_for(nsb + 1)), dim3(kThreads), 0, s, nsb, rows, rowptr, rem_prefix.p, rem_before.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+    DBuf<int> dsteps(static_cast<size_t>(nsb) + 1);  // tile steps before each super-block
+    hipLaunchKernelGGL(k_gather_int, dim3(grid_for(nsb + 1)), dim3(kThreads), 0, s, nsb + 1, first_run.p, run_step_off.p, dsteps.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<int> h_rem(static_cast<size_t>(nsb) + 1), h_dsteps(static_cast<size_t>(nsb) + 1);
+    rem_before.download(h_rem.data(), h_rem.size());
+    dsteps.download(h_dsteps.data(), h_dsteps.size());
+    std::vector<int> h_sb_ptr(static_cast<size_t>(nsb) + 1), h_sb_mid(static_cast<size_t>(nsb));
+    int rsteps_before = 0;
+    for (int sb = 0; sb <= nsb; ++sb) {
+        h_sb_ptr[sb] = h_dsteps[sb] + rsteps_before;
+        if (sb < nsb) {
+            h_sb_mid[sb] = h_sb_ptr[sb] + (h_dsteps[sb + 1] - h_dsteps[sb]);
+            rsteps_before += (h_rem[sb + 1] - h_rem[sb] + kTileRemCap - 1) / kTileRemCap;
+        }
+    }
+    const int total_steps = h_sb_ptr[nsb];
+    sb_ptr.alloc(h_sb_ptr.size());
+    sb_ptr.upload(h_sb_ptr.data(), h_sb_ptr.size());
+    sb_mid.alloc(h_sb_mid.size());
+    sb_mid.upload(h_sb_mid.data(), h_sb_mid.size());
+    steps.alloc(static_cast<size_t>(total_steps));
+
+    // pass 2: the packed entries and the tile steps; remainder arrays and steps
+    tidx.alloc_zero(static_cast<size_t>(n_tile) + 8);
+    tperm.alloc(static_cast<size_t>(n_tile) + 8);
+    tval.alloc_zero(static_cast<size_t>(n_tile) + 8);
+    hipLaunchKernelGGL(k_run_pass2, dim3(grid_for(nruns)), dim3(kThreads), 0, s, nruns, tile_bits, run_start.p, skey.p, sperm.p, padded_len.p,
+                       run_off.p, run_step_off.p, first_run.p, sb_ptr.p, col, tidx.p, tperm.p, steps.p);
+    rcol.alloc_zero(static_cast<size_t>(n_rem) + 8);
+    rperm.alloc(static_cast<size_t>(n_rem) + 8);
+    rrow.alloc_zero(static_cast<size_t>(n_rem) + 8);
+    rval.alloc_zero(static_cast<size_t>(n_rem) + 8);
+    if (n_rem > 0) {
+        DBuf<int> rem_k(static_cast<size_t>(n_rem)), nsel(1);
+        hipcub::CountingInputIterator<int> iota(0);
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota, flag_orig.p, rem_k.p, nsel.p, static_cast<int>(nnz), s));
+        DBuf<char> tmp(bytes + 16);
+        HIP_CHECK(hipcub::DeviceSelect::Flagged(tmp.p, bytes, iota, flag_orig.p, rem_k.p, nsel.p, static_cast<int>(nnz), s));
+        hipLaunchKernelGGL(k_fill_remainder, dim3(grid_for(n_rem)), dim3(kThreads), 0, s, static_cast<int>(n_rem), rows, rem_k.p, rowptr, col,
+                           rperm.p, rcol.p, rrow.p);
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_rem_steps, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, sb_mid.p, rem_before.p, steps.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+
+    dense_entries = static_cast<long>(tot[0]);
+    padding = static_cast<long>(tot[1]);
+    n_steps = total_steps;
+    view = TiledDev();
+    view.valid = true;
+    view.nsb = nsb;
+    view.grid = (nsb + 7) / 8 * 8;
+    view.sb_ptr = sb_ptr.p;
+    view.sb_mid = sb_mid.p;
+    view.steps = steps.p;
+    view.tval = tval.p;
+    view.tidx = tidx.p;
+    view.rval = rval.p;
+    view.rcol = rcol.p;
+    view.rrow = rrow.p;
+    return true;
+}
+
+}  // namespace hprlp

@@ -86,3 +86,51 @@ def test_background_tiling_gives_the_tiled_kernels_iterates(gpu):
     b = with_env(env, lambda: run(True))
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
     model.free()
+
+
+@pytest.mark.parametrize("case", ["banded", "narrow_band_long_segments", "ragged_with_empty_rows", "unsorted_columns", "wide_random"])
+def test_device_tiled_build_equals_host_build(gpu, case):
+    """HPRLP_TILING_CHECK=1 makes the solver build the tiled copies with BOTH builders (device: tiled_build.hip, host:
+    tiled.cpp) and compare every array; creation fails with the first difference."""
+    rng = np.random.default_rng(5)
+    if case == "banded":
+        m, n = 30000, 30000
+        lp = bh.banded_lp(m, n, 12, 600)
+        rp, ci, v = lp["rowptr"], lp["colind"], lp["values"]
+    elif case == "narrow_band_long_segments":
+        m, n = 9001, 2500
+        lp = bh.banded_lp(m, n, 9, 40)
+        rp, ci, v = lp["rowptr"], lp["colind"], lp["values"]
+    else:
+        m, n = (20011, 5003) if case == "ragged_with_empty_rows" else (17000, 40000)
+        dens = 0.002 if case != "wide_random" else 0.0006
+        A = sparse.random(m, n, density=dens, random_state=rng, format="csr", data_rvs=lambda k: rng.normal(size=k))
+        if case == "ragged_with_empty_rows":
+            A = A.tolil(); A[100:400, :] = 0.0; A = A.tocsr(); A.eliminate_zeros()
+        A.sort_indices()
+        rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+        if case == "unsorted_columns":  # reverse the entries of every row: CSR order is not column order
+            for i in range(m):
+                ci[rp[i]:rp[i + 1]] = ci[rp[i]:rp[i + 1]][::-1]
+                v[rp[i]:rp[i + 1]] = v[rp[i]:rp[i + 1]][::-1]
+    x = rng.uniform(0, 1, size=n)
+    b = sparse.csr_matrix((v, ci, rp), shape=(m, n)) @ x
+    model = hprlp.Model.from_csr(m, n, rp, ci, v, b - 1, b + 1, np.zeros(n), np.full(n, 2.0), rng.normal(size=n))
+
+    def make():
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))  # raises if the builders disagree
+        info = s.info()
+        s.scale()
+        lam, _ = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        s.iterate(5, True)
+        out = (info["tiled"], s.get("x"), s.get("y"))
+        s.close()
+        return out
+
+    env = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "0.0", "HPRLP_TILING_CHECK": "1", "HPRLP_HOST_TRANSPOSE": "1"}
+    dev = with_env(env, make)
+    host = with_env({**env, "HPRLP_TILING_CHECK": "0", "HPRLP_HOST_TILING": "1"}, make)
+    assert dev[0] & 3 == 3 and host[0] & 3 == 3
+    assert np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2])
+    model.free()
