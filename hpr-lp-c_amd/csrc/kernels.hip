@@ -212,7 +212,6 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
     constexpr int TPT = T / NT;
     constexpr int NACC = Epi::NACC;
     typedef double d2_t __attribute__((ext_vector_type(2)));
-    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     __shared__ double acc[R];
     __shared__ double ytile[T];
     const TiledDev &t = A.tiled;
@@ -230,7 +229,7 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
         if (s0 < smid) {
             d2_t va, vb;
-            u4_t ix;
+            uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
             double tl[TPT];
             TileStep st = t.steps[s0];
             TileStep st_next = t.steps[min(s0 + 1, smid - 1)];
@@ -239,7 +238,11 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
                 const int ee = (e < q.e_end) ? e : q.e_begin;
                 va = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee));
                 vb = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee) + 1);
-                ix = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(t.tidx + ee));
+                typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));  // one 12-byte load per lane
+                const u3_t w = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.tidx3 + (ee / K) * 3));
+                i0 = w.x;
+                i1 = w.y;
+                i2 = w.z;
 #pragma unroll
                 for (int j = 0; j < TPT; ++j) tl[j] = vec[min(q.col0 + tid + j * NT, ncols - 1)];
             };
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
             for (int s = s0; s < smid; ++s) {
                 const TileStep cur = st;
                 const d2_t ca = va, cb = vb;
-                const u4_t cx = ix;
+                const uint32_t c0 = i0, c1 = i1, c2 = i2;
                 lds_barrier();  // every lane is done with the previous tile
 #pragma unroll
                 for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
@@ -257,14 +260,14 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
                 lds_barrier();  // tile visible
                 if (K * tid < cur.e_end - cur.e_begin) {
                     const double v[K] = {ca.x, ca.y, cb.x, cb.y};
-                    const uint32_t id[K] = {cx.x, cx.y, cx.z, cx.w};
+                    const uint32_t id[K] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
                     uint32_t rw[K];
                     double a[K], y[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        rw[k] = id[k] & 0xffffu;
+                        rw[k] = id[k] & (R - 1);
                         a[k] = acc[rw[k]];
-                        y[k] = ytile[id[k] >> 16];
+                        y[k] = ytile[id[k] >> kTileRowBits];
                     }
                     double sk[K];
                     sk[0] = a[0] + v[0] * y[0];

@@ -99,7 +99,7 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
                         ++L->pad;
                     }
                 for (size_t q = i; q < j; ++q) {
-                    L->tidx.push_back((static_cast<uint32_t>(b[q].lcol) << 16) | static_cast<uint32_t>(b[q].row));
+                    L->tidx.push_back(tile_code(b[q].lcol, b[q].row));
                     L->tperm.push_back(b[q].k);
                     ++L->dense;
                 }
@@ -257,7 +257,8 @@ void DeviceTiled::upload(const TiledHost &h) {
     view.sb_mid = sb_mid.p;
     view.steps = steps.p;
     view.tval = tval.p;
-    view.tidx = tidx.p;
+    pack_indices(nullptr);
+    view.tidx3 = tidx3.p;
     view.rval = rval.p;
     view.rcol = rcol.p;
     view.rrow = rrow.p;
@@ -289,7 +290,16 @@ void DeviceTiled::compare_with(const TiledHost &h) const {
         a_rperm.insert(a_rperm.end(), pc.rperm.begin(), pc.rperm.end());
         a_rrow.insert(a_rrow.end(), pc.rrow.begin(), pc.rrow.end());
     }
-    same("tidx", tidx, a_tidx);
+    {   // the device copy holds the packed form only
+        std::vector<uint32_t> packed(a_tidx.size() / 4 * 3);
+        for (size_t c = 0; c < a_tidx.size() / 4; ++c) {
+            const uint32_t e0 = a_tidx[4 * c], e1 = a_tidx[4 * c + 1], e2 = a_tidx[4 * c + 2], e3 = a_tidx[4 * c + 3];
+            packed[3 * c] = e0 | (e1 << 24);
+            packed[3 * c + 1] = (e1 >> 8) | (e2 << 16);
+            packed[3 * c + 2] = (e2 >> 16) | (e3 << 8);
+        }
+        same("tidx3", tidx3, packed);
+    }
     same("tperm", tperm, a_tperm);
     same("rcol", rcol, a_rcol);
     same("rperm", rperm, a_rperm);

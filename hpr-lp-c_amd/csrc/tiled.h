@@ -29,6 +29,10 @@ constexpr int kTileRemK = (kTileCols * 8 - 8) / (10 * kTileThreads);          //
 constexpr int kTileRemCap = kTileThreads * kTileRemK;                         // (scratch aliases the tile buffer)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
 static_assert(kTileRemK >= 1, "tile buffer too small for the remainder scratch");
+constexpr int kTileRowBits = 13;  // local row in an entry code
+static_assert((1 << kTileRowBits) == kTileRows && kTileCols <= (1 << (24 - kTileRowBits)) && kTileChunk == 4,
+              "entry codes are 24 bits: 13 of local row, 11 of local column, four per chunk");
+inline uint32_t tile_code(int lcol, int row) { return (static_cast<uint32_t>(lcol) << kTileRowBits) | static_cast<uint32_t>(row); }
 
 struct TileStep {
     int col0;     // first column of the tile
@@ -45,7 +49,9 @@ struct TiledDev {
     const int *sb_mid = nullptr;   // nsb: first remainder step
     const TileStep *steps = nullptr;
     const double *tval = nullptr;  // tile entries: value
-    const uint32_t *tidx = nullptr;  // local column << 16 | local row
+    // tile entries: 24-bit codes (local column << 13 | local row), four per lane chunk packed in three 32-bit words
+    // (w0 = e0 | e1 << 24, w1 = e1 >> 8 | e2 << 16, w2 = e2 >> 16 | e3 << 8): 44 instead of 48 bytes per chunk
+    const uint32_t *tidx3 = nullptr;
     const double *rval = nullptr;  // remainder entries
     const int *rcol = nullptr;
     const uint16_t *rrow = nullptr;
@@ -78,7 +84,8 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
 struct DeviceTiled {
     DBuf<int> sb_ptr, sb_mid, tperm, rperm, rcol;
     DBuf<TileStep> steps;
-    DBuf<uint32_t> tidx;
+    DBuf<uint32_t> tidx;   // one code per entry: filled by the builders, released by pack_indices()
+    DBuf<uint32_t> tidx3;  // packed codes, what the kernel reads
     DBuf<uint16_t> rrow;
     DBuf<double> tval, rval;
     TiledDev view;
@@ -86,6 +93,7 @@ struct DeviceTiled {
     long dense_entries = 0, padding = 0;
     int n_steps = 0;
     void upload(const TiledHost &h);
+    void pack_indices(hipStream_t s);  // tidx -> tidx3
     // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,
     // too scattered, or too large for 32-bit entry offsets) and nothing is valid.
     bool build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,

@@ -25,7 +25,7 @@ namespace {
 
 constexpr int R = kTileRows, T = kTileCols, K = kTileChunk;
 constexpr int kRowBits = 13;
-static_assert((1 << kRowBits) == R, "the key packs the local row in 13 bits");
+static_assert((1 << kRowBits) == R && kRowBits == kTileRowBits, "the key and the entry codes pack the local row in 13 bits");
 
 __device__ __forceinline__ int row_of_entry(const int *__restrict__ rowptr, int rows, int k) {
     int lo = 0, hi = rows;  // rowptr[lo] <= k < rowptr[hi]
@@ -98,7 +98,7 @@ __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long 
             if (PASS == 2) {
                 const int src = sperm[q];
                 tperm[out0 + len_out] = src;
-                tidx[out0 + len_out] = (static_cast<uint32_t>(col[src] - col0) << 16) | static_cast<uint32_t>(row);
+                tidx[out0 + len_out] = (static_cast<uint32_t>(col[src] - col0) << kTileRowBits) | static_cast<uint32_t>(row);
             }
             ++len_out;
         }
@@ -214,7 +214,24 @@ __global__ void __launch_bounds__(kThreads) k_rem_steps(int nsb, const int *__re
 
 inline unsigned grid_for(long n) { return static_cast<unsigned>((n + kThreads - 1) / kThreads); }
 
+__global__ void __launch_bounds__(kThreads) k_pack_codes(long nchunk, const uint32_t *__restrict__ code, uint32_t *__restrict__ packed) {
+    const long c = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (c >= nchunk) return;
+    const uint32_t e0 = code[4 * c], e1 = code[4 * c + 1], e2 = code[4 * c + 2], e3 = code[4 * c + 3];
+    packed[3 * c] = e0 | (e1 << 24);
+    packed[3 * c + 1] = (e1 >> 8) | (e2 << 16);
+    packed[3 * c + 2] = (e2 >> 16) | (e3 << 8);
+}
+
 }  // namespace
+
+void DeviceTiled::pack_indices(hipStream_t s) {
+    const long nchunk = n_tile / K;
+    tidx3.alloc_zero(static_cast<size_t>(nchunk) * 3 + 8);
+    if (nchunk > 0) hipLaunchKernelGGL(k_pack_codes, dim3(grid_for(nchunk)), dim3(kThreads), 0, s, nchunk, tidx.p, tidx3.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+    tidx.release();
+}
 
 bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
                                   double min_dense_fraction, hipStream_t s) {
@@ -364,7 +381,8 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     view.sb_mid = sb_mid.p;
     view.steps = steps.p;
     view.tval = tval.p;
-    view.tidx = tidx.p;
+    pack_indices(s);
+    view.tidx3 = tidx3.p;
     view.rval = rval.p;
     view.rcol = rcol.p;
     view.rrow = rrow.p;
