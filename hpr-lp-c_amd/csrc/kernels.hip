@@ -200,8 +200,12 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
 // accumulators (all LDS reads first, running segment sums in registers, then the writes).  The
 // barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain vmcnt
 // and expose the latency of the prefetched global loads in every step.  Super-blocks are mapped
-// XCD-aware (contiguous range per XCD) so that concurrently running workgroups share their column
-// window in one L2.  Summation order per row = CSR order (tiles ascending), remainder entries last.
+// XCD-aware (contiguous range per XCD) and the workgroups are persistent (the resident number per
+// XCD, each taking every slots-th super-block of the range), so that the workgroups of one XCD work
+// on consecutive super-blocks in step; every sweep starts at its rotation point (finish_schedule in
+// tiled_build.hip) so that they stage the same vector tile at the same time.  Summation order per
+// row: tiles ascending from the rotation point, then the tiles below it, remainder entries last --
+// fixed by the matrix, so results are reproducible run to run.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -216,14 +220,17 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
     __shared__ double ytile[T];
     const TiledDev &t = A.tiled;
     const int tid = threadIdx.x;
-    const int per = gridDim.x / 8;
-    const int sb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const int per = t.per, slots = gridDim.x / 8;  // persistent: slot, slot + slots, ... of this XCD's range
+    const int slot = blockIdx.x / 8;
     double racc[NACC > 0 ? NACC : 1];
 #pragma unroll
     for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
     epi.begin();
-    if (sb < t.nsb) {
+    for (int q = slot; q < per; q += slots) {
+        const int sb = (blockIdx.x % 8) * per + q;
+        if (sb >= t.nsb) break;
         const double *__restrict__ vec = epi.gv[0];
+        lds_barrier();  // the previous super-block's epilogue is done with acc
         const int ncols = A.cols;
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
@@ -231,8 +238,11 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
             d2_t va, vb;
             uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
             double tl[TPT];
-            TileStep st = t.steps[s0];
-            TileStep st_next = t.steps[min(s0 + 1, smid - 1)];
+            const int nst = smid - s0;
+            const int rot = t.steps[s0].rot;  // rotated sweep (tiled_build.hip, finish_schedule)
+            auto sidx = [&](int i) { i = min(i, nst - 1) + rot; return s0 + (i < nst ? i : i - nst); };
+            TileStep st = t.steps[sidx(0)];
+            TileStep st_next = t.steps[sidx(1)];
             auto issue = [&](const TileStep &q) {
                 const int e = q.e_begin + K * tid;
                 const int ee = (e < q.e_end) ? e : q.e_begin;
@@ -255,7 +265,7 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
 #pragma unroll
                 for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
                 st = st_next;
-                st_next = t.steps[min(s + 2, smid - 1)];
+                st_next = t.steps[sidx(s - s0 + 2)];
                 if (s + 1 < smid) issue(st);
                 lds_barrier();  // tile visible
                 if (K * tid < cur.e_end - cur.e_begin) {

@@ -223,6 +223,7 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
 void DeviceTiled::upload(const TiledHost &h) {
     n_tile = static_cast<long>(h.n_tile);
     n_rem = static_cast<long>(h.n_rem);
+    n_steps = static_cast<int>(h.steps.size());
     const int nsb = static_cast<int>(h.sb_mid.size());
     sb_ptr.alloc(h.sb_ptr.size()); sb_ptr.upload(h.sb_ptr.data(), h.sb_ptr.size());
     sb_mid.alloc(h.sb_mid.size()); sb_mid.upload(h.sb_mid.data(), h.sb_mid.size());
@@ -252,7 +253,6 @@ void DeviceTiled::upload(const TiledHost &h) {
     }
     view.valid = true;
     view.nsb = nsb;
-    view.grid = (nsb + 7) / 8 * 8;
     view.sb_ptr = sb_ptr.p;
     view.sb_mid = sb_mid.p;
     view.steps = steps.p;
@@ -262,6 +262,7 @@ void DeviceTiled::upload(const TiledHost &h) {
     view.rval = rval.p;
     view.rcol = rcol.p;
     view.rrow = rrow.p;
+    finish_schedule(nullptr);
 }
 
 void DeviceTiled::compare_with(const TiledHost &h) const {
@@ -279,7 +280,13 @@ void DeviceTiled::compare_with(const TiledHost &h) const {
     same("sb_ptr", sb_ptr, h.sb_ptr);
     same("sb_mid", sb_mid, h.sb_mid);
     if (static_cast<size_t>(n_steps) != h.steps.size()) fail("step count");
-    same("steps", steps, h.steps);
+    {  // the steps without the rotation offsets, which finish_schedule() adds on the device for either builder
+        std::vector<TileStep> dev(h.steps.size());
+        if (!dev.empty()) HIP_CHECK(hipMemcpy(dev.data(), steps.p, dev.size() * sizeof(TileStep), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < dev.size(); ++i)
+            if (dev[i].col0 != h.steps[i].col0 || dev[i].e_begin != h.steps[i].e_begin || dev[i].e_end != h.steps[i].e_end)
+                fail("steps differ at " + std::to_string(i));
+    }
     std::vector<uint32_t> a_tidx;
     std::vector<int> a_tperm, a_rcol, a_rperm;
     std::vector<uint16_t> a_rrow;

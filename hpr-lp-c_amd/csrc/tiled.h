@@ -34,17 +34,20 @@ static_assert((1 << kTileRowBits) == kTileRows && kTileCols <= (1 << (24 - kTile
               "entry codes are 24 bits: 13 of local row, 11 of local column, four per chunk");
 inline uint32_t tile_code(int lcol, int row) { return (static_cast<uint32_t>(lcol) << kTileRowBits) | static_cast<uint32_t>(row); }
 
+constexpr int kTileResidentPerCu = 2;  // 80 KiB of LDS per workgroup, 160 KiB per CU
+
 struct TileStep {
     int col0;     // first column of the tile
     int e_begin;  // entry range in tval/tidx (tile step) or rval/rcol/rrow (remainder step)
     int e_end;
-    int pad;
+    int rot;      // first step of a super-block: offset of the step its rotated sweep starts with (finish_schedule)
 };
 
 struct TiledDev {
     bool valid = false;
     int nsb = 0;               // super-blocks
-    int grid = 0;              // nsb rounded up to a multiple of 8 (XCD-aware mapping)
+    int per = 0;               // super-blocks per XCD: nsb rounded up to a multiple of 8, / 8
+    int grid = 0;              // launch grid: 8 * min(per, resident workgroups of one XCD)
     const int *sb_ptr = nullptr;   // nsb+1: steps of a super-block
     const int *sb_mid = nullptr;   // nsb: first remainder step
     const TileStep *steps = nullptr;
@@ -94,6 +97,10 @@ struct DeviceTiled {
     int n_steps = 0;
     void upload(const TiledHost &h);
     void pack_indices(hipStream_t s);  // tidx -> tidx3
+    // launch shape (persistent workgroups per XCD) and the rotation of every super-block's sweep; rot_period is the
+    // alignment period in tiles (0 = no rotation)
+    void finish_schedule(hipStream_t s);
+    int rot_period = 0;
     // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,
     // too scattered, or too large for 32-bit entry offsets) and nothing is valid.
     bool build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,

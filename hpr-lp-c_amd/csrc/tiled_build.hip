@@ -11,6 +11,8 @@
 // size the padded list (or to flag a sparse run / long segments for the remainder) and, after an exclusive scan
 // of the sizes, a second time to write tidx / tperm / the steps; remainder entries are the flagged entries in
 // original order [hipCUB select]; the per-super-block step tables (1221 entries on config 5) are finished on the host.
+#include <algorithm>
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include <vector>
@@ -233,6 +235,73 @@ void DeviceTiled::pack_indices(hipStream_t s) {
     tidx.release();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Launch schedule.  The kernel runs min(per, resident) persistent workgroups per XCD; workgroup `slot` of an XCD
+// takes that XCD's super-blocks slot, slot + slots, ...: the workgroups of one XCD work on `slots` consecutive
+// super-blocks at any time (a cohort).  Neighbouring super-blocks read almost the same vector tiles, but a sweep
+// that starts at each window's own first tile reads them 4 steps apart, and the matrix stream has flushed the
+// 4 MiB L2 by then.  Rotation: every super-block starts its sweep at the first tile whose index is a multiple of
+// rot_period (wrapping around to its window's first tiles at the end), so that the workgroups of a cohort read
+// the SAME tile in the same step and one of them pays the miss.  rot_period = mean window width in tiles.
+// The rotation is a fixed property of the matrix: results are reproducible, the per-row summation order is
+// "tiles from the rotation point upwards, then the tiles below it, then the remainder entries".
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(kThreads) k_window_widths(int nsb, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
+                                                           const TileStep *__restrict__ steps, unsigned long long *__restrict__ out) {
+    const int sb = blockIdx.x * kThreads + threadIdx.x;
+    if (sb >= nsb) return;
+    const int s0 = sb_ptr[sb], smid = sb_mid[sb];
+    if (s0 >= smid) return;
+    const int w = (steps[smid - 1].col0 - steps[s0].col0) / T + 1;
+    atomicAdd(out, static_cast<unsigned long long>(w));  // integer sums: order-independent
+    atomicAdd(out + 1, 1ull);
+}
+
+__global__ void __launch_bounds__(kThreads) k_rotation(int nsb, int period, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
+                                                      TileStep *__restrict__ steps) {
+    const int sb = blockIdx.x * kThreads + threadIdx.x;
+    if (sb >= nsb) return;
+    const int s0 = sb_ptr[sb], smid = sb_mid[sb];
+    if (s0 >= smid) return;
+    const int nst = smid - s0;
+    const int w0 = steps[s0].col0 / T;
+    const long target = static_cast<long>((w0 + period - 1) / period) * period * T;
+    int lo = 0, hi = nst;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (steps[s0 + mid].col0 < target) lo = mid + 1; else hi = mid;
+    }
+    steps[s0].rot = lo < nst ? lo : 0;
+}
+
+}  // namespace
+
+void DeviceTiled::finish_schedule(hipStream_t s) {
+    const int nsb = view.nsb;
+    int dev = 0, cus = 256;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int resident = std::max(1, cus / 8) * kTileResidentPerCu;
+    view.per = (nsb + 7) / 8;
+    view.grid = 8 * std::min(view.per, resident);
+    rot_period = 0;
+    if (nsb <= 0 || n_steps <= 0) return;
+    if (const char *e = std::getenv("HPRLP_TILE_ROT")) rot_period = std::atoi(e);
+    else {
+        DBuf<unsigned long long> acc(2);
+        HIP_CHECK(hipMemsetAsync(acc.p, 0, 2 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_window_widths, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, acc.p);
+        unsigned long long h[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (h[1] > 0) rot_period = static_cast<int>((h[0] + h[1] - 1) / h[1]);
+    }
+    if (rot_period > 0) hipLaunchKernelGGL(k_rotation, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, rot_period, sb_ptr.p, sb_mid.p, steps.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
 bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
                                   double min_dense_fraction, hipStream_t s) {
     if (rows < min_rows || rows <= 0 || cols <= 0 || nnz <= 0 || nnz >= 2000000000L) return false;
@@ -376,7 +445,6 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     view = TiledDev();
     view.valid = true;
     view.nsb = nsb;
-    view.grid = (nsb + 7) / 8 * 8;
     view.sb_ptr = sb_ptr.p;
     view.sb_mid = sb_mid.p;
     view.steps = steps.p;
@@ -386,6 +454,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     view.rval = rval.p;
     view.rcol = rcol.p;
     view.rrow = rrow.p;
+    finish_schedule(s);
     return true;
 }
 
