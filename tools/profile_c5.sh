@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collects, on the GPU box, what profiles/ holds for config 5: the rocprofv3 kernel-trace statistics of the bench command and the
+# FETCH_SIZE / WRITE_SIZE counters in separate passes (gpurun refuses counter passes combined with other trace domains).
+# usage (from the repo root, inside one gpurun call):  bash tools/profile_c5.sh v7   ->  gpurun_out/prof_v7/
+set -e
+tag=${1:-run}
+out=$PWD/gpurun_out/prof_$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --no-cpu --no-side --no-solve --steps 100 --warmup 20 > "$out/bench_line.json" 2> /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 bench.py --no-cpu --no-side --no-solve --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 bench.py --no-cpu --no-side --no-solve --steps 20 --warmup 5 > /dev/null 2>&1
+cp "$out"/trace/*/*kernel_stats.csv "$out/kernel_stats.csv"
+python3 - "$out" <<'PY'
+import csv, glob, collections, sys, json
+out = sys.argv[1]
+res = {}
+for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == ctr:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    with open(f"{out}/pmc_{name}.csv", "w") as g:
+        g.write("Kernel_Name,Launches,Mean_%s_KB\n" % ctr)
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            g.write('"%s",%d,%.1f\n' % (k, len(v), sum(v) / len(v)))
+            if "k_tiled_fused" in k or "k_spmv_fused" in k:
+                res.setdefault(k.split("(")[0].replace("void hprlp::", ""), {})[ctr] = sum(v) / len(v)
+for k, d in res.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["bytes_per_launch"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+json.dump(res, open(f"{out}/pmc_traffic_per_kernel.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+rm -rf "$out/trace" "$out/fetch" "$out/write"
