@@ -135,6 +135,7 @@ struct Solver {
     void solve_loop(HPRLP_results *out);                            // src/HPRLP.cu:154-310
     void collect_solution(HPRLP_results *out);                      // src/utils.cu:143-200
     double reduce_sum_sq(const double *v, int n_local);             // allreduced ||v||^2
+    void verify_exchange();                                         // set-up self-test of the exchange (multi-GPU only)
     void gather(double *gbuf, bool is_m);                           // all-gather a length-m or length-n vector
     void allreduce_scalars();
     void finish_tiling();  // adopt tiled copies whose background build is still pending (no-op otherwise)

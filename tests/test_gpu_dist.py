@@ -161,3 +161,23 @@ def test_sharded_solver_with_tiled_kernels_on_the_shards(gpu):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_failed_exchange_self_test_falls_back_to_the_all_gather(gpu):
+    """Set-up self-test of the exchange (Solver::verify_exchange): a neighbour exchange reported as failed is replaced
+    by the all-gather on every rank and the solve goes on to the single-GPU answer."""
+    import os
+    import bench_helpers as bh
+    os.environ["HPRLP_DIST_SELFTEST_FAIL"] = "1"
+    try:
+        m = n = 6001
+        lp = bh.banded_lp(m, n, 8, 150)
+        model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+        ref = single(model, prm, 23)
+        ranks = run_ranks(model, prm, 2, 23)
+        assert all(o["info"]["m_sparse"] == 0 and o["info"]["n_sparse"] == 0 for o in ranks)
+        check_against_single(ref, ranks, m, n, lp["obj_star"])
+        model.free()
+    finally:
+        del os.environ["HPRLP_DIST_SELFTEST_FAIL"]
