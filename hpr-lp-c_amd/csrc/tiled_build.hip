@@ -26,7 +26,7 @@ namespace hprlp {
 namespace {
 
 constexpr int R = kTileRows, T = kTileCols, K = kTileChunk;
-constexpr int kRowBits = 13;
+constexpr int kRowBits = kTileRowBits;
 static_assert((1 << kRowBits) == R && kRowBits == kTileRowBits, "the key and the entry codes pack the local row in 13 bits");
 
 __device__ __forceinline__ int row_of_entry(const int *__restrict__ rowptr, int rows, int k) {

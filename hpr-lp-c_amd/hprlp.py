@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_ROOT, "lib", "libhprlp.so")
+LIB_PATH = os.environ.get("HPRLP_LIB") or os.path.join(_ROOT, "lib", "libhprlp.so")  # HPRLP_LIB: developer builds (kernel shape variants)
 
 c_int_p = C.POINTER(C.c_int)
 c_dbl_p = C.POINTER(C.c_double)
