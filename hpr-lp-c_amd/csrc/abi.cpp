@@ -514,18 +514,9 @@ extern "C" int hprlp_solver_time_iterations(hprlp_solver *h, int warmup, int ste
     } else {
         std::vector<hipEvent_t> ev(static_cast<size_t>(steps) * 3);
         for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
-        XHalfArgs xa{s.gy.p, s.x.p, s.x_hat, s.l.p, s.u.p, s.c.p, s.last_x.p, nullptr, nullptr, nullptr, s.ctrl.p, nullptr, 0};
-        YHalfArgs ya{s.gxh.p, s.y, s.AL.p, s.AU.p, s.last_y.p, nullptr, nullptr, nullptr, s.ctrl.p, nullptr, 0};
+        // the solver's own normal pair (with the multi-GPU overlap when it is on): events before / between / after the halves
         HIP_CHECK(hipEventRecord(e0, s.stream));
-        for (int i = 0; i < steps; ++i) {
-            HIP_CHECK(hipEventRecord(ev[3 * i], s.stream));
-            launch_x_half(s.AT.view, xa, false, s.stream);
-            HIP_CHECK(hipEventRecord(ev[3 * i + 1], s.stream));
-            s.gather(s.gxh.p, false);
-            launch_y_half(s.A.view, ya, false, s.stream);
-            HIP_CHECK(hipEventRecord(ev[3 * i + 2], s.stream));
-            s.gather(s.gy.p, true);
-        }
+        for (int i = 0; i < steps; ++i) s.launch_normal_pair(i + 1 < steps, &ev[3 * static_cast<size_t>(i)]);
         HIP_CHECK(hipEventRecord(e1, s.stream));
         HIP_CHECK(hipEventSynchronize(e1));
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));

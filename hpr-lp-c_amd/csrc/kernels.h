@@ -105,6 +105,9 @@ struct FinalizeArgs {
 
 void launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s);
 void launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s);
+// normal half-steps over the remote-column part of a split matrix; base = row sums of the local-column part
+void launch_x_half_base(const CsrDev &AT_remote, const XHalfArgs &a, const double *base, hipStream_t s);
+void launch_y_half_base(const CsrDev &A_remote, const YHalfArgs &a, const double *base, hipStream_t s);
 
 // |(c - AT y_bar - z_bar) .* col_norm|^2 partials (reference residual_compute_Rd, main_iterate.cu:217-226)
 void launch_resid_d(const CsrDev &AT, const double *ybar_full, const double *c, const double *z_bar,
@@ -178,6 +181,11 @@ void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s);
 // trp has cols+1 entries, tci / tv nnz
 void device_transpose(int rows, int cols, long nnz, const int *rowptr, const int *col, const double *val, int *trp,
                       int *tci, double *tv, hipStream_t s);
+
+// column split of a device CSR matrix into the entries with lo <= column < hi and the rest (transpose.hip)
+void device_split_columns(int rows, long nnz, const int *rowptr, const int *col, const double *val, int lo, int hi, DBuf<int> &rp_loc,
+                          DBuf<int> &col_loc, DBuf<double> &val_loc, DBuf<int> &rp_rem, DBuf<int> &col_rem, DBuf<double> &val_rem,
+                          hipStream_t s);
 
 // multi-GPU neighbour exchange: dst[k] = src[idx[k]] before the sends, dst[idx[k]] = src[k] after the receives
 void launch_pack(const double *src, const int *idx, double *dst, int n, hipStream_t s);

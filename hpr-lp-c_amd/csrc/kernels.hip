@@ -613,6 +613,33 @@ void launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t 
     }
 }
 
+// Second kernel of a half-step whose matrix was split by columns (multi-GPU overlap): `base[r]` is the row sum over
+// the local-column part, computed while the exchange was in flight; this launch adds the remote-column part and runs
+// the epilogue.  Summation order per row: local entries (CSR order), then remote entries (CSR order).
+template <class Epi>
+struct WithBase : Epi {
+    const double *base;
+    struct Row {
+        typename Epi::Row w;
+        double b;
+    };
+    __device__ __forceinline__ Row load_row(int r) const { return Row{Epi::load_row(r), base[r]}; }
+    __device__ __forceinline__ void apply(int r, const Row &w, const double (&s)[1], double (&acc)[Epi::NACC > 0 ? Epi::NACC : 1]) const {
+        const double t[1] = {w.b + s[0]};
+        Epi::apply(r, w.w, t, acc);
+    }
+};
+
+void launch_x_half_base(const CsrDev &AT_remote, const XHalfArgs &a, const double *base, hipStream_t s) {
+    WithBase<XEpi<false>> e{{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0}, base};
+    launch_fused(AT_remote, e, s);
+}
+
+void launch_y_half_base(const CsrDev &A_remote, const YHalfArgs &a, const double *base, hipStream_t s) {
+    WithBase<YEpi<false>> e{{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0}, base};
+    launch_fused(A_remote, e, s);
+}
+
 void launch_resid_d(const CsrDev &AT, const double *ybar_full, const double *c, const double *z_bar,
                     const double *col_norm, double *partials, hipStream_t s) {
     RdEpi e{{ybar_full}, c, z_bar, col_norm, partials, AT.grid()};

@@ -201,6 +201,10 @@ void DeviceMatrix::refresh_tiled(hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 Solver::~Solver() {
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    if (ev_ready) (void)hipEventDestroy(ev_ready);
+    if (ev_done_x) (void)hipEventDestroy(ev_done_x);
+    if (ev_done_y) (void)hipEventDestroy(ev_done_y);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -224,6 +228,8 @@ void Solver::alloc_work() {
     part_v.alloc_zero(static_cast<size_t>(2) * kReduceBlocks);
     const char *ng = std::getenv("HPRLP_NO_GRAPH");
     use_graph = !(ng && ng[0] == '1') && comm == nullptr;
+    const char *no = std::getenv("HPRLP_NO_OVERLAP");
+    overlap_enabled = comm != nullptr && comm->size > 1 && !(no && no[0] == '1');
 }
 
 void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
@@ -438,17 +444,17 @@ void HaloPlan::build(Comm *comm, const int *cols, long nnz, int total, int chunk
     }
 }
 
-void Solver::gather(double *gbuf, bool is_m) {
+void Solver::gather_on(double *gbuf, bool is_m, hipStream_t s) {
     if (!comm) return;  // (a one-rank communicator still runs the collective: used to test the RCCL path)
     HaloPlan &h = is_m ? halo_m : halo_n;
     if (!h.sparse) {
         const size_t chunk = static_cast<size_t>(is_m ? m_pad : n_pad) / comm->size;
-        comm->allgather_inplace(gbuf, chunk, stream);
+        comm->allgather_inplace(gbuf, chunk, s);
         return;
     }
-    launch_pack(gbuf, h.send_idx.p, h.sendbuf.p, h.nsend, stream);
-    comm->exchange(h.ops.data(), static_cast<int>(h.ops.size()), stream);
-    launch_scatter(gbuf, h.recv_idx.p, h.recvbuf.p, h.nrecv, stream);
+    launch_pack(gbuf, h.send_idx.p, h.sendbuf.p, h.nsend, s);
+    comm->exchange(h.ops.data(), static_cast<int>(h.ops.size()), s);
+    launch_scatter(gbuf, h.recv_idx.p, h.recvbuf.p, h.nrecv, s);
 }
 
 // One exchange of a vector whose entry j is j + 1 on its owner and -1 elsewhere: every entry this shard reads must
@@ -535,6 +541,9 @@ static double bnorm_sq(Solver *s) {
 // ------------------------------------------------------------------------------------------------
 void Solver::scale() {
     const auto t0 = time_now();
+    overlap_ready = false;  // the split copies of the shards carry matrix values
+    ovA.reset();
+    ovAT.reset();
     double *t1 = gsm.p + row_off, *t2 = gsn.p + col_off;
     launch_fill(row_norm.p, 1.0, m_loc, stream);
     launch_fill(col_norm.p, 1.0, n_loc, stream);
@@ -683,13 +692,78 @@ void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
     set_sigma_lambda(s0, lambda_max, true);
 }
 
-void Solver::launch_normal_pair() {
+// Column split of one shard on the device: local = entries whose column lies in [lo, hi).
+static void split_shard(const DeviceMatrix &M, int lo, int hi, Solver::SplitShard *out, hipStream_t s) {
+    const int rows = M.view.rows, cols = M.view.cols;
+    device_split_columns(rows, M.view.nnz, M.rowptr.p, M.col.p, M.val.p, lo, hi, out->loc.rowptr, out->loc.col, out->loc.val,
+                         out->rem.rowptr, out->rem.col, out->rem.val, s);
+    std::vector<int> rp(static_cast<size_t>(rows) + 1);
+    out->loc.rowptr.download(rp.data(), rp.size());
+    out->loc.describe(rows, cols, rp.data(), nullptr, nullptr);
+    out->rem.rowptr.download(rp.data(), rp.size());
+    out->rem.describe(rows, cols, rp.data(), nullptr, nullptr);
+    out->loc.finish_tiling(s);
+    out->rem.finish_tiling(s);
+    out->part.alloc_zero(static_cast<size_t>(std::max(rows, 1)));
+}
+
+void Solver::prepare_overlap() {
+    finish_tiling();
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (!comm_stream) {
+        HIP_CHECK(hipStreamCreate(&comm_stream));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_done_x, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_done_y, hipEventDisableTiming));
+    }
+    ovAT.reset(new SplitShard);  // A^T shard: n_loc rows, columns = rows of A; this rank owns y[row_off, row_off + m_loc)
+    split_shard(AT, row_off, row_off + m_loc, ovAT.get(), stream);
+    ovA.reset(new SplitShard);   // A shard: m_loc rows; this rank owns x_hat[col_off, col_off + n_loc)
+    split_shard(A, col_off, col_off + n_loc, ovA.get(), stream);
+    HIP_CHECK(hipDeviceSynchronize());
+    overlap_ready = true;
+}
+
+void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev) {
     XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
-    launch_x_half(AT.view, xa, false, stream);
-    gather(gxh.p, false);
     YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
-    launch_y_half(A.view, ya, false, stream);
-    gather(gy.p, true);
+    if (ev) HIP_CHECK(hipEventRecord(ev[0], stream));
+    if (!overlap_enabled) {
+        launch_x_half(AT.view, xa, false, stream);
+        if (ev) HIP_CHECK(hipEventRecord(ev[1], stream));
+        gather(gxh.p, false);
+        launch_y_half(A.view, ya, false, stream);
+        if (ev) HIP_CHECK(hipEventRecord(ev[2], stream));
+        gather(gy.p, true);
+        return;
+    }
+    if (!overlap_ready) prepare_overlap();
+    // ---- x-half: if the exchange of y is still in flight, the local-column part runs beside it
+    if (y_exchange_pending) {
+        launch_spmv_plain(ovAT->loc.view, gy.p, ovAT->part.p, nullptr, false, nullptr, 0, stream);
+        HIP_CHECK(hipStreamWaitEvent(stream, ev_done_y, 0));
+        launch_x_half_base(ovAT->rem.view, xa, ovAT->part.p, stream);
+        y_exchange_pending = false;
+    } else {
+        launch_x_half(AT.view, xa, false, stream);  // gathered y complete: the unsplit shard in one launch
+    }
+    if (ev) HIP_CHECK(hipEventRecord(ev[1], stream));
+    // ---- exchange of x_hat on comm_stream beside the local-column part of the y-half
+    HIP_CHECK(hipEventRecord(ev_ready, stream));
+    launch_spmv_plain(ovA->loc.view, gxh.p, ovA->part.p, nullptr, false, nullptr, 0, stream);
+    HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+    gather_on(gxh.p, false, comm_stream);
+    HIP_CHECK(hipEventRecord(ev_done_x, comm_stream));
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_done_x, 0));
+    launch_y_half_base(ovA->rem.view, ya, ovA->part.p, stream);
+    if (ev) HIP_CHECK(hipEventRecord(ev[2], stream));
+    // ---- exchange of y: left in flight for the next pair, or waited for
+    HIP_CHECK(hipEventRecord(ev_ready, stream));
+    HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+    gather_on(gy.p, true, comm_stream);
+    HIP_CHECK(hipEventRecord(ev_done_y, comm_stream));
+    if (more_follow) y_exchange_pending = true;
+    else HIP_CHECK(hipStreamWaitEvent(stream, ev_done_y, 0));
 }
 
 void Solver::step(bool check) {
@@ -740,7 +814,7 @@ void Solver::run_normal(int count) {
         return;
     }
     if (!use_graph) {
-        for (int i = 0; i < count; ++i) launch_normal_pair();
+        for (int i = 0; i < count; ++i) launch_normal_pair(i + 1 < count);
         return;
     }
     while (count > 0) {

@@ -136,14 +136,33 @@ struct Solver {
     void collect_solution(HPRLP_results *out);                      // src/utils.cu:143-200
     double reduce_sum_sq(const double *v, int n_local);             // allreduced ||v||^2
     void verify_exchange();                                         // set-up self-test of the exchange (multi-GPU only)
-    void gather(double *gbuf, bool is_m);                           // all-gather a length-m or length-n vector
+    void gather(double *gbuf, bool is_m) { gather_on(gbuf, is_m, stream); }  // all-gather a length-m or length-n vector
+    void gather_on(double *gbuf, bool is_m, hipStream_t s);
+
+    // Multi-GPU overlap of the exchange with the local part of the next half-step: both shards are split
+    // by columns into the part that reads this rank's own slice of the gathered vector and the part that reads remote
+    // entries.  While the exchange runs on comm_stream, the local part's row sums go to `part`; the remote part's
+    // kernel adds them and runs the epilogue.  Built after scaling (the copies carry the scaled values).
+    struct SplitShard {
+        DeviceMatrix loc, rem;
+        DBuf<double> part;
+    };
+    std::unique_ptr<SplitShard> ovA, ovAT;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done_x = nullptr, ev_done_y = nullptr;
+    bool overlap_enabled = false, overlap_ready = false, y_exchange_pending = false;
+    void prepare_overlap();
     void allreduce_scalars();
     void finish_tiling();  // adopt tiled copies whose background build is still pending (no-op otherwise)
+
+    // One normal iteration.  ev (optional, 3 events): recorded before the x-half, between the halves, after the y-half.
+    // more_follow (multi-GPU overlap only): the caller launches another normal pair next, so the exchange of y may stay
+    // in flight behind the local part of that pair's x-half; otherwise the gathered y is complete on return.
+    void launch_normal_pair(bool more_follow = false, hipEvent_t *ev = nullptr);
 
    private:
     void alloc_work();
     hipGraphExec_t graph_for(int len);
-    void launch_normal_pair();
 };
 
 }  // namespace hprlp

@@ -79,4 +79,69 @@ void device_transpose(int rows, int cols, long nnz, const int *rowptr, const int
     HIP_CHECK(hipStreamSynchronize(s));  // the temporaries are released on return
 }
 
+// ------------------------------------------------------------------------------------------------
+// Column split of a device CSR matrix (multi-GPU overlap, solver.cpp prepare_overlap): the entries whose column lies
+// in [lo, hi) -- the part of the gathered vector this rank owns -- go to one CSR matrix, the others to a second one;
+// both keep all rows and the CSR order inside a row.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(kThreads) k_count_local(int rows, const int *__restrict__ rowptr, const int *__restrict__ col, int lo,
+                                                         int hi, int *__restrict__ cnt) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r > rows) return;
+    int c = 0;
+    if (r < rows)
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += (col[k] >= lo && col[k] < hi);
+    cnt[r] = c;  // cnt[rows] = 0: the scan's last element is the total
+}
+
+__global__ void __launch_bounds__(kThreads) k_split_rows(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                        const double *__restrict__ val, int lo, int hi, const int *__restrict__ rp_loc,
+                                                        int *__restrict__ rp_rem, int *__restrict__ col_loc, double *__restrict__ val_loc,
+                                                        int *__restrict__ col_rem, double *__restrict__ val_rem) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r > rows) return;
+    int a = rp_loc[r], b = rowptr[r] - a;
+    rp_rem[r] = b;
+    if (r == rows) return;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int c = col[k];
+        if (c >= lo && c < hi) {
+            col_loc[a] = c;
+            val_loc[a++] = val[k];
+        } else {
+            col_rem[b] = c;
+            val_rem[b++] = val[k];
+        }
+    }
+}
+
+}  // namespace
+
+void device_split_columns(int rows, long nnz, const int *rowptr, const int *col, const double *val, int lo, int hi, DBuf<int> &rp_loc,
+                          DBuf<int> &col_loc, DBuf<double> &val_loc, DBuf<int> &rp_rem, DBuf<int> &col_rem, DBuf<double> &val_rem,
+                          hipStream_t s) {
+    const unsigned grid = static_cast<unsigned>((static_cast<long>(rows) + 1 + kThreads - 1) / kThreads);
+    DBuf<int> cnt(static_cast<size_t>(rows) + 1);
+    rp_loc.alloc(static_cast<size_t>(rows) + 1);
+    rp_rem.alloc(static_cast<size_t>(rows) + 1);
+    hipLaunchKernelGGL(k_count_local, dim3(grid), dim3(kThreads), 0, s, rows, rowptr, col, lo, hi, cnt.p);
+    size_t tmp_bytes = 0;
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt.p, rp_loc.p, rows + 1, s));
+    DBuf<char> tmp(tmp_bytes);
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, cnt.p, rp_loc.p, rows + 1, s));
+    int n_loc = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_loc, rp_loc.p + rows, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    const long n_rem = nnz - n_loc;
+    col_loc.alloc(static_cast<size_t>(n_loc));
+    val_loc.alloc(static_cast<size_t>(n_loc));
+    col_rem.alloc(static_cast<size_t>(n_rem));
+    val_rem.alloc(static_cast<size_t>(n_rem));
+    hipLaunchKernelGGL(k_split_rows, dim3(grid), dim3(kThreads), 0, s, rows, rowptr, col, val, lo, hi, rp_loc.p, rp_rem.p, col_loc.p,
+                       val_loc.p, col_rem.p, val_rem.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
 }  // namespace hprlp

@@ -181,3 +181,22 @@ def test_failed_exchange_self_test_falls_back_to_the_all_gather(gpu):
         model.free()
     finally:
         del os.environ["HPRLP_DIST_SELFTEST_FAIL"]
+
+
+def test_sharded_solver_without_the_exchange_overlap(gpu):
+    """HPRLP_NO_OVERLAP=1: the unsplit shards with the exchange in line on the solver stream (the default splits every
+    shard by columns and runs the exchange beside the local-column part; every other test here covers that)."""
+    import os
+    import bench_helpers as bh
+    os.environ["HPRLP_NO_OVERLAP"] = "1"
+    try:
+        m = n = 6001
+        lp = bh.banded_lp(m, n, 8, 150)
+        model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+        ref = single(model, prm, 23)
+        ranks = run_ranks(model, prm, 2, 23)
+        check_against_single(ref, ranks, m, n, lp["obj_star"])
+        model.free()
+    finally:
+        del os.environ["HPRLP_NO_OVERLAP"]
