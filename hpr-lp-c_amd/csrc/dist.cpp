@@ -133,6 +133,7 @@ struct LocalGroup {
 namespace {
 struct LocalComm : Comm {
     LocalGroup *g = nullptr;
+    bool host_blocking() const override { return true; }
     void allgather_inplace(double *buf, size_t chunk, hipStream_t s) override {
         HIP_CHECK(hipStreamSynchronize(s));
         g->bufs[rank] = buf;

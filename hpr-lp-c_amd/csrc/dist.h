@@ -30,6 +30,8 @@ struct Comm {
     virtual void allreduce_sum(double *buf, int count, hipStream_t s) = 0;
     // all sends and receives of the list progress together; rank a's send to b pairs with b's receive from a
     virtual void exchange(const P2P *ops, int nops, hipStream_t s) = 0;
+    // true if the calls above block the host until the data has moved (the in-process group); RCCL only enqueues
+    virtual bool host_blocking() const { return false; }
 };
 
 // RCCL implementation; librccl.so is loaded at run time on first use so that a single-GPU process

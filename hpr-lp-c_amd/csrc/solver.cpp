@@ -230,6 +230,8 @@ void Solver::alloc_work() {
     use_graph = !(ng && ng[0] == '1') && comm == nullptr;
     const char *no = std::getenv("HPRLP_NO_OVERLAP");
     overlap_enabled = comm != nullptr && comm->size > 1 && !(no && no[0] == '1');
+    // HPRLP_OVERLAP_COMM_FIRST=1 (tests): take RCCL's launch order with the in-process group too
+    overlap_spmv_first = comm != nullptr && comm->host_blocking() && !std::getenv("HPRLP_OVERLAP_COMM_FIRST");
 }
 
 void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
@@ -688,6 +690,7 @@ void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
 
 void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
     finish_tiling();
+    if (overlap_enabled && !overlap_ready) prepare_overlap();  // set-up work, not part of the first iteration
     const double s0 = (norm_b > 1e-8 && norm_c > 1e-8) ? norm_b / norm_c : 1.0;
     set_sigma_lambda(s0, lambda_max, true);
 }
@@ -705,13 +708,20 @@ static void split_shard(const DeviceMatrix &M, int lo, int hi, Solver::SplitShar
     out->loc.finish_tiling(s);
     out->rem.finish_tiling(s);
     out->part.alloc_zero(static_cast<size_t>(std::max(rows, 1)));
+    // The local part runs BESIDE the exchange's kernels.  The persistent schedule of the tiled kernel assumes that all
+    // of its workgroups are resident; a CU that also hosts a workgroup of the exchange would leave one of them waiting
+    // for a whole cohort list.  One workgroup per super-block (dispatched as slots free up) has no such tail.
+    if (out->loc.view.tiled.valid) out->loc.view.tiled.grid = 8 * out->loc.view.tiled.per;
 }
 
 void Solver::prepare_overlap() {
     finish_tiling();
     HIP_CHECK(hipStreamSynchronize(stream));
     if (!comm_stream) {
-        HIP_CHECK(hipStreamCreate(&comm_stream));
+        // highest priority: the few workgroups of the exchange must not queue behind the half-step's grid
+        int prio_low = 0, prio_high = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIP_CHECK(hipStreamCreateWithPriority(&comm_stream, hipStreamDefault, prio_high));
         HIP_CHECK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_done_x, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_done_y, hipEventDisableTiming));
@@ -738,9 +748,22 @@ void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev) {
         return;
     }
     if (!overlap_ready) prepare_overlap();
+    // Exchange on comm_stream behind ev_ready, beside the local-column SpMV on the solver stream.  RCCL only enqueues,
+    // so the exchange goes first and its workgroups are placed before the SpMV's grid fills the chip; the in-process
+    // group blocks the host inside the exchange, so there the SpMV is launched first to run beside it.
+    auto exchange_beside = [&](double *gbuf, bool is_m, hipEvent_t done, const CsrDev *local, double *part) {
+        HIP_CHECK(hipEventRecord(ev_ready, stream));
+        const bool spmv_first = overlap_spmv_first;
+        if (local && spmv_first) launch_spmv_plain(*local, gbuf, part, nullptr, false, nullptr, 0, stream);
+        HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+        gather_on(gbuf, is_m, comm_stream);
+        HIP_CHECK(hipEventRecord(done, comm_stream));
+        if (local && !spmv_first) launch_spmv_plain(*local, gbuf, part, nullptr, false, nullptr, 0, stream);
+    };
     // ---- x-half: if the exchange of y is still in flight, the local-column part runs beside it
     if (y_exchange_pending) {
-        launch_spmv_plain(ovAT->loc.view, gy.p, ovAT->part.p, nullptr, false, nullptr, 0, stream);
+        if (!overlap_spmv_first)  // (the in-process group launched it before its blocking exchange, below)
+            launch_spmv_plain(ovAT->loc.view, gy.p, ovAT->part.p, nullptr, false, nullptr, 0, stream);
         HIP_CHECK(hipStreamWaitEvent(stream, ev_done_y, 0));
         launch_x_half_base(ovAT->rem.view, xa, ovAT->part.p, stream);
         y_exchange_pending = false;
@@ -748,20 +771,13 @@ void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev) {
         launch_x_half(AT.view, xa, false, stream);  // gathered y complete: the unsplit shard in one launch
     }
     if (ev) HIP_CHECK(hipEventRecord(ev[1], stream));
-    // ---- exchange of x_hat on comm_stream beside the local-column part of the y-half
-    HIP_CHECK(hipEventRecord(ev_ready, stream));
-    launch_spmv_plain(ovA->loc.view, gxh.p, ovA->part.p, nullptr, false, nullptr, 0, stream);
-    HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
-    gather_on(gxh.p, false, comm_stream);
-    HIP_CHECK(hipEventRecord(ev_done_x, comm_stream));
+    // ---- exchange of x_hat beside the local-column part of the y-half
+    exchange_beside(gxh.p, false, ev_done_x, &ovA->loc.view, ovA->part.p);
     HIP_CHECK(hipStreamWaitEvent(stream, ev_done_x, 0));
     launch_y_half_base(ovA->rem.view, ya, ovA->part.p, stream);
     if (ev) HIP_CHECK(hipEventRecord(ev[2], stream));
-    // ---- exchange of y: left in flight for the next pair, or waited for
-    HIP_CHECK(hipEventRecord(ev_ready, stream));
-    HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
-    gather_on(gy.p, true, comm_stream);
-    HIP_CHECK(hipEventRecord(ev_done_y, comm_stream));
+    // ---- exchange of y: beside the local-column part of the next pair's x-half, or waited for
+    exchange_beside(gy.p, true, ev_done_y, more_follow && overlap_spmv_first ? &ovAT->loc.view : nullptr, ovAT->part.p);
     if (more_follow) y_exchange_pending = true;
     else HIP_CHECK(hipStreamWaitEvent(stream, ev_done_y, 0));
 }

@@ -151,6 +151,7 @@ struct Solver {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done_x = nullptr, ev_done_y = nullptr;
     bool overlap_enabled = false, overlap_ready = false, y_exchange_pending = false;
+    bool overlap_spmv_first = false;  // launch order of the local SpMV and the exchange (launch_normal_pair)
     void prepare_overlap();
     void allreduce_scalars();
     void finish_tiling();  // adopt tiled copies whose background build is still pending (no-op otherwise)

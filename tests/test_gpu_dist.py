@@ -183,12 +183,14 @@ def test_failed_exchange_self_test_falls_back_to_the_all_gather(gpu):
         del os.environ["HPRLP_DIST_SELFTEST_FAIL"]
 
 
-def test_sharded_solver_without_the_exchange_overlap(gpu):
+@pytest.mark.parametrize("switch", ["HPRLP_NO_OVERLAP", "HPRLP_OVERLAP_COMM_FIRST"])
+def test_sharded_solver_other_forms_of_the_exchange(gpu, switch):
     """HPRLP_NO_OVERLAP=1: the unsplit shards with the exchange in line on the solver stream (the default splits every
-    shard by columns and runs the exchange beside the local-column part; every other test here covers that)."""
+    shard by columns and runs the exchange beside the local-column part; every other test here covers that).
+    HPRLP_OVERLAP_COMM_FIRST=1: the launch order used with RCCL (exchange enqueued first, local SpMV after it)."""
     import os
     import bench_helpers as bh
-    os.environ["HPRLP_NO_OVERLAP"] = "1"
+    os.environ[switch] = "1"
     try:
         m = n = 6001
         lp = bh.banded_lp(m, n, 8, 150)
@@ -199,4 +201,4 @@ def test_sharded_solver_without_the_exchange_overlap(gpu):
         check_against_single(ref, ranks, m, n, lp["obj_star"])
         model.free()
     finally:
-        del os.environ["HPRLP_NO_OVERLAP"]
+        del os.environ[switch]
