@@ -123,6 +123,7 @@ bool Presolve::run(const LP_info_cpu *model) {
         col_alive[j] = 0;
         stack_.push_back(Record{kind, -1, j, 0.0, v, l[j], u[j], v, v});
         if (kind == FixedCol) ++stats_.fixed_cols;
+        else if (kind == DualFixCol) ++stats_.dual_fixed_cols;
         else ++stats_.empty_cols;
     };
     auto drop_row = [&](int i, Kind kind) {
@@ -214,6 +215,26 @@ bool Presolve::run(const LP_info_cpu *model) {
                 changed = true;
             }
         }
+        // ---- dual fixing (PSLP: Simple_dual_fix): a column whose cost and whose rows all push it the same way sits at
+        // that bound in some optimal solution.  Down: c_j >= 0 and lowering x_j can violate no row (positive entries
+        // only in rows without a lower side, negative entries only in rows without an upper side); up: mirrored.
+        for (int j = 0; j < n && !give_up; ++j) {
+            if (!col_alive[j] || col_cnt[j] == 0) continue;
+            const double c = model->c[j];
+            bool down_ok = c >= 0.0 && fin(l[j]), up_ok = c <= 0.0 && fin(u[j]);
+            for (int k = trp_[j]; k < trp_[j + 1] && (down_ok || up_ok); ++k) {
+                const int i = tci_[k];
+                const double a = tv_[k];
+                if (!row_alive[i] || a == 0.0) continue;
+                const bool has_lo = fin(AL[i]), has_up = fin(AU[i]);
+                if (a > 0 ? has_lo : has_up) down_ok = false;  // lowering x_j lowers (a > 0) / raises (a < 0) the activity
+                if (a > 0 ? has_up : has_lo) up_ok = false;
+            }
+            if (down_ok || up_ok) {
+                fix_column(j, down_ok ? l[j] : u[j], DualFixCol);
+                changed = true;
+            }
+        }
         // ---- columns that no row uses any more
         for (int j = 0; j < n && !give_up; ++j) {
             if (!col_alive[j] || col_cnt[j] != 0) continue;
@@ -283,6 +304,7 @@ void Presolve::postsolve(const double *xr, const double *yr, const double *zr, d
         const Record &r = stack_[s];
         switch (r.kind) {
             case FixedCol:
+            case DualFixCol:
             case EmptyCol: {
                 double red = org_->c[r.j];
                 for (int k = trp_[r.j]; k < trp_[r.j + 1]; ++k) red -= tv_[k] * y[tci_[k]];

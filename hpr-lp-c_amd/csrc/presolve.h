@@ -5,8 +5,9 @@
 // This is our own presolver, run in-process (no fork next to a live HIP context): a fixed-point loop
 // over the reductions whose postsolve is exact for a primal-dual pair --
 //   fixed columns (l == u), empty rows, singleton rows (turned into column bounds), redundant rows
-//   (activity bounds inside [AL, AU]) and empty columns (moved to the bound the cost prefers).
-// PSLP applies more (doubleton equations, parallel rows/columns, dual fixing, bound propagation);
+//   (activity bounds inside [AL, AU]), empty columns (moved to the bound the cost prefers) and dual fixing (columns
+//   whose cost and rows all push them to one bound).
+// PSLP applies more (doubleton equations, parallel rows/columns, singleton columns, bound propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
 //   min c.x  s.t.  AL <= A x <= AU,  l <= x <= u,   z = c - A^T y,  y_i > 0 <=> row at AL.
 // Any doubt (infeasible or unbounded-looking input, nothing left to solve) makes run() return false
@@ -26,6 +27,7 @@ class Presolve {
    public:
     struct Stats {
         int fixed_cols = 0, empty_cols = 0, empty_rows = 0, singleton_rows = 0, redundant_rows = 0, passes = 0;
+        int dual_fixed_cols = 0;
         double seconds = 0.0;
     };
     Presolve() = default;
@@ -44,7 +46,7 @@ class Presolve {
 
    private:
     bool worth_it(const LP_info_cpu *model) const;  // large models: is there enough to remove?
-    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow };
+    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol };
     struct Record {
         Kind kind;
         int i, j;

@@ -156,6 +156,55 @@ def test_binding_singleton_row_gets_the_multiplier():
     pre.free(); model.free()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_dual_fixing(seed):
+    """Columns whose cost and rows all push them to one bound (PSLP's Simple_dual_fix): slack-like columns appended to a
+    planted LP are fixed at that bound, the optimum is unchanged and the postsolved triple passes the original KKT."""
+    rng = np.random.default_rng(seed)
+    base = lpgen.planted_lp(40, 70, 240, seed)
+    m0, n0 = 40, 70
+    A = sparse.csr_matrix((base["values"], base["colind"], base["rowptr"]), shape=(m0, n0)).tolil()
+    AL, AU = base["AL"].copy(), base["AU"].copy()
+    only_up = np.where(~np.isfinite(AL) & np.isfinite(AU))[0]
+    only_lo = np.where(np.isfinite(AL) & ~np.isfinite(AU))[0]
+    if len(only_lo) < 2:  # the generator makes equalities and <= rows: turn two <= rows around (sign flip keeps them valid)
+        for i in only_up[:2]:
+            A[i, :] = -A[i, :]
+            AL[i], AU[i] = -AU[i], INF
+        only_up = only_up[2:]
+        only_lo = np.where(np.isfinite(AL) & ~np.isfinite(AU))[0]
+    assert len(only_up) >= 2 and len(only_lo) >= 2
+    new_cols = sparse.lil_matrix((m0, 3))
+    # column n0: cost > 0, +entries in <= rows and a -entry in a >= row: lowering it can only help  -> lower bound 0.3
+    new_cols[only_up[0], 0] = 1.5; new_cols[only_up[1], 0] = 0.25; new_cols[only_lo[0], 0] = -2.0
+    # column n0+1: cost < 0, +entry in a >= row and -entry in a <= row: raising it can only help   -> upper bound 2.5
+    new_cols[only_lo[1], 1] = 1.0; new_cols[only_up[0], 1] = -0.5
+    # column n0+2: zero cost, +entry in a <= row, lower bound only                                 -> lower bound -1
+    new_cols[only_up[1], 2] = 3.0
+    A2 = sparse.hstack([A.tocsr(), new_cols.tocsr()]).tocsr()
+    A2.sort_indices()
+    l = np.concatenate([base["l"], [0.3, -INF, -1.0]])
+    u = np.concatenate([base["u"], [INF, 2.5, INF]])
+    c = np.concatenate([base["c"], [0.7, -0.4, 0.0]])
+    # keep the planted point feasible: shift the row sides by the new columns at their dual-fixed values
+    shift = A2[:, n0:] @ np.array([0.3, 2.5, -1.0])
+    AL, AU = AL + shift, AU + shift
+    lp = dict(m=m0, n=n0 + 3, rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), values=A2.data.copy(),
+              AL=AL, AU=AU, l=l, u=u, c=c)
+    model = make_model(lp)
+    f0, x0, y0, z0 = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], AL, AU, l, u, c)
+    pre = hprlp.Presolved(model)
+    assert pre.stats["dual_fixed_cols"] >= 3 and pre.stats["n"] <= n0
+    rm, rn, rp, ci, v, rAL, rAU, rl, ru, rc = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp, ci, v, rAL, rAU, rl, ru, rc)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-8 * (1 + abs(f0))
+    x, y, z = pre.postsolve(xr, yr, zr)
+    np.testing.assert_allclose(x[n0:], [0.3, 2.5, -1.0], atol=0)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert k["primal_feas"] <= 1e-9 and k["dual_feas"] <= 1e-9 and k["gap"] <= 1e-9, k
+    pre.free(); model.free()
+
+
 def test_presolve_declines(model_mps_arrays):
     """Nothing to remove (the reference's model.mps) and infeasible input: the caller keeps the original model."""
     a = model_mps_arrays
