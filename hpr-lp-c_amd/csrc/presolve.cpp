@@ -96,6 +96,7 @@ bool Presolve::run(const LP_info_cpu *model) {
 
     std::vector<double> AL(model->AL, model->AL + m), AU(model->AU, model->AU + m);
     std::vector<double> l(model->l, model->l + n), u(model->u, model->u + n);
+    std::vector<double> cost(model->c, model->c + n);  // slack substitution moves cost between columns
     std::vector<char> row_alive(m, 1), col_alive(n, 1);
     std::vector<int> row_cnt(m), col_cnt(n);
     for (int i = 0; i < m; ++i) row_cnt[i] = rp[i + 1] - rp[i];
@@ -119,9 +120,9 @@ bool Presolve::run(const LP_info_cpu *model) {
             if (fin(AU[i])) AU[i] -= s;
             --row_cnt[i];
         }
-        offset += model->c[j] * v;
+        offset += cost[j] * v;
         col_alive[j] = 0;
-        stack_.push_back(Record{kind, -1, j, 0.0, v, l[j], u[j], v, v});
+        stack_.push_back(Record{kind, -1, j, 0.0, v, l[j], u[j], v, v, cost[j]});
         if (kind == FixedCol) ++stats_.fixed_cols;
         else if (kind == DualFixCol) ++stats_.dual_fixed_cols;
         else ++stats_.empty_cols;
@@ -215,12 +216,43 @@ bool Presolve::run(const LP_info_cpu *model) {
                 changed = true;
             }
         }
+        // ---- slack columns (PSLP: StonCols, the equality-row case): column j appears only in the equality row i,
+        //   a x_j + sum_k a_ik x_k = b,  l_j <= x_j <= u_j.
+        // x_j is eliminated: the row becomes  b - a u_j <= sum_k a_ik x_k <= b - a l_j  (a > 0; mirrored for a < 0)
+        // and c_j x_j = c_j (b - sum_k a_ik x_k) / a moves onto the other columns' costs.
+        for (int j = 0; j < n && !give_up; ++j) {
+            if (!col_alive[j] || col_cnt[j] != 1) continue;
+            int i = -1;
+            double a = 0.0;
+            for (int k = trp_[j]; k < trp_[j + 1]; ++k)
+                if (row_alive[tci_[k]] && tv_[k] != 0.0) {
+                    i = tci_[k];
+                    a = tv_[k];
+                    break;
+                }
+            if (i < 0 || !fin(AL[i]) || AL[i] != AU[i] || row_cnt[i] < 2) continue;
+            const double b = AL[i], cj = cost[j], ratio = cj / a;
+            if (!fin(ratio)) continue;
+            const double lo = a > 0 ? b - a * u[j] : b - a * l[j];  // -inf when that bound of x_j is infinite
+            const double up = a > 0 ? b - a * l[j] : b - a * u[j];
+            if (std::isnan(lo) || std::isnan(up)) continue;
+            for (int k = rp[i]; k < rp[i + 1]; ++k)
+                if (col_alive[ci[k]] && ci[k] != j && av[k] != 0.0) cost[ci[k]] -= ratio * av[k];
+            offset += ratio * b;
+            AL[i] = lo;
+            AU[i] = up;
+            --row_cnt[i];
+            col_alive[j] = 0;
+            stack_.push_back(Record{SlackCol, i, j, a, b, l[j], u[j], 0.0, 0.0, cj});
+            ++stats_.slack_cols;
+            changed = true;
+        }
         // ---- dual fixing (PSLP: Simple_dual_fix): a column whose cost and whose rows all push it the same way sits at
         // that bound in some optimal solution.  Down: c_j >= 0 and lowering x_j can violate no row (positive entries
         // only in rows without a lower side, negative entries only in rows without an upper side); up: mirrored.
         for (int j = 0; j < n && !give_up; ++j) {
             if (!col_alive[j] || col_cnt[j] == 0) continue;
-            const double c = model->c[j];
+            const double c = cost[j];
             bool down_ok = c >= 0.0 && fin(l[j]), up_ok = c <= 0.0 && fin(u[j]);
             for (int k = trp_[j]; k < trp_[j + 1] && (down_ok || up_ok); ++k) {
                 const int i = tci_[k];
@@ -238,7 +270,7 @@ bool Presolve::run(const LP_info_cpu *model) {
         // ---- columns that no row uses any more
         for (int j = 0; j < n && !give_up; ++j) {
             if (!col_alive[j] || col_cnt[j] != 0) continue;
-            const double c = model->c[j];
+            const double c = cost[j];
             double v;
             if (c > 0) v = l[j];
             else if (c < 0) v = u[j];
@@ -281,7 +313,7 @@ bool Presolve::run(const LP_info_cpu *model) {
     for (int q = 0; q < rn; ++q) {
         rl[q] = l[col_of_[q]];
         ru[q] = u[col_of_[q]];
-        rc[q] = model->c[col_of_[q]];
+        rc[q] = cost[col_of_[q]];
     }
     reduced_ = model_from_csr(rm, rn, static_cast<long>(rci.size()), rrp.data(), rci.data(), rv.data(), rAL.data(),
                               rAU.data(), rl.data(), ru.data(), rc.data(), model->obj_constant + offset);
@@ -298,18 +330,40 @@ void Presolve::postsolve(const double *xr, const double *yr, const double *zr, d
         z[col_of_[q]] = zr[q];
     }
     for (size_t r = 0; r < row_of_.size(); ++r) y[row_of_[r]] = yr[r];
-    // undo the reductions last-in first-out; rows not yet restored carry y = 0, and whenever a row
-    // dual is set the reduced cost of its column is updated, so z = c - A^T y holds at the end
+    std::vector<char> have_x(static_cast<size_t>(n_), 0);  // columns whose x is final at this point of the undo sequence
+    for (size_t q = 0; q < col_of_.size(); ++q) have_x[col_of_[q]] = 1;
+    const int *rp = org_->A->rowPtr, *ci = org_->A->colIndex;
+    const double *av = org_->A->value;
+    // Undo the reductions last-in first-out.  At every point (x, y, z) is a primal-dual pair of the problem as it was
+    // when the record on top was applied: rows not yet restored carry y = 0, a column's reduced cost is formed with its
+    // cost at that time, whenever a row dual is set the reduced cost of its column is updated, and undoing a slack
+    // substitution shifts the row's dual by what it had moved into the other columns' costs (their reduced costs do
+    // not change).  So z = c - A^T y holds for the original model at the end.
     for (size_t s = stack_.size(); s-- > 0;) {
         const Record &r = stack_[s];
         switch (r.kind) {
             case FixedCol:
             case DualFixCol:
             case EmptyCol: {
-                double red = org_->c[r.j];
+                double red = r.cost;
                 for (int k = trp_[r.j]; k < trp_[r.j + 1]; ++k) red -= tv_[k] * y[tci_[k]];
                 x[r.j] = r.v;
                 z[r.j] = red;
+                have_x[r.j] = 1;
+                break;
+            }
+            case SlackCol: {
+                // r.v = right-hand side b when the column was eliminated; the columns of the row that were alive at that
+                // time are exactly the ones restored so far
+                double act = 0.0;
+                for (int k = rp[r.i]; k < rp[r.i + 1]; ++k)
+                    if (ci[k] != r.j && have_x[ci[k]]) act += av[k] * x[ci[k]];
+                double xj = (r.v - act) / r.a;
+                xj = std::min(std::max(xj, r.l_old), r.u_old);  // rounding only: the reduced row keeps it inside
+                x[r.j] = xj;
+                z[r.j] = -r.a * y[r.i];    // which side of the ranged row is active = which bound x_j sits on
+                y[r.i] += r.cost / r.a;    // the cost that moved onto the other columns belongs to the row's multiplier
+                have_x[r.j] = 1;
                 break;
             }
             case SingletonRow: {

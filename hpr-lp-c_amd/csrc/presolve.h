@@ -5,9 +5,11 @@
 // This is our own presolver, run in-process (no fork next to a live HIP context): a fixed-point loop
 // over the reductions whose postsolve is exact for a primal-dual pair --
 //   fixed columns (l == u), empty rows, singleton rows (turned into column bounds), redundant rows
-//   (activity bounds inside [AL, AU]), empty columns (moved to the bound the cost prefers) and dual fixing (columns
-//   whose cost and rows all push them to one bound).
-// PSLP applies more (doubleton equations, parallel rows/columns, singleton columns, bound propagation);
+//   (activity bounds inside [AL, AU]), empty columns (moved to the bound the cost prefers), dual fixing (columns
+//   whose cost and rows all push them to one bound) and slack columns (a column that appears only in one equality
+//   row is eliminated: the row becomes a ranged row, its cost moves onto the row's other columns).
+// PSLP applies more (doubleton equations, parallel rows/columns, singleton columns of inequality rows, bound
+// propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
 //   min c.x  s.t.  AL <= A x <= AU,  l <= x <= u,   z = c - A^T y,  y_i > 0 <=> row at AL.
 // Any doubt (infeasible or unbounded-looking input, nothing left to solve) makes run() return false
@@ -27,7 +29,7 @@ class Presolve {
    public:
     struct Stats {
         int fixed_cols = 0, empty_cols = 0, empty_rows = 0, singleton_rows = 0, redundant_rows = 0, passes = 0;
-        int dual_fixed_cols = 0;
+        int dual_fixed_cols = 0, slack_cols = 0;
         double seconds = 0.0;
     };
     Presolve() = default;
@@ -46,12 +48,13 @@ class Presolve {
 
    private:
     bool worth_it(const LP_info_cpu *model) const;  // large models: is there enough to remove?
-    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol };
+    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol, SlackCol };
     struct Record {
         Kind kind;
         int i, j;
         double a, v;
         double l_old, u_old, l_new, u_new;
+        double cost = 0.0;  // column records: the column's cost when it was removed (slack substitution moves cost)
     };
     int m_ = 0, n_ = 0;
     const LP_info_cpu *org_ = nullptr;

@@ -205,6 +205,60 @@ def test_dual_fixing(seed):
     pre.free(); model.free()
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_slack_columns_of_equality_rows(seed):
+    """An LP in equality form with explicit slack / surplus / free columns (some of them with a cost, some boxed): every
+    such column appears in one equality row only and is substituted out (PSLP's StonCols, equality case); the row turns
+    into a ranged row, the optimum is unchanged and the postsolved triple passes the original KKT."""
+    rng = np.random.default_rng(seed)
+    m0, n0 = 35, 60
+    base = lpgen.planted_lp(m0, n0, 220, seed)
+    A = sparse.csr_matrix((base["values"], base["colind"], base["rowptr"]), shape=(m0, n0))
+    AL, AU = base["AL"].copy(), base["AU"].copy()
+    ineq = np.where(~(np.isfinite(AL) & (AL == AU)))[0]
+    assert len(ineq) >= 6
+    cols, l_new, u_new, c_new = [], [], [], []
+    for t, i in enumerate(ineq):
+        a = float(rng.choice([1.0, -1.0, 2.5, -0.5]))
+        col = sparse.lil_matrix((m0, 1))
+        col[i, 0] = a
+        cols.append(col.tocsr())
+        # row i:  AL <= r.x <= AU   becomes   r.x + a s = b  with  s in [ (b - AU)/a , (b - AL)/a ]  (sorted)
+        b = AU[i] if np.isfinite(AU[i]) else AL[i]
+        lo, hi = (b - AU[i]) / a, (b - AL[i]) / a
+        lo, hi = min(lo, hi), max(lo, hi)
+        l_new.append(lo); u_new.append(hi)
+        c_new.append(0.0)  # costs on a third of them are set below
+        AL[i] = AU[i] = b
+    A2 = sparse.hstack([A] + cols).tocsr()
+    A2.sort_indices()
+    l = np.concatenate([base["l"], l_new]); u = np.concatenate([base["u"], u_new]); c = np.concatenate([base["c"], c_new])
+    # slack columns WITH a cost: add cost c_s to slack s and subtract c_s/a * (row) from nothing -- instead perturb directly
+    # and let the exact solver be the judge (the LP stays feasible and bounded: boxed or one-sided slacks with the cost
+    # pointing at the finite side)
+    k = n0
+    for t in range(len(ineq)):
+        if t % 3 == 0:
+            if np.isfinite(l[k + t]):
+                c[k + t] = 0.3
+            elif np.isfinite(u[k + t]):
+                c[k + t] = -0.3
+    lp = dict(m=m0, n=A2.shape[1], rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), values=A2.data.copy(),
+              AL=AL, AU=AU, l=l, u=u, c=c)
+    model = make_model(lp)
+    f0, x0, y0, z0 = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], AL, AU, l, u, c)
+    pre = hprlp.Presolved(model)
+    assert pre.stats["slack_cols"] >= len(ineq) - 1, pre.stats
+    rm, rn, rp, ci, v, rAL, rAU, rl, ru, rc = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp, ci, v, rAL, rAU, rl, ru, rc)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-8 * (1 + abs(f0))
+    x, y, z = pre.postsolve(xr, yr, zr)
+    kk = hprlp.original_kkt(model, x, y, z)
+    assert kk["primal_feas"] <= 1e-9 and kk["dual_feas"] <= 1e-9 and kk["gap"] <= 1e-9, kk
+    assert abs(kk["primal_obj"] - f0) <= 1e-8 * (1 + abs(f0))
+    pre.free(); model.free()
+
+
 def test_presolve_declines(model_mps_arrays):
     """Nothing to remove (the reference's model.mps) and infeasible input: the caller keeps the original model."""
     a = model_mps_arrays

@@ -9,6 +9,12 @@
 #include "tiled.h"
 #include "presolve.h"
 using namespace hprlp;
+// device-side members of DeviceTiled (tiled_build.hip) that tiled.cpp's upload path references: never called here
+namespace hprlp {
+void DeviceTiled::pack_indices(hipStream_t) {}
+void DeviceTiled::finish_schedule(hipStream_t) {}
+}  // namespace hprlp
+
 int main() {
     std::mt19937_64 rng(7);
     for (int rep = 0; rep < 6; ++rep) {
@@ -32,6 +38,8 @@ int main() {
         std::vector<double> AL(m, -1.0), AU(m, 1.0), l(n, 0.0), u(n, 2.0), c(n, 1.0);
         for (int j = 0; j < n; j += 13) u[j] = l[j];          // fixed columns
         for (int i = 0; i < m; i += 7) AU[i] = INFINITY;
+        for (int i = 2; i < m; i += 5) AL[i] = AU[i] = 0.0;   // equality rows: slack-column substitution
+        for (int j = 0; j < n; j += 3) c[j] = -0.5;           // both cost signs: dual fixing either way
         LP_info_cpu *model = create_model_from_arrays(m, n, (int)nnz, rp.data(), ci.data(), v.data(), AL.data(), AU.data(), l.data(), u.data(), c.data(), false);
         if (!model) { printf("model null\n"); return 1; }
         {
