@@ -84,3 +84,24 @@ def test_tiled_handles_long_segments_and_ragged_edges(gpu, force_tiled):
     got = s.residuals(10, True)
     assert np.isfinite(got["kkt"])
     s.close(); model.free()
+
+
+def test_tiled_runs_are_bit_reproducible(gpu, force_tiled):
+    """The rotated sweeps and the persistent schedule fix the summation order by the matrix alone: two solvers on the
+    same model produce identical bits, whatever order the workgroups happen to run in."""
+    m = n = 40000
+    lp, model = build(m, n, 12, 900)
+    states = []
+    for _ in range(2):
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        assert s.info()["tiled"] == 3
+        s.scale()
+        lam, it = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        s.iterate(60, True)
+        states.append((lam, it, {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}))
+        s.close()
+    assert states[0][0] == states[1][0] and states[0][1] == states[1][1]
+    for k in states[0][2]:
+        assert np.array_equal(states[0][2][k], states[1][2][k]), k
+    model.free()
