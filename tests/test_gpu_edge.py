@@ -186,3 +186,41 @@ def test_dense_rows_and_columns_are_split(gpu):
     want = highs(A, AL, AU, l, u, c)
     assert abs(r.primal_obj - want) <= 1e-4 * (1 + abs(want))
     model.free()
+
+
+def test_duplicate_and_unsorted_entries(gpu):
+    """create_model_from_arrays takes the arrays as they are (reference src/HPRLP.cu:343-452 copies them): rows whose
+    column indices are not sorted and repeat.  The solve must equal the solve of the canonical form (sorted, duplicates
+    summed) -- the kernels add duplicates as separate entries."""
+    lp = lpgen.planted_lp(300, 500, 3000, 12)
+    m, n = lp["m"], lp["n"]
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    rng = np.random.default_rng(5)
+    rp, ci, v = [0], [], []
+    for i in range(m):
+        cols = A.indices[A.indptr[i]:A.indptr[i + 1]]
+        vals = A.data[A.indptr[i]:A.indptr[i + 1]]
+        cc, vv = [], []
+        for c_, a in zip(cols, vals):
+            if rng.random() < 0.3:  # split the entry in two: a = 0.25 a + 0.75 a exactly representable parts
+                cc += [c_, c_]; vv += [0.25 * a, 0.75 * a]
+            else:
+                cc.append(c_); vv.append(a)
+        order = rng.permutation(len(cc))
+        ci += [cc[k] for k in order]; v += [vv[k] for k in order]
+        rp.append(len(ci))
+    raw = hprlp.Model.from_csr(m, n, np.array(rp, np.int32), np.array(ci, np.int32), np.array(v), lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    canon = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False, max_iter=200000)
+    r_raw, r_can = raw.solve(prm), canon.solve(prm)
+    assert r_raw.status == r_can.status == "OPTIMAL"
+    assert abs(r_raw.primal_obj - lp["obj_star"]) <= 1e-5 * (1 + abs(lp["obj_star"]))
+    assert abs(r_raw.primal_obj - r_can.primal_obj) <= 1e-5 * (1 + abs(r_can.primal_obj))
+    # (iteration counts differ: the scalings see 0.75 a where the canonical form has a)
+    # the optimum is not unique: check the raw solve's primal-dual triple against the CANONICAL model instead
+    k = hprlp.original_kkt(canon, r_raw.x, r_raw.y, r_raw.z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-5, k
+    # with presolve on the same holds (the presolver counts structure per entry)
+    r_pre = raw.solve(hprlp.Parameters(stop_tol=1e-6, use_presolve=True, max_iter=200000))
+    assert r_pre.status == "OPTIMAL" and abs(r_pre.primal_obj - lp["obj_star"]) <= 1e-5 * (1 + abs(lp["obj_star"]))
+    raw.free(); canon.free()
