@@ -216,10 +216,11 @@ bool Presolve::run(const LP_info_cpu *model) {
                 changed = true;
             }
         }
-        // ---- slack columns (PSLP: StonCols, the equality-row case): column j appears only in the equality row i,
-        //   a x_j + sum_k a_ik x_k = b,  l_j <= x_j <= u_j.
-        // x_j is eliminated: the row becomes  b - a u_j <= sum_k a_ik x_k <= b - a l_j  (a > 0; mirrored for a < 0)
-        // and c_j x_j = c_j (b - sum_k a_ik x_k) / a moves onto the other columns' costs.
+        // ---- slack columns (PSLP: StonCols): column j appears only in row i,
+        //   AL <= a x_j + sum_k a_ik x_k <= AU,  l_j <= x_j <= u_j,
+        // and either the row is an equality (any cost) or c_j = 0.  x_j is eliminated: the row becomes
+        //   AL - a u_j <= sum_k a_ik x_k <= AU - a l_j   (a > 0; bounds swapped for a < 0)
+        // and, in the equality case, c_j x_j = c_j (b - sum_k a_ik x_k) / a moves onto the other columns' costs.
         for (int j = 0; j < n && !give_up; ++j) {
             if (!col_alive[j] || col_cnt[j] != 1) continue;
             int i = -1;
@@ -230,20 +231,25 @@ bool Presolve::run(const LP_info_cpu *model) {
                     a = tv_[k];
                     break;
                 }
-            if (i < 0 || !fin(AL[i]) || AL[i] != AU[i] || row_cnt[i] < 2) continue;
-            const double b = AL[i], cj = cost[j], ratio = cj / a;
+            if (i < 0 || row_cnt[i] < 2) continue;
+            const bool equality = fin(AL[i]) && AL[i] == AU[i];
+            const double cj = cost[j];
+            if (!equality && cj != 0.0) continue;
+            const double ratio = cj / a;
             if (!fin(ratio)) continue;
-            const double lo = a > 0 ? b - a * u[j] : b - a * l[j];  // -inf when that bound of x_j is infinite
-            const double up = a > 0 ? b - a * l[j] : b - a * u[j];
+            const double lo = a > 0 ? AL[i] - a * u[j] : AL[i] - a * l[j];  // -inf when that bound of x_j is infinite
+            const double up = a > 0 ? AU[i] - a * l[j] : AU[i] - a * u[j];
             if (std::isnan(lo) || std::isnan(up)) continue;
-            for (int k = rp[i]; k < rp[i + 1]; ++k)
-                if (col_alive[ci[k]] && ci[k] != j && av[k] != 0.0) cost[ci[k]] -= ratio * av[k];
-            offset += ratio * b;
+            if (cj != 0.0) {
+                for (int k = rp[i]; k < rp[i + 1]; ++k)
+                    if (col_alive[ci[k]] && ci[k] != j && av[k] != 0.0) cost[ci[k]] -= ratio * av[k];
+                offset += ratio * AL[i];
+            }
+            stack_.push_back(Record{SlackCol, i, j, a, 0.0, l[j], u[j], AL[i], AU[i], cj});  // l_new / u_new: the row's sides
             AL[i] = lo;
             AU[i] = up;
             --row_cnt[i];
             col_alive[j] = 0;
-            stack_.push_back(Record{SlackCol, i, j, a, b, l[j], u[j], 0.0, 0.0, cj});
             ++stats_.slack_cols;
             changed = true;
         }
@@ -353,13 +359,21 @@ void Presolve::postsolve(const double *xr, const double *yr, const double *zr, d
                 break;
             }
             case SlackCol: {
-                // r.v = right-hand side b when the column was eliminated; the columns of the row that were alive at that
-                // time are exactly the ones restored so far
+                // r.l_new / r.u_new = the row's sides when the column was eliminated; the columns of the row that were
+                // alive at that time are exactly the ones restored so far.  a x_j has to land in
+                // [AL - act, AU - act] and in a * [l_j, u_j]; an active side of the reduced row (y != 0) pins it to the
+                // matching end, which is also the bound of x_j that the reduced cost -a y then leans on.
                 double act = 0.0;
                 for (int k = rp[r.i]; k < rp[r.i + 1]; ++k)
                     if (ci[k] != r.j && have_x[ci[k]]) act += av[k] * x[ci[k]];
-                double xj = (r.v - act) / r.a;
-                xj = std::min(std::max(xj, r.l_old), r.u_old);  // rounding only: the reduced row keeps it inside
+                const double b1 = r.a * r.l_old, b2 = r.a * r.u_old;
+                const double tlo = std::max(r.l_new - act, std::min(b1, b2)), thi = std::min(r.u_new - act, std::max(b1, b2));
+                double t;
+                if (y[r.i] > 0.0) t = tlo;
+                else if (y[r.i] < 0.0) t = thi;
+                else t = fin(tlo) ? tlo : (fin(thi) ? thi : 0.0);
+                double xj = t / r.a;
+                xj = std::min(std::max(xj, r.l_old), r.u_old);  // rounding only
                 x[r.j] = xj;
                 z[r.j] = -r.a * y[r.i];    // which side of the ranged row is active = which bound x_j sits on
                 y[r.i] += r.cost / r.a;    // the cost that moved onto the other columns belongs to the row's multiplier

@@ -6,9 +6,10 @@
 // over the reductions whose postsolve is exact for a primal-dual pair --
 //   fixed columns (l == u), empty rows, singleton rows (turned into column bounds), redundant rows
 //   (activity bounds inside [AL, AU]), empty columns (moved to the bound the cost prefers), dual fixing (columns
-//   whose cost and rows all push them to one bound) and slack columns (a column that appears only in one equality
-//   row is eliminated: the row becomes a ranged row, its cost moves onto the row's other columns).
-// PSLP applies more (doubleton equations, parallel rows/columns, singleton columns of inequality rows, bound
+//   whose cost and rows all push them to one bound) and slack columns (a column that appears in one row only is
+//   eliminated when the row is an equality -- its cost moves onto the row's other columns -- or when its cost is
+//   zero: the row's sides widen by the column's range).
+// PSLP applies more (doubleton equations, parallel rows/columns, costed singleton columns of inequality rows, bound
 // propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
 //   min c.x  s.t.  AL <= A x <= AU,  l <= x <= u,   z = c - A^T y,  y_i > 0 <=> row at AL.
