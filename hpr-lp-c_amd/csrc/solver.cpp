@@ -13,6 +13,7 @@
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <thread>
 
 #include "dist.h"
 
@@ -79,8 +80,22 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     // the kernels index without bounds checks: refuse anything that could fault on the device
     for (int i = 0; i < rows; ++i)
         if (rp[i + 1] < rp[i]) throw std::runtime_error("row pointer array is not monotone");
-    for (int k = 0; k < nnz; ++k)
-        if (ci[k] < 0 || ci[k] >= cols) throw std::runtime_error("column index out of range");
+    {
+        const int T = nnz > 4000000 ? static_cast<int>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()))) : 1;
+        std::vector<char> bad(static_cast<size_t>(T), 0);
+        auto scan = [&](int t) {
+            const long lo = static_cast<long>(nnz) * t / T, hi = static_cast<long>(nnz) * (t + 1) / T;
+            char b = 0;
+            for (long k = lo; k < hi; ++k) b |= (ci[k] < 0 || ci[k] >= cols);
+            bad[t] = b;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+        for (char b : bad)
+            if (b) throw std::runtime_error("column index out of range");
+    }
     pt.tick("  validate indices");
     rowptr.alloc(static_cast<size_t>(rows) + 1);
     rowptr.upload(rp, static_cast<size_t>(rows) + 1);
