@@ -7,8 +7,9 @@
 // super-block) and accumulates row sums in LDS.  Entries of a (super-block, tile) pair are sorted by
 // (row, column) and packed in chunks of 4; a row segment never straddles a chunk (zero-valued
 // padding continues the previous row), so exactly one lane touches a given accumulator in a step:
-// no atomics, deterministic, and the per-row summation order stays the CSR order.  Segments longer
-// than 4 and entries of sparse tiles go to a remainder list processed with direct gathers.
+// no atomics, deterministic; the per-row summation order is fixed by the matrix (tiles in the order of
+// the super-block's rotated sweep -- finish_schedule() in tiled_build.hip -- then the remainder).
+// Segments longer than 4 and entries of sparse tiles go to a remainder list processed with direct gathers.
 #pragma once
 
 #include <hip/hip_runtime.h>
