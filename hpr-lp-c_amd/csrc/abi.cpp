@@ -299,6 +299,29 @@ extern "C" int hprlp_solver_dist_info(hprlp_solver *h, long out[8]) {
     return 0;
 }
 
+// One grouped send/recv of `count` doubles from this rank to ITSELF through the solver's communicator (pattern
+// i -> 3 i + 1), checked on the host: exercises the point-to-point entry points of the transport (RCCL: ncclGroupStart /
+// ncclSend / ncclRecv / ncclGroupEnd) on a box where no second rank can exist.  0 = delivered intact.
+extern "C" int hprlp_solver_dist_loopback(hprlp_solver *h, int count) {
+    GUARD_BEGIN
+    Solver &s = h->s;
+    if (!s.comm) throw std::runtime_error("solver has no communicator");
+    if (count <= 0) throw std::runtime_error("count must be positive");
+    std::vector<double> src(static_cast<size_t>(count)), dst(static_cast<size_t>(count), -1.0);
+    for (int i = 0; i < count; ++i) src[i] = 3.0 * i + 1.0;
+    DBuf<double> a(src.size()), b(dst.size());
+    a.upload(src.data(), src.size());
+    b.upload(dst.data(), dst.size());
+    const P2P op{s.comm->rank, a.p, src.size() * sizeof(double), b.p, dst.size() * sizeof(double)};
+    s.comm->exchange(&op, 1, s.stream);
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    b.download(dst.data(), dst.size());
+    for (int i = 0; i < count; ++i)
+        if (dst[i] != src[i]) throw std::runtime_error("loopback send/recv delivered wrong data at element " + std::to_string(i));
+    return 0;
+    GUARD_END(-1)
+}
+
 extern "C" void hprlp_solver_destroy(hprlp_solver *h) {
     try {
         if (!h) return;

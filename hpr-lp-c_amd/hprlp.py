@@ -391,6 +391,11 @@ class Solver:
         L.hprlp_local_group_destroy.argtypes = [C.c_void_p]
         L.hprlp_local_group_destroy(group)
 
+    def dist_loopback(self, count=100000):
+        L = lib()
+        L.hprlp_solver_dist_loopback.argtypes = [C.c_void_p, C.c_int]
+        self._chk(L.hprlp_solver_dist_loopback(self.h, int(count)))
+
     def dist_info(self):
         L = lib()
         L.hprlp_solver_dist_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]

@@ -113,6 +113,9 @@ hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_par
  * overrides (same value on every rank).
  * out = {m-vectors sparse?, entries sent, received, n-vectors sparse?, sent, received, all ranks' requests m, n} */
 int hprlp_solver_dist_info(hprlp_solver *s, long out[8]);
+/* Test hook: one grouped send/recv of `count` doubles from this rank to itself through the solver's communicator,
+ * verified on the host (0 = intact).  Exercises the point-to-point transport calls where no second rank exists. */
+int hprlp_solver_dist_loopback(hprlp_solver *s, int count);
 /* The same multi-rank solver with `size` ranks as host THREADS of one process on one GPU, exchanging through
  * device copies and host barriers instead of RCCL: lets the sharded path run on a one-GPU box (tests). Every
  * rank's thread must make the same sequence of solver calls. */

@@ -17,6 +17,7 @@ def test_one_rank_rccl_path_equals_plain_solver(gpu):
     plain = hprlp.Solver(model, prm)
     uid = hprlp.Solver.dist_unique_id()
     dist = hprlp.Solver.create_dist(model, prm, 0, 1, uid)
+    dist.dist_loopback(1 << 18)  # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd: rank 0 to itself, 2 MiB, verified
     out = []
     for s in (plain, dist):
         s.scale()
