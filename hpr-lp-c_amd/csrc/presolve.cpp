@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <limits>
 #include <thread>
+#include <unordered_map>
 
 #include "HPRLP.h"
 #include "common.h"
@@ -216,6 +217,63 @@ bool Presolve::run(const LP_info_cpu *model) {
                 changed = true;
             }
         }
+        // ---- parallel rows (PSLP: Parallel_rows): row i2 = lambda * row i1 over the live columns.  Row i2 goes, row i1
+        // keeps the intersection of its own sides and row i2's sides divided by lambda.
+        {
+            std::unordered_map<unsigned long long, std::vector<int>> buckets;  // hash of the live column pattern -> rows
+            std::vector<std::pair<int, double>> e1, e2;
+            auto live_entries = [&](int i, std::vector<std::pair<int, double>> &out) {
+                out.clear();
+                for (int k = rp[i]; k < rp[i + 1]; ++k)
+                    if (col_alive[ci[k]] && av[k] != 0.0) out.emplace_back(ci[k], av[k]);
+                std::sort(out.begin(), out.end());
+                for (size_t q = 1; q < out.size(); ++q)
+                    if (out[q].first == out[q - 1].first) return false;  // repeated column index: leave the row alone
+                return true;
+            };
+            for (int i = 0; i < m; ++i) {
+                if (!row_alive[i] || row_cnt[i] < 2) continue;
+                unsigned long long h = 1469598103934665603ULL;
+                std::vector<int> cols;
+                for (int k = rp[i]; k < rp[i + 1]; ++k)
+                    if (col_alive[ci[k]] && av[k] != 0.0) cols.push_back(ci[k]);
+                std::sort(cols.begin(), cols.end());
+                for (int cc : cols) h = (h ^ static_cast<unsigned long long>(cc + 1)) * 1099511628211ULL;
+                buckets[h].push_back(i);
+            }
+            for (auto &kv : buckets) {
+                std::vector<int> &rows = kv.second;
+                if (rows.size() < 2) continue;
+                std::sort(rows.begin(), rows.end());  // deterministic whatever the map's order
+                for (size_t p1 = 0; p1 < rows.size() && !give_up; ++p1) {
+                    const int i1 = rows[p1];
+                    if (!row_alive[i1] || !live_entries(i1, e1)) continue;
+                    for (size_t p2 = p1 + 1; p2 < rows.size() && !give_up; ++p2) {
+                        const int i2 = rows[p2];
+                        if (!row_alive[i2] || !live_entries(i2, e2) || e2.size() != e1.size()) continue;
+                        const double lambda = e2[0].second / e1[0].second;
+                        bool par = std::isfinite(lambda) && lambda != 0.0;
+                        for (size_t q = 0; q < e1.size() && par; ++q)
+                            par = e1[q].first == e2[q].first &&
+                                  std::abs(e2[q].second - lambda * e1[q].second) <= 1e-12 * std::abs(e2[q].second);
+                        if (!par) continue;
+                        const double lo2 = lambda > 0 ? AL[i2] / lambda : AU[i2] / lambda;
+                        const double up2 = lambda > 0 ? AU[i2] / lambda : AL[i2] / lambda;
+                        const double lo = std::max(AL[i1], lo2), up = std::min(AU[i1], up2);
+                        if (lo > up && lo - up > rel(lo)) {
+                            give_up = true;  // the two rows contradict each other: the solver reports it
+                            break;
+                        }
+                        stack_.push_back(Record{ParallelRow, i2, i1, lambda, 0.0, AL[i1], AU[i1], lo2, up2});
+                        AL[i1] = lo;
+                        AU[i1] = std::max(up, lo);
+                        drop_row(i2, SingletonRow);  // (SingletonRow: drop_row pushes no record of its own)
+                        ++stats_.parallel_rows;
+                        changed = true;
+                    }
+                }
+            }
+        }
         // ---- slack columns (PSLP: StonCols): column j appears only in row i,
         //   AL <= a x_j + sum_k a_ik x_k <= AU,  l_j <= x_j <= u_j,
         // and either the row is an equality (any cost) or c_j = 0.  x_j is eliminated: the row becomes
@@ -391,6 +449,20 @@ void Presolve::postsolve(const double *xr, const double *yr, const double *zr, d
                 if (yi != 0.0) {
                     y[r.i] = yi;
                     z[r.j] = 0.0;
+                }
+                break;
+            }
+            case ParallelRow: {
+                // row r.i = r.a * row r.j was folded into row r.j: the multiplier belongs to whichever of the two rows
+                // supplied the active side (r.l_old / r.u_old: row r.j's own sides, r.l_new / r.u_new: row r.i's sides
+                // divided by r.a); a_{r.j} y = a_{r.i} (y / r.a), so no reduced cost changes
+                const double yk = y[r.j];
+                const bool from_i = (yk > 0.0 && r.l_new > r.l_old) || (yk < 0.0 && r.u_new < r.u_old);
+                if (from_i) {
+                    y[r.i] = yk / r.a;
+                    y[r.j] = 0.0;
+                } else {
+                    y[r.i] = 0.0;
                 }
                 break;
             }

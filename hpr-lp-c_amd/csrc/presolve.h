@@ -8,8 +8,9 @@
 //   (activity bounds inside [AL, AU]), empty columns (moved to the bound the cost prefers), dual fixing (columns
 //   whose cost and rows all push them to one bound) and slack columns (a column that appears in one row only is
 //   eliminated when the row is an equality -- its cost moves onto the row's other columns -- or when its cost is
-//   zero: the row's sides widen by the column's range).
-// PSLP applies more (doubleton equations, parallel rows/columns, costed singleton columns of inequality rows, bound
+//   zero: the row's sides widen by the column's range), parallel rows (a row that is a multiple of another one over
+//   the live columns is folded into it: intersection of the sides).
+// PSLP applies more (doubleton equations, parallel columns, costed singleton columns of inequality rows, bound
 // propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
 //   min c.x  s.t.  AL <= A x <= AU,  l <= x <= u,   z = c - A^T y,  y_i > 0 <=> row at AL.
@@ -30,7 +31,7 @@ class Presolve {
    public:
     struct Stats {
         int fixed_cols = 0, empty_cols = 0, empty_rows = 0, singleton_rows = 0, redundant_rows = 0, passes = 0;
-        int dual_fixed_cols = 0, slack_cols = 0;
+        int dual_fixed_cols = 0, slack_cols = 0, parallel_rows = 0;
         double seconds = 0.0;
     };
     Presolve() = default;
@@ -49,7 +50,7 @@ class Presolve {
 
    private:
     bool worth_it(const LP_info_cpu *model) const;  // large models: is there enough to remove?
-    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol, SlackCol };
+    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol, SlackCol, ParallelRow };
     struct Record {
         Kind kind;
         int i, j;

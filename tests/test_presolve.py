@@ -297,15 +297,31 @@ def decorated_lp(seed):
         col = sparse.lil_matrix((m, 1)); col[i, 0] = a
         new_cols.append(col.tocsr()); nl.append(0.0); nu.append(float(rng.choice([1.5, INF]))); nc.append(0.0)
     A2 = sparse.hstack([A.tocsr()] + new_cols).tocsr() if new_cols else A.tocsr()
+    # parallel rows: multiples of existing rows, looser on both sides or with one side only
+    picks = [i for i in range(m) if A2.indptr[i + 1] - A2.indptr[i] >= 3][: 4 + seed % 3]
+    extra_rows, eAL, eAU = [], [], []
+    for t, i in enumerate(picks):
+        lam = float(rng.choice([2.0, -0.5, 1.0, -3.0]))
+        lo_i, up_i = AL[i], AU[i]
+        if t % 2 == 0:   # looser copy of the row (the original stays the binding one)
+            lo_n, up_n = (lo_i - 0.4 if np.isfinite(lo_i) else -INF), (up_i + 0.7 if np.isfinite(up_i) else INF)
+        else:            # one side tighter by nothing, the other missing: the sides get split between the two rows
+            lo_n, up_n = lo_i, INF
+        a, b = lam * lo_n, lam * up_n
+        extra_rows.append(A2[i] * lam); eAL.append(min(a, b)); eAU.append(max(a, b))
+    if extra_rows:
+        A2 = sparse.vstack([A2] + extra_rows).tocsr()
+        AL, AU = np.concatenate([AL, eAL]), np.concatenate([AU, eAU])
     A2.sort_indices()
-    return dict(m=m, n=A2.shape[1], rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), values=A2.data.copy(),
+    return dict(m=A2.shape[0], n=A2.shape[1], rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), values=A2.data.copy(),
                 AL=AL, AU=AU, l=np.concatenate([l, nl]), u=np.concatenate([u, nu]), c=np.concatenate([c, nc]))
 
 
 def test_randomised_sweep_of_all_reductions():
     """40 decorated LPs: the reduced model has the original optimum and the postsolved triple satisfies the KKT conditions
     of the original model -- the undo sequence is exercised with every mix of reductions the generator produces."""
-    seen = dict(fixed_cols=0, empty_cols=0, singleton_rows=0, empty_rows=0, redundant_rows=0, dual_fixed_cols=0, slack_cols=0)
+    seen = dict(fixed_cols=0, empty_cols=0, singleton_rows=0, empty_rows=0, redundant_rows=0, dual_fixed_cols=0, slack_cols=0,
+                parallel_rows=0)
     for seed in range(40):
         lp = decorated_lp(seed)
         try:

@@ -25,6 +25,11 @@ int main() {
             std::vector<int> cols;
             for (int k = 0; k < len; ++k) cols.push_back(rng() % n);
             std::sort(cols.begin(), cols.end()); cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            if (i % 50 == 4 && rp[i] - rp[i - 1] >= 2) {  // parallel to the previous row: -2 x its entries
+                for (int k = rp[i - 1]; k < rp[i]; ++k) { ci.push_back(ci[k]); v.push_back(-2.0 * v[k]); }
+                rp[i + 1] = (int)ci.size();
+                continue;
+            }
             for (int c : cols) { ci.push_back(c); v.push_back((double)(rng() % 1000) / 100.0 - 5.0); }
             rp[i + 1] = (int)ci.size();
         }
