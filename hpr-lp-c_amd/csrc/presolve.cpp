@@ -274,6 +274,58 @@ bool Presolve::run(const LP_info_cpu *model) {
                 }
             }
         }
+        // ---- parallel columns (PSLP: Parallel_cols): column j2 = lambda * column j1 over the live rows and c_j2 =
+        // lambda * c_j1.  The pair acts through x_j1 + lambda x_j2 only: column j2 goes, column j1 stands for the sum
+        // with the sum's range as its bounds.
+        {
+            std::unordered_map<unsigned long long, std::vector<int>> buckets;
+            std::vector<std::pair<int, double>> e1, e2;
+            auto live_entries = [&](int j, std::vector<std::pair<int, double>> &out) {
+                out.clear();
+                for (int k = trp_[j]; k < trp_[j + 1]; ++k)
+                    if (row_alive[tci_[k]] && tv_[k] != 0.0) out.emplace_back(tci_[k], tv_[k]);
+                std::sort(out.begin(), out.end());
+                for (size_t q = 1; q < out.size(); ++q)
+                    if (out[q].first == out[q - 1].first) return false;
+                return true;
+            };
+            for (int j = 0; j < n; ++j) {
+                if (!col_alive[j] || col_cnt[j] < 2) continue;
+                if (!live_entries(j, e1)) continue;
+                unsigned long long h = 1469598103934665603ULL;
+                for (const auto &e : e1) h = (h ^ static_cast<unsigned long long>(e.first + 1)) * 1099511628211ULL;
+                buckets[h].push_back(j);
+            }
+            for (auto &kv : buckets) {
+                std::vector<int> &cols = kv.second;
+                if (cols.size() < 2) continue;
+                std::sort(cols.begin(), cols.end());
+                for (size_t p1 = 0; p1 < cols.size(); ++p1) {
+                    const int j1 = cols[p1];
+                    if (!col_alive[j1] || !live_entries(j1, e1)) continue;
+                    for (size_t p2 = p1 + 1; p2 < cols.size(); ++p2) {
+                        const int j2 = cols[p2];
+                        if (!col_alive[j2] || !live_entries(j2, e2) || e2.size() != e1.size()) continue;
+                        const double lambda = e2[0].second / e1[0].second;
+                        bool par = std::isfinite(lambda) && lambda != 0.0 &&
+                                   std::abs(cost[j2] - lambda * cost[j1]) <= 1e-12 * std::abs(cost[j2]);
+                        for (size_t q = 0; q < e1.size() && par; ++q)
+                            par = e1[q].first == e2[q].first &&
+                                  std::abs(e2[q].second - lambda * e1[q].second) <= 1e-12 * std::abs(e2[q].second);
+                        if (!par) continue;
+                        const double t_lo = std::min(lambda * l[j2], lambda * u[j2]), t_up = std::max(lambda * l[j2], lambda * u[j2]);
+                        if (std::isnan(t_lo) || std::isnan(t_up)) continue;
+                        stack_.push_back(Record{ParallelCol, j2, j1, lambda, 0.0, l[j1], u[j1], l[j2], u[j2]});
+                        l[j1] += t_lo;  // (-inf stays -inf; the lower parts are never +inf)
+                        u[j1] += t_up;
+                        for (const auto &e : e2) --row_cnt[e.first];
+                        col_alive[j2] = 0;
+                        ++stats_.parallel_cols;
+                        changed = true;
+                    }
+                }
+            }
+        }
         // ---- slack columns (PSLP: StonCols): column j appears only in row i,
         //   AL <= a x_j + sum_k a_ik x_k <= AU,  l_j <= x_j <= u_j,
         // and either the row is an equality (any cost) or c_j = 0.  x_j is eliminated: the row becomes
@@ -450,6 +502,22 @@ void Presolve::postsolve(const double *xr, const double *yr, const double *zr, d
                     y[r.i] = yi;
                     z[r.j] = 0.0;
                 }
+                break;
+            }
+            case ParallelCol: {
+                // x[r.j] is the sum x_j1 + lambda x_j2 (r.i = j2, r.a = lambda; r.l_old / r.u_old: bounds of j1, r.l_new /
+                // r.u_new: bounds of j2): split it inside both boxes.  At a bound of the sum both parts sit at their own
+                // bounds, so the reduced costs z_j1 = z, z_j2 = lambda z keep their meaning.
+                const double xm = x[r.j], zm = z[r.j];
+                const double t_lo = std::min(r.a * r.l_new, r.a * r.u_new), t_up = std::max(r.a * r.l_new, r.a * r.u_new);
+                const double t_pref = std::min(std::max(0.0, t_lo), t_up);
+                double x1 = std::min(std::max(xm - t_pref, r.l_old), r.u_old);
+                const double t2 = std::min(std::max(xm - x1, t_lo), t_up);
+                x1 = xm - t2;
+                x[r.j] = std::min(std::max(x1, r.l_old), r.u_old);  // rounding only
+                x[r.i] = std::min(std::max(t2 / r.a, r.l_new), r.u_new);
+                z[r.i] = r.a * zm;
+                have_x[r.i] = 1;
                 break;
             }
             case ParallelRow: {

@@ -9,9 +9,9 @@
 //   whose cost and rows all push them to one bound) and slack columns (a column that appears in one row only is
 //   eliminated when the row is an equality -- its cost moves onto the row's other columns -- or when its cost is
 //   zero: the row's sides widen by the column's range), parallel rows (a row that is a multiple of another one over
-//   the live columns is folded into it: intersection of the sides).
-// PSLP applies more (doubleton equations, parallel columns, costed singleton columns of inequality rows, bound
-// propagation);
+//   the live columns is folded into it: intersection of the sides) and parallel columns (a column that is a multiple
+//   of another one, cost included, is folded into it: the kept column stands for the weighted sum).
+// PSLP applies more (doubleton equations, costed singleton columns of inequality rows, bound propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
 //   min c.x  s.t.  AL <= A x <= AU,  l <= x <= u,   z = c - A^T y,  y_i > 0 <=> row at AL.
 // Any doubt (infeasible or unbounded-looking input, nothing left to solve) makes run() return false
@@ -31,7 +31,7 @@ class Presolve {
    public:
     struct Stats {
         int fixed_cols = 0, empty_cols = 0, empty_rows = 0, singleton_rows = 0, redundant_rows = 0, passes = 0;
-        int dual_fixed_cols = 0, slack_cols = 0, parallel_rows = 0;
+        int dual_fixed_cols = 0, slack_cols = 0, parallel_rows = 0, parallel_cols = 0;
         double seconds = 0.0;
     };
     Presolve() = default;
@@ -50,7 +50,7 @@ class Presolve {
 
    private:
     bool worth_it(const LP_info_cpu *model) const;  // large models: is there enough to remove?
-    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol, SlackCol, ParallelRow };
+    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol, SlackCol, ParallelRow, ParallelCol };
     struct Record {
         Kind kind;
         int i, j;

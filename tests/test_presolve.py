@@ -296,6 +296,10 @@ def decorated_lp(seed):
         a = float(rng.choice([1.0, -2.0]))
         col = sparse.lil_matrix((m, 1)); col[i, 0] = a
         new_cols.append(col.tocsr()); nl.append(0.0); nu.append(float(rng.choice([1.5, INF]))); nc.append(0.0)
+    Acsc = A.tocsc()
+    for t, j in enumerate([j for j in range(n) if Acsc.indptr[j + 1] - Acsc.indptr[j] >= 2][: 3 + seed % 2]):
+        lam = float(rng.choice([2.0, -1.0, 0.5]))  # parallel columns: lam x column j, cost lam c_j, a finite box around 0
+        new_cols.append((Acsc[:, j] * lam).tocsr()); nl.append(-0.5 if t % 2 else 0.0); nu.append(1.2); nc.append(lam * c[j])
     A2 = sparse.hstack([A.tocsr()] + new_cols).tocsr() if new_cols else A.tocsr()
     # parallel rows: multiples of existing rows, looser on both sides or with one side only
     picks = [i for i in range(m) if A2.indptr[i + 1] - A2.indptr[i] >= 3][: 4 + seed % 3]
@@ -321,7 +325,7 @@ def test_randomised_sweep_of_all_reductions():
     """40 decorated LPs: the reduced model has the original optimum and the postsolved triple satisfies the KKT conditions
     of the original model -- the undo sequence is exercised with every mix of reductions the generator produces."""
     seen = dict(fixed_cols=0, empty_cols=0, singleton_rows=0, empty_rows=0, redundant_rows=0, dual_fixed_cols=0, slack_cols=0,
-                parallel_rows=0)
+                parallel_rows=0, parallel_cols=0)
     for seed in range(40):
         lp = decorated_lp(seed)
         try:
