@@ -7,7 +7,6 @@
 #include <cstdlib>
 #include <limits>
 #include <thread>
-#include <unordered_map>
 
 #include "HPRLP.h"
 #include "common.h"
@@ -17,9 +16,17 @@ namespace {
 
 constexpr double kFeasTol = 1e-9;  // a crossing of bounds beyond this (relative) is left to the solver
 constexpr int kMaxPasses = 50;
+constexpr size_t kMaxParallelProbe = 64;  // partners tried per row / column inside a group of equal sparsity pattern
 
 inline bool fin(double v) { return std::isfinite(v); }
 inline double rel(double v) { return kFeasTol * (1.0 + std::abs(v)); }
+// per-index term of the order-independent pattern hash of the parallel-row / parallel-column scans
+inline unsigned long long pattern_hash(int idx) {
+    unsigned long long z = static_cast<unsigned long long>(idx) + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
 
 }  // namespace
 
@@ -218,9 +225,12 @@ bool Presolve::run(const LP_info_cpu *model) {
             }
         }
         // ---- parallel rows (PSLP: Parallel_rows): row i2 = lambda * row i1 over the live columns.  Row i2 goes, row i1
-        // keeps the intersection of its own sides and row i2's sides divided by lambda.
-        {
-            std::unordered_map<unsigned long long, std::vector<int>> buckets;  // hash of the live column pattern -> rows
+        // keeps the intersection of its own sides and row i2's sides divided by lambda.  (The two parallel scans hash
+        // every live row and column: they run in the first pass and then in every fourth one.)
+        const bool scan_parallel = stats_.passes % 4 == 1;
+        if (scan_parallel) {
+            // rows grouped by an order-independent hash of their live column pattern
+            std::vector<std::pair<unsigned long long, int>> keys;
             std::vector<std::pair<int, double>> e1, e2;
             auto live_entries = [&](int i, std::vector<std::pair<int, double>> &out) {
                 out.clear();
@@ -233,22 +243,24 @@ bool Presolve::run(const LP_info_cpu *model) {
             };
             for (int i = 0; i < m; ++i) {
                 if (!row_alive[i] || row_cnt[i] < 2) continue;
-                unsigned long long h = 1469598103934665603ULL;
-                std::vector<int> cols;
+                unsigned long long h = static_cast<unsigned long long>(row_cnt[i]);
                 for (int k = rp[i]; k < rp[i + 1]; ++k)
-                    if (col_alive[ci[k]] && av[k] != 0.0) cols.push_back(ci[k]);
-                std::sort(cols.begin(), cols.end());
-                for (int cc : cols) h = (h ^ static_cast<unsigned long long>(cc + 1)) * 1099511628211ULL;
-                buckets[h].push_back(i);
+                    if (col_alive[ci[k]] && av[k] != 0.0) h += pattern_hash(ci[k]);
+                keys.emplace_back(h, i);
             }
-            for (auto &kv : buckets) {
-                std::vector<int> &rows = kv.second;
+            std::sort(keys.begin(), keys.end());
+            std::vector<int> rows;
+            for (size_t g0 = 0; g0 < keys.size() && !give_up;) {
+                size_t g1 = g0 + 1;
+                while (g1 < keys.size() && keys[g1].first == keys[g0].first) ++g1;
+                rows.clear();
+                for (size_t q = g0; q < g1; ++q) rows.push_back(keys[q].second);  // ascending row numbers
+                g0 = g1;
                 if (rows.size() < 2) continue;
-                std::sort(rows.begin(), rows.end());  // deterministic whatever the map's order
                 for (size_t p1 = 0; p1 < rows.size() && !give_up; ++p1) {
                     const int i1 = rows[p1];
                     if (!row_alive[i1] || !live_entries(i1, e1)) continue;
-                    for (size_t p2 = p1 + 1; p2 < rows.size() && !give_up; ++p2) {
+                    for (size_t p2 = p1 + 1; p2 < rows.size() && p2 - p1 <= kMaxParallelProbe && !give_up; ++p2) {
                         const int i2 = rows[p2];
                         if (!row_alive[i2] || !live_entries(i2, e2) || e2.size() != e1.size()) continue;
                         const double lambda = e2[0].second / e1[0].second;
@@ -277,8 +289,8 @@ bool Presolve::run(const LP_info_cpu *model) {
         // ---- parallel columns (PSLP: Parallel_cols): column j2 = lambda * column j1 over the live rows and c_j2 =
         // lambda * c_j1.  The pair acts through x_j1 + lambda x_j2 only: column j2 goes, column j1 stands for the sum
         // with the sum's range as its bounds.
-        {
-            std::unordered_map<unsigned long long, std::vector<int>> buckets;
+        if (scan_parallel) {
+            std::vector<std::pair<unsigned long long, int>> keys;
             std::vector<std::pair<int, double>> e1, e2;
             auto live_entries = [&](int j, std::vector<std::pair<int, double>> &out) {
                 out.clear();
@@ -291,19 +303,24 @@ bool Presolve::run(const LP_info_cpu *model) {
             };
             for (int j = 0; j < n; ++j) {
                 if (!col_alive[j] || col_cnt[j] < 2) continue;
-                if (!live_entries(j, e1)) continue;
-                unsigned long long h = 1469598103934665603ULL;
-                for (const auto &e : e1) h = (h ^ static_cast<unsigned long long>(e.first + 1)) * 1099511628211ULL;
-                buckets[h].push_back(j);
+                unsigned long long h = static_cast<unsigned long long>(col_cnt[j]);
+                for (int k = trp_[j]; k < trp_[j + 1]; ++k)
+                    if (row_alive[tci_[k]] && tv_[k] != 0.0) h += pattern_hash(tci_[k]);
+                keys.emplace_back(h, j);
             }
-            for (auto &kv : buckets) {
-                std::vector<int> &cols = kv.second;
+            std::sort(keys.begin(), keys.end());
+            std::vector<int> cols;
+            for (size_t g0 = 0; g0 < keys.size();) {
+                size_t g1 = g0 + 1;
+                while (g1 < keys.size() && keys[g1].first == keys[g0].first) ++g1;
+                cols.clear();
+                for (size_t q = g0; q < g1; ++q) cols.push_back(keys[q].second);
+                g0 = g1;
                 if (cols.size() < 2) continue;
-                std::sort(cols.begin(), cols.end());
                 for (size_t p1 = 0; p1 < cols.size(); ++p1) {
                     const int j1 = cols[p1];
                     if (!col_alive[j1] || !live_entries(j1, e1)) continue;
-                    for (size_t p2 = p1 + 1; p2 < cols.size(); ++p2) {
+                    for (size_t p2 = p1 + 1; p2 < cols.size() && p2 - p1 <= kMaxParallelProbe; ++p2) {
                         const int j2 = cols[p2];
                         if (!col_alive[j2] || !live_entries(j2, e2) || e2.size() != e1.size()) continue;
                         const double lambda = e2[0].second / e1[0].second;
