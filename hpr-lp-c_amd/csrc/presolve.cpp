@@ -359,9 +359,17 @@ bool Presolve::run(const LP_info_cpu *model) {
                     break;
                 }
             if (i < 0 || row_cnt[i] < 2) continue;
-            const bool equality = fin(AL[i]) && AL[i] == AU[i];
+            bool equality = fin(AL[i]) && AL[i] == AU[i];
             const double cj = cost[j];
-            if (!equality && cj != 0.0) continue;
+            if (!equality && cj != 0.0) {
+                // a FREE column with a cost: its reduced cost must vanish, so y_i = c_j / a is known and not zero -- the
+                // row is active on the matching side in every optimal solution and may be treated as that equality
+                if (fin(l[j]) || fin(u[j])) continue;
+                const double side = (cj / a > 0.0) ? AL[i] : AU[i];
+                if (!fin(side)) continue;  // unbounded direction: the solver sees it
+                AL[i] = AU[i] = side;
+                equality = true;
+            }
             const double ratio = cj / a;
             if (!fin(ratio)) continue;
             const double lo = a > 0 ? AL[i] - a * u[j] : AL[i] - a * l[j];  // -inf when that bound of x_j is infinite

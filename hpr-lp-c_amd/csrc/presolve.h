@@ -11,7 +11,8 @@
 //   zero: the row's sides widen by the column's range), parallel rows (a row that is a multiple of another one over
 //   the live columns is folded into it: intersection of the sides) and parallel columns (a column that is a multiple
 //   of another one, cost included, is folded into it: the kept column stands for the weighted sum).
-// PSLP applies more (doubleton equations, costed singleton columns of inequality rows, bound propagation);
+// (A free singleton column with a cost turns its row into the equality its multiplier c_j / a demands first.)
+// PSLP applies more (doubleton equations, implied-free singleton columns, bound propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
 //   min c.x  s.t.  AL <= A x <= AU,  l <= x <= u,   z = c - A^T y,  y_i > 0 <=> row at AL.
 // Any doubt (infeasible or unbounded-looking input, nothing left to solve) makes run() return false

@@ -296,6 +296,12 @@ def decorated_lp(seed):
         a = float(rng.choice([1.0, -2.0]))
         col = sparse.lil_matrix((m, 1)); col[i, 0] = a
         new_cols.append(col.tocsr()); nl.append(0.0); nu.append(float(rng.choice([1.5, INF]))); nc.append(0.0)
+    for t, i in enumerate(one_sided[6:8]):  # free columns with a cost that pushes them against the row's finite side
+        only_up = np.isfinite(AU[i])
+        a = float(rng.choice([1.0, 2.0]))
+        col = sparse.lil_matrix((m, 1)); col[i, 0] = a
+        # row <= AU: raising x_j is blocked by the row, so a negative cost is bounded; row >= AL: positive cost
+        new_cols.append(col.tocsr()); nl.append(-INF); nu.append(INF); nc.append(-0.35 if only_up else 0.35)
     Acsc = A.tocsc()
     for t, j in enumerate([j for j in range(n) if Acsc.indptr[j + 1] - Acsc.indptr[j] >= 2][: 3 + seed % 2]):
         lam = float(rng.choice([2.0, -1.0, 0.5]))  # parallel columns: lam x column j, cost lam c_j, a finite box around 0
@@ -344,6 +350,28 @@ def test_randomised_sweep_of_all_reductions():
         assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-8, (seed, k, pre.stats)
         pre.free(); model.free()
     assert all(v > 0 for v in seen.values()), seen
+
+
+def test_free_singleton_column_with_a_cost():
+    """min 0.5 f + x1 + 2 x2  s.t.  f + x1 + x2 >= 2 (row 0),  1 <= x1 + 3 x2 <= 4 (row 1),  0 <= x1, x2 <= 5,  f free.
+    f appears in row 0 only and is free, so z_f = 0 forces y_0 = 0.5 > 0: row 0 is active at 2 in every optimum and f is
+    substituted out as in an equality row; row 0 disappears with it."""
+    rp = np.array([0, 3, 5], np.int32); ci = np.array([0, 1, 2, 1, 2], np.int32); v = np.array([1.0, 1.0, 1.0, 1.0, 3.0])
+    AL, AU = np.array([2.0, 1.0]), np.array([INF, 4.0])
+    l, u, c = np.array([-INF, 0.0, 0.0]), np.array([INF, 5.0, 5.0]), np.array([0.5, 1.0, 2.0])
+    model = hprlp.Model.from_csr(2, 3, rp, ci, v, AL, AU, l, u, c)
+    f0, x0, y0, z0 = highs(2, 3, rp, ci, v, AL, AU, l, u, c)
+    pre = hprlp.Presolved(model)
+    assert pre.stats["slack_cols"] == 1 and pre.reduced.m == 1 and pre.reduced.n == 2
+    rm, rn, rp2, ci2, v2, rAL, rAU, rl, ru, rc = reduced_arrays(pre)
+    np.testing.assert_allclose(rc, [0.5, 1.5])  # c_k - (c_f / a) a_0k
+    fr, xr, yr, zr = highs(rm, rn, rp2, ci2, v2, rAL, rAU, rl, ru, rc)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-12
+    x, y, z = pre.postsolve(xr, yr, zr)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-12, k
+    assert y[0] == 0.5 and z[0] == 0.0 and abs(x[0] + x[1] + x[2] - 2.0) <= 1e-12
+    pre.free(); model.free()
 
 
 def test_presolve_declines(model_mps_arrays):
