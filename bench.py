@@ -323,6 +323,9 @@ def main():
                          "yhalf_GBps": ((12 * nnz + 4 * (m + P) + 40 * m) / P + 8 * n) / (y_ms * 1e-3) / 1e9,
                          "iteration_GBps": bytes_per_iteration(m, n, nnz) / P / (1e-3 * (x_ms + y_ms)) / 1e9},
             "kkt_after_run": res["kkt"], "finite": bool(ok),
+            # outside the timed region (rank 0): device set-up incl. transpose and tiled copies, scaling, power iteration
+            "phases_s": {"device_setup": sc["setup_time"], "scaling": sc["scaling_time"], "power_iteration": sc["power_time"],
+                         "power_iterations": int(pw_it)},
         }
         if spmv is not None:
             # SpMV-only figure B_spmv = 12 nnz + 4 (rows+1) + 8 cols + 8 rows over the bare kernel's time,
