@@ -115,7 +115,7 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
     const Presolve::Stats &st = pre.stats();
     std::cout << "Presolve reduced problem: (" << model->m << ", " << model->n << ") -> (" << pre.reduced()->m << ", "
               << pre.reduced()->n << ")  [fixed cols " << st.fixed_cols << ", empty cols " << st.empty_cols
-              << ", dual-fixed cols " << st.dual_fixed_cols << ", slack cols " << st.slack_cols << ", parallel rows " << st.parallel_rows << ", parallel cols " << st.parallel_cols << ", singleton rows " << st.singleton_rows << ", empty rows " << st.empty_rows << ", redundant rows "
+              << ", dual-fixed cols " << st.dual_fixed_cols << ", slack cols " << st.slack_cols << ", parallel rows " << st.parallel_rows << ", parallel cols " << st.parallel_cols << ", forcing rows " << st.forcing_rows << ", singleton rows " << st.singleton_rows << ", empty rows " << st.empty_rows << ", redundant rows "
               << st.redundant_rows << "]" << std::endl;
     HPRLP_results r = HPRLP_main_solve(pre.reduced(), p);
     if (!(r.x && r.y && r.z)) return r;
@@ -164,12 +164,13 @@ extern "C" hprlp_presolve *hprlp_presolve_run(const LP_info_cpu *model) {
     return nullptr;
 }
 extern "C" const LP_info_cpu *hprlp_presolve_reduced(const hprlp_presolve *h) { return h ? h->p.reduced() : nullptr; }
-extern "C" int hprlp_presolve_stats(const hprlp_presolve *h, int out[12]) {
+extern "C" int hprlp_presolve_stats(const hprlp_presolve *h, int out[16]) {
     if (!h || !out) return -1;
     const Presolve::Stats &s = h->p.stats();
     out[0] = h->p.reduced()->m; out[1] = h->p.reduced()->n; out[2] = s.fixed_cols; out[3] = s.empty_cols;
     out[4] = s.singleton_rows; out[5] = s.empty_rows; out[6] = s.redundant_rows; out[7] = s.passes;
     out[8] = s.dual_fixed_cols; out[9] = s.slack_cols; out[10] = s.parallel_rows; out[11] = s.parallel_cols;
+    out[12] = s.forcing_rows; out[13] = out[14] = out[15] = 0;
     return 0;
 }
 extern "C" int hprlp_presolve_postsolve(const hprlp_presolve *h, const double *xr, const double *yr, const double *zr,

@@ -222,6 +222,29 @@ bool Presolve::run(const LP_info_cpu *model) {
                 drop_row(i, RedundantRow);
                 ++stats_.redundant_rows;
                 changed = true;
+                continue;
+            }
+            // forcing row: the smallest activity the box allows already sits on the upper side (or the largest on the
+            // lower side) -- every column of the row is pinned to the bound that realises it
+            const bool force_min = fin(AU[i]) && !lo_inf && std::abs(lo_act - AU[i]) <= rel(AU[i]);
+            const bool force_max = fin(AL[i]) && !up_inf && std::abs(up_act - AL[i]) <= rel(AL[i]);
+            if (force_min || force_max) {
+                std::vector<int> live;
+                for (int k = rp[i]; k < rp[i + 1]; ++k)
+                    if (col_alive[ci[k]] && av[k] != 0.0) live.push_back(ci[k]);
+                std::sort(live.begin(), live.end());
+                if (std::adjacent_find(live.begin(), live.end()) != live.end()) continue;  // repeated column index: leave it
+                const int cnt = static_cast<int>(live.size());
+                drop_row(i, SingletonRow);  // (no record of its own from drop_row)
+                stack_.push_back(Record{ForcingRow, i, cnt, force_min ? -1.0 : 1.0, 0.0, 0.0, 0.0, 0.0, 0.0});
+                for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                    const int j = ci[k];
+                    if (!col_alive[j] || av[k] == 0.0) continue;
+                    const bool at_lower = (av[k] > 0) == force_min;
+                    fix_column(j, at_lower ? l[j] : u[j], FixedCol);
+                }
+                ++stats_.forcing_rows;
+                changed = true;
             }
         }
         // ---- parallel rows (PSLP: Parallel_rows): row i2 = lambda * row i1 over the live columns.  Row i2 goes, row i1
@@ -557,6 +580,29 @@ void Presolve::postsolve(const double *xr, const double *yr, const double *zr, d
                 } else {
                     y[r.i] = 0.0;
                 }
+                break;
+            }
+            case ForcingRow: {
+                // the r.j records above this one (already undone) are the columns the row pinned; their reduced costs were
+                // formed with y_i = 0.  r.a = -1: row on its upper side, columns at the bound of least activity -- the
+                // multiplier is the largest y <= 0 that leaves every one of them the sign its bound needs; r.a = +1: mirrored.
+                double yi = 0.0;
+                for (int q = 1; q <= r.j; ++q) {
+                    const Record &c = stack_[s + q];
+                    double a = 0.0;
+                    for (int k = trp_[c.j]; k < trp_[c.j + 1]; ++k)
+                        if (tci_[k] == r.i) a += tv_[k];
+                    if (a == 0.0) continue;
+                    const double cand = z[c.j] / a;
+                    yi = r.a < 0.0 ? std::min(yi, cand) : std::max(yi, cand);
+                }
+                y[r.i] = yi;
+                if (yi != 0.0)
+                    for (int q = 1; q <= r.j; ++q) {
+                        const Record &c = stack_[s + q];
+                        for (int k = trp_[c.j]; k < trp_[c.j + 1]; ++k)
+                            if (tci_[k] == r.i) z[c.j] -= tv_[k] * yi;
+                    }
                 break;
             }
             case EmptyRow:

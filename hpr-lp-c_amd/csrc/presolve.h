@@ -10,7 +10,8 @@
 //   eliminated when the row is an equality -- its cost moves onto the row's other columns -- or when its cost is
 //   zero: the row's sides widen by the column's range), parallel rows (a row that is a multiple of another one over
 //   the live columns is folded into it: intersection of the sides) and parallel columns (a column that is a multiple
-//   of another one, cost included, is folded into it: the kept column stands for the weighted sum).
+//   of another one, cost included, is folded into it: the kept column stands for the weighted sum), forcing rows (the
+//   box allows only one activity inside the row's sides: every column of the row is pinned to the bound realising it).
 // (A free singleton column with a cost turns its row into the equality its multiplier c_j / a demands first.)
 // PSLP applies more (doubleton equations, implied-free singleton columns, bound propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
@@ -32,7 +33,7 @@ class Presolve {
    public:
     struct Stats {
         int fixed_cols = 0, empty_cols = 0, empty_rows = 0, singleton_rows = 0, redundant_rows = 0, passes = 0;
-        int dual_fixed_cols = 0, slack_cols = 0, parallel_rows = 0, parallel_cols = 0;
+        int dual_fixed_cols = 0, slack_cols = 0, parallel_rows = 0, parallel_cols = 0, forcing_rows = 0;
         double seconds = 0.0;
     };
     Presolve() = default;
@@ -51,7 +52,7 @@ class Presolve {
 
    private:
     bool worth_it(const LP_info_cpu *model) const;  // large models: is there enough to remove?
-    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol, SlackCol, ParallelRow, ParallelCol };
+    enum Kind : int { FixedCol, EmptyCol, EmptyRow, SingletonRow, RedundantRow, DualFixCol, SlackCol, ParallelRow, ParallelCol, ForcingRow };
     struct Record {
         Kind kind;
         int i, j;

@@ -259,9 +259,9 @@ class Presolved:
         if not self.h:
             raise RuntimeError(last_error())
         self.reduced = Model(lib().hprlp_presolve_reduced(self.h))
-        out = (C.c_int * 12)()
+        out = (C.c_int * 16)()
         lib().hprlp_presolve_stats(self.h, out)
-        keys = ("m", "n", "fixed_cols", "empty_cols", "singleton_rows", "empty_rows", "redundant_rows", "passes", "dual_fixed_cols", "slack_cols", "parallel_rows", "parallel_cols")
+        keys = ("m", "n", "fixed_cols", "empty_cols", "singleton_rows", "empty_rows", "redundant_rows", "passes", "dual_fixed_cols", "slack_cols", "parallel_rows", "parallel_cols", "forcing_rows")
         self.stats = dict(zip(keys, [int(v) for v in out]))
 
     def postsolve(self, xr, yr, zr):

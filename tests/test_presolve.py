@@ -319,6 +319,24 @@ def decorated_lp(seed):
             lo_n, up_n = lo_i, INF
         a, b = lam * lo_n, lam * up_n
         extra_rows.append(A2[i] * lam); eAL.append(min(a, b)); eAU.append(max(a, b))
+    # forcing rows: over columns that sit at their lower bound in the planted point (so the LP stays feasible), the least
+    # (or, with negative coefficients, the largest) activity the box allows is made the row's only feasible value
+    m0, n0 = 30 + seed % 7, 45 + seed % 11
+    xs = lpgen.planted_lp(m0, n0, 6 * m0, seed)["x_star"]
+    at_low = [j for j in range(n0) if np.isfinite(l[j]) and xs[j] == l[j] and u[j] > l[j]]
+    for t in range(min(2, len(at_low) // 3)):
+        cols = at_low[3 * t: 3 * t + 3]
+        sign = 1.0 if (seed + t) % 2 == 0 else -1.0
+        vals = sign * np.array([1.0, 2.0, 0.5])
+        act = float(sum(a * l[j] for a, j in zip(vals, cols)))
+        r = sparse.lil_matrix((1, A2.shape[1]))
+        for a, j in zip(vals, cols):
+            r[0, j] = a
+        extra_rows.append(r.tocsr())
+        if sign > 0:
+            eAL.append(-INF); eAU.append(act)   # activity <= its own minimum
+        else:
+            eAL.append(act); eAU.append(INF)    # activity >= its own maximum
     if extra_rows:
         A2 = sparse.vstack([A2] + extra_rows).tocsr()
         AL, AU = np.concatenate([AL, eAL]), np.concatenate([AU, eAU])
@@ -331,7 +349,7 @@ def test_randomised_sweep_of_all_reductions():
     """40 decorated LPs: the reduced model has the original optimum and the postsolved triple satisfies the KKT conditions
     of the original model -- the undo sequence is exercised with every mix of reductions the generator produces."""
     seen = dict(fixed_cols=0, empty_cols=0, singleton_rows=0, empty_rows=0, redundant_rows=0, dual_fixed_cols=0, slack_cols=0,
-                parallel_rows=0, parallel_cols=0)
+                parallel_rows=0, parallel_cols=0, forcing_rows=0)
     for seed in range(40):
         lp = decorated_lp(seed)
         try:
