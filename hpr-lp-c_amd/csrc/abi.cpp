@@ -117,7 +117,32 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
               << pre.reduced()->n << ")  [fixed cols " << st.fixed_cols << ", empty cols " << st.empty_cols
               << ", dual-fixed cols " << st.dual_fixed_cols << ", slack cols " << st.slack_cols << ", parallel rows " << st.parallel_rows << ", parallel cols " << st.parallel_cols << ", forcing rows " << st.forcing_rows << ", singleton rows " << st.singleton_rows << ", empty rows " << st.empty_rows << ", redundant rows "
               << st.redundant_rows << "]" << std::endl;
-    HPRLP_results r = HPRLP_main_solve(pre.reduced(), p);
+    // The stopping test is relative to 1 + |b| and 1 + |c| of the model it runs on, and slack substitution moves cost
+    // between columns (|c| of the reduced model can be several times the original's): the same absolute residuals would
+    // then pass on the reduced model and fail the original-model check below.  Hand the reduced solve the tolerance
+    // that corresponds to stop_tol on the ORIGINAL norms.
+    auto norm_bc = [](const LP_info_cpu *mod, double *nb, double *nc) {
+        double sb = 0.0, sc = 0.0;
+        for (int i = 0; i < mod->m; ++i) {
+            const double a = std::isinf(mod->AL[i]) ? 0.0 : std::abs(mod->AL[i]), b = std::isinf(mod->AU[i]) ? 0.0 : std::abs(mod->AU[i]);
+            const double v = std::max(a, b);
+            sb += v * v;
+        }
+        for (int j = 0; j < mod->n; ++j) sc += mod->c[j] * mod->c[j];
+        *nb = std::sqrt(sb);
+        *nc = std::sqrt(sc);
+    };
+    double nb0, nc0, nb1, nc1;
+    norm_bc(model, &nb0, &nc0);
+    norm_bc(pre.reduced(), &nb1, &nc1);
+    HPRLP_parameters pr = *p;
+    const double shrink = std::min(1.0, std::min((1.0 + nb0) / (1.0 + nb1), (1.0 + nc0) / (1.0 + nc1)));
+    if (shrink < 1.0) {
+        pr.stop_tol = p->stop_tol * shrink;
+        std::cout << "Reduced-model tolerance " << pr.stop_tol << " (original norms |b| " << nb0 << ", |c| " << nc0 << "; reduced "
+                  << nb1 << ", " << nc1 << ")" << std::endl;
+    }
+    HPRLP_results r = HPRLP_main_solve(pre.reduced(), &pr);
     if (!(r.x && r.y && r.z)) return r;
     double *x = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->n, 1)));
     double *y = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->m, 1)));

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <string>
 #include <thread>
 
 #include "HPRLP.h"
@@ -16,6 +17,7 @@ namespace {
 
 constexpr double kFeasTol = 1e-9;  // a crossing of bounds beyond this (relative) is left to the solver
 constexpr int kMaxPasses = 50;
+constexpr double kSlackPivot = 0.5;  // a costed slack column is substituted only if |a_ij| >= this * max_k |a_ik|
 constexpr size_t kMaxParallelProbe = 64;  // partners tried per row / column inside a group of equal sparsity pattern
 
 inline bool fin(double v) { return std::isfinite(v); }
@@ -118,6 +120,13 @@ bool Presolve::run(const LP_info_cpu *model) {
             }
     double offset = 0.0;
     bool give_up = false;
+    // HPRLP_PRESOLVE_OFF=slack,dualfix,parallel,forcing switches reductions off (diagnostics)
+    const char *off_env = std::getenv("HPRLP_PRESOLVE_OFF");
+    const std::string off = off_env ? off_env : "";
+    const bool use_slack = off.find("slack") == std::string::npos, use_dualfix = off.find("dualfix") == std::string::npos;
+    const bool use_parallel = off.find("parallel") == std::string::npos, use_forcing = off.find("forcing") == std::string::npos;
+    const char *sp_env = std::getenv("HPRLP_SLACK_PIVOT");
+    const double slack_pivot = sp_env ? std::atof(sp_env) : kSlackPivot;
 
     auto fix_column = [&](int j, double v, Kind kind) {
         for (int k = trp_[j]; k < trp_[j + 1]; ++k) {
@@ -228,7 +237,7 @@ bool Presolve::run(const LP_info_cpu *model) {
             // lower side) -- every column of the row is pinned to the bound that realises it
             const bool force_min = fin(AU[i]) && !lo_inf && std::abs(lo_act - AU[i]) <= rel(AU[i]);
             const bool force_max = fin(AL[i]) && !up_inf && std::abs(up_act - AL[i]) <= rel(AL[i]);
-            if (force_min || force_max) {
+            if (use_forcing && (force_min || force_max)) {
                 std::vector<int> live;
                 for (int k = rp[i]; k < rp[i + 1]; ++k)
                     if (col_alive[ci[k]] && av[k] != 0.0) live.push_back(ci[k]);
@@ -250,7 +259,7 @@ bool Presolve::run(const LP_info_cpu *model) {
         // ---- parallel rows (PSLP: Parallel_rows): row i2 = lambda * row i1 over the live columns.  Row i2 goes, row i1
         // keeps the intersection of its own sides and row i2's sides divided by lambda.  (The two parallel scans hash
         // every live row and column: they run in the first pass and then in every fourth one.)
-        const bool scan_parallel = stats_.passes % 4 == 1;
+        const bool scan_parallel = use_parallel && stats_.passes % 4 == 1;
         if (scan_parallel) {
             // rows grouped by an order-independent hash of their live column pattern
             std::vector<std::pair<unsigned long long, int>> keys;
@@ -371,7 +380,7 @@ bool Presolve::run(const LP_info_cpu *model) {
         // and either the row is an equality (any cost) or c_j = 0.  x_j is eliminated: the row becomes
         //   AL - a u_j <= sum_k a_ik x_k <= AU - a l_j   (a > 0; bounds swapped for a < 0)
         // and, in the equality case, c_j x_j = c_j (b - sum_k a_ik x_k) / a moves onto the other columns' costs.
-        for (int j = 0; j < n && !give_up; ++j) {
+        for (int j = 0; j < n && !give_up && use_slack; ++j) {
             if (!col_alive[j] || col_cnt[j] != 1) continue;
             int i = -1;
             double a = 0.0;
@@ -395,6 +404,14 @@ bool Presolve::run(const LP_info_cpu *model) {
             }
             const double ratio = cj / a;
             if (!fin(ratio)) continue;
+            if (cj != 0.0) {
+                // the cost moves onto the row's other columns multiplied by a_ik / a: only behind a pivot that is not small
+                // for its row, or |c| of the reduced model (and with it the meaning of the relative tolerance) blows up
+                double row_max = 0.0;
+                for (int k = rp[i]; k < rp[i + 1]; ++k)
+                    if (col_alive[ci[k]]) row_max = std::max(row_max, std::abs(av[k]));
+                if (std::abs(a) < slack_pivot * row_max) continue;
+            }
             const double lo = a > 0 ? AL[i] - a * u[j] : AL[i] - a * l[j];  // -inf when that bound of x_j is infinite
             const double up = a > 0 ? AU[i] - a * l[j] : AU[i] - a * u[j];
             if (std::isnan(lo) || std::isnan(up)) continue;
@@ -414,7 +431,7 @@ bool Presolve::run(const LP_info_cpu *model) {
         // ---- dual fixing (PSLP: Simple_dual_fix): a column whose cost and whose rows all push it the same way sits at
         // that bound in some optimal solution.  Down: c_j >= 0 and lowering x_j can violate no row (positive entries
         // only in rows without a lower side, negative entries only in rows without an upper side); up: mirrored.
-        for (int j = 0; j < n && !give_up; ++j) {
+        for (int j = 0; j < n && !give_up && use_dualfix; ++j) {
             if (!col_alive[j] || col_cnt[j] == 0) continue;
             const double c = cost[j];
             bool down_ok = c >= 0.0 && fin(l[j]), up_ok = c <= 0.0 && fin(u[j]);
