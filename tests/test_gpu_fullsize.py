@@ -1,0 +1,59 @@
+"""BASELINE config 5 at full size on one GPU (10M x 10M, 2e8 nonzeros): properties that do not need the oracle
+(it would take minutes there) -- the planted optimum is reached in the known number of iterations, the returned
+primal-dual triple passes an independent KKT evaluation on the original model, the run is bit-reproducible, and the
+set-up paths that only large matrices take (device transpose, device-built tiled copies, persistent rotated schedule)
+are the ones that ran."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config5_full_size_properties(gpu):
+    import bench as B
+    H = B.H
+    m, n, per_row, band = B.WORKLOADS["c5"]
+    lp = B.banded_lp(m, n, per_row, band)
+    model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    for k in ("rowptr", "colind", "values"):
+        lp.pop(k)
+    prm = H.Parameters(stop_tol=1e-4, use_presolve=False)
+
+    # step-level: both matrices tiled
+    s = H.Solver(model, prm)
+    assert s.info()["tiled"] == 3
+    s.scale()
+    lam, it = s.power_iteration()
+    assert it == 290 and lam > 0
+    s.init(-1.0, lam * 1.01)
+    s.iterate(3, True)
+    res = s.residuals(4, True)
+    assert np.isfinite(res["kkt"]) and res["kkt"] < 1.0 + 1e-6
+    state1 = {k: s.get(k) for k in ("x", "y")}
+    s.close()
+
+    s2 = H.Solver(model, prm)
+    s2.scale()
+    lam2, it2 = s2.power_iteration()
+    s2.init(-1.0, lam2 * 1.01)
+    s2.iterate(3, True)
+    state2 = {k: s2.get(k) for k in ("x", "y")}
+    s2.close()
+    assert lam == lam2 and it == it2
+    for k in state1:
+        assert np.array_equal(state1[k], state2[k]), k  # bit-reproducible at full size
+
+    # whole solve: planted optimum, the iteration count every earlier run of this LP took
+    r = model.solve(prm)
+    assert r.status == "OPTIMAL" and r.iter == 480
+    assert abs(r.primal_obj - lp["obj_star"]) <= 2e-4 * (1 + abs(lp["obj_star"]))
+    # independent KKT of the returned triple on the ORIGINAL model (host loops over 2e8 entries in C)
+    k = H.original_kkt(model, r.x, r.y, r.z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 2e-4, k
+    model.free()
