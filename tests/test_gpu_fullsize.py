@@ -57,3 +57,47 @@ def test_config5_full_size_properties(gpu):
     k = H.original_kkt(model, r.x, r.y, r.z)
     assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 2e-4, k
     model.free()
+
+
+def test_config5_sharded_over_four_thread_ranks(gpu):
+    """The same LP row-partitioned over 4 ranks (host threads of this process on the one GPU: device copies and host
+    barriers in place of RCCL): neighbour exchange chosen, tiled shards, exchange/compute overlap on, and the solve ends
+    where the single-GPU solve ends."""
+    import threading
+    import bench as B
+    H = B.H
+    m, n, per_row, band = B.WORKLOADS["c5"]
+    lp = B.banded_lp(m, n, per_row, band)
+    model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    for k in ("rowptr", "colind", "values"):
+        lp.pop(k)
+    prm = H.Parameters(stop_tol=1e-4, use_presolve=False)
+    world = 4
+    group = H.Solver.local_group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            s = H.Solver.create_local(model, prm, rank, world, group)
+            s.scale()
+            lam, _ = s.power_iteration()
+            s.init(-1.0, lam * 1.01)
+            r = s.run()
+            out[rank] = dict(status=r.status, iters=r.iter, obj=r.primal_obj, info=s.dist_info(), tiled=s.info()["tiled"])
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            err[rank] = repr(e)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    H.Solver.free_local_group(group)
+    model.free()
+    assert not any(err), err
+    for o in out:
+        assert o["status"] == "OPTIMAL" and o["iters"] == 480
+        assert abs(o["obj"] - lp["obj_star"]) <= 2e-4 * (1 + abs(lp["obj_star"]))
+        assert o["info"]["m_sparse"] == 1 and o["info"]["n_sparse"] == 1 and o["tiled"] == 3
+        assert 0 < o["info"]["m_received"] < 0.3 * m
