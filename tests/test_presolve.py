@@ -452,3 +452,23 @@ def test_solve_with_presolve_matches_solve_without(gpu):
     k = hprlp.original_kkt(model, on.x, on.y, on.z)
     assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-6, k
     model.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3, 8, 12, 21, 30])
+def test_gpu_solve_of_decorated_lps_with_presolve(gpu, seed):
+    """End to end on the GPU: solve() with the presolver on, for LPs that trigger every reduction; the returned triple (in
+    the ORIGINAL dimensions) has the exact solver's optimum and passes the original-model KKT evaluation."""
+    lp = decorated_lp(seed)
+    try:
+        f0, *_ = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    except AssertionError:
+        pytest.skip("this decoration is infeasible or unbounded")
+    model = make_model(lp)
+    r = model.solve(hprlp.Parameters(stop_tol=1e-7, use_presolve=True, max_iter=400000))
+    assert r.status == "OPTIMAL"
+    assert abs(r.primal_obj - f0) <= 1e-5 * (1 + abs(f0))
+    k = hprlp.original_kkt(model, r.x, r.y, r.z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-5, k
+    assert len(r.x) == lp["n"] and len(r.y) == lp["m"]
+    model.free()
