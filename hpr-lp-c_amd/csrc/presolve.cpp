@@ -393,27 +393,44 @@ bool Presolve::run(const LP_info_cpu *model) {
             if (i < 0 || row_cnt[i] < 2) continue;
             bool equality = fin(AL[i]) && AL[i] == AU[i];
             const double cj = cost[j];
+            const double ratio = cj / a;
+            if (!fin(ratio)) continue;
+            double row_max = 0.0, mn = 0.0, mx = 0.0;  // largest entry of the row; activity range of its OTHER columns
+            bool mn_inf = false, mx_inf = false;
+            for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                const int c2 = ci[k];
+                if (!col_alive[c2] || av[k] == 0.0) continue;
+                row_max = std::max(row_max, std::abs(av[k]));
+                if (c2 == j) continue;
+                const double bl = av[k] > 0 ? l[c2] : u[c2], bu = av[k] > 0 ? u[c2] : l[c2];
+                if (fin(bl)) mn += av[k] * bl; else mn_inf = true;
+                if (fin(bu)) mx += av[k] * bu; else mx_inf = true;
+            }
+            // the cost moves onto the row's other columns multiplied by a_ik / a: only behind a pivot that is not small
+            // for its row, or |c| of the reduced model (and with it the meaning of the relative tolerance) blows up
+            if (cj != 0.0 && std::abs(a) < slack_pivot * row_max) continue;
+            // implied-free column: the row and the other columns' bounds already keep x_j inside [l_j, u_j] -- it
+            // counts as free (the bounds stay in the record; they only guard rounding at postsolve)
+            double lj = l[j], uj = u[j];
+            if (fin(lj) || fin(uj)) {
+                const double t_lo = (fin(AL[i]) && !mx_inf) ? AL[i] - mx : -INFINITY, t_up = (fin(AU[i]) && !mn_inf) ? AU[i] - mn : INFINITY;
+                const double x_lo = a > 0 ? t_lo / a : t_up / a, x_up = a > 0 ? t_up / a : t_lo / a;
+                if ((!fin(lj) || x_lo >= lj - rel(lj)) && (!fin(uj) || x_up <= uj + rel(uj))) {
+                    lj = -INFINITY;
+                    uj = INFINITY;
+                }
+            }
             if (!equality && cj != 0.0) {
                 // a FREE column with a cost: its reduced cost must vanish, so y_i = c_j / a is known and not zero -- the
                 // row is active on the matching side in every optimal solution and may be treated as that equality
-                if (fin(l[j]) || fin(u[j])) continue;
-                const double side = (cj / a > 0.0) ? AL[i] : AU[i];
+                if (fin(lj) || fin(uj)) continue;
+                const double side = (ratio > 0.0) ? AL[i] : AU[i];
                 if (!fin(side)) continue;  // unbounded direction: the solver sees it
                 AL[i] = AU[i] = side;
                 equality = true;
             }
-            const double ratio = cj / a;
-            if (!fin(ratio)) continue;
-            if (cj != 0.0) {
-                // the cost moves onto the row's other columns multiplied by a_ik / a: only behind a pivot that is not small
-                // for its row, or |c| of the reduced model (and with it the meaning of the relative tolerance) blows up
-                double row_max = 0.0;
-                for (int k = rp[i]; k < rp[i + 1]; ++k)
-                    if (col_alive[ci[k]]) row_max = std::max(row_max, std::abs(av[k]));
-                if (std::abs(a) < slack_pivot * row_max) continue;
-            }
-            const double lo = a > 0 ? AL[i] - a * u[j] : AL[i] - a * l[j];  // -inf when that bound of x_j is infinite
-            const double up = a > 0 ? AU[i] - a * l[j] : AU[i] - a * u[j];
+            const double lo = a > 0 ? AL[i] - a * uj : AL[i] - a * lj;  // -inf when that bound of x_j is infinite
+            const double up = a > 0 ? AU[i] - a * lj : AU[i] - a * uj;
             if (std::isnan(lo) || std::isnan(up)) continue;
             if (cj != 0.0) {
                 for (int k = rp[i]; k < rp[i + 1]; ++k)

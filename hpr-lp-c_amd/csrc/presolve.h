@@ -12,8 +12,9 @@
 //   the live columns is folded into it: intersection of the sides) and parallel columns (a column that is a multiple
 //   of another one, cost included, is folded into it: the kept column stands for the weighted sum), forcing rows (the
 //   box allows only one activity inside the row's sides: every column of the row is pinned to the bound realising it).
-// (A free singleton column with a cost turns its row into the equality its multiplier c_j / a demands first.)
-// PSLP applies more (doubleton equations, implied-free singleton columns, bound propagation);
+// (A free or implied-free singleton column with a cost turns its row into the equality its multiplier c_j / a demands
+// first; implied free: the row and the other columns' bounds already keep it inside its own bounds.)
+// PSLP applies more (doubleton equations, bound propagation);
 // tests/test_presolve.py compares both on the same LPs.  Convention (as the solver and PSLP):
 //   min c.x  s.t.  AL <= A x <= AU,  l <= x <= u,   z = c - A^T y,  y_i > 0 <=> row at AL.
 // Any doubt (infeasible or unbounded-looking input, nothing left to solve) makes run() return false

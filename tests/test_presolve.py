@@ -393,6 +393,29 @@ def test_free_singleton_column_with_a_cost():
     pre.free(); model.free()
 
 
+def test_implied_free_singleton_column():
+    """min f + 3 x1 + 0.5 x2  s.t.  f + x1 + x2 = 4 (row 0),  x1 + 2 x2 <= 2.5 (row 1),  -0.5 <= x1 - x2 <= 0.8 (row 2),
+    0 <= x1, x2 <= 1,  0 <= f <= 10.  Row 0 and the boxes of x1, x2 keep f in [2, 4]: its own bounds never bind, so it
+    counts as free, is substituted out and takes row 0 with it (the row would otherwise stay behind as a ranged row)."""
+    rp = np.array([0, 3, 5, 7], np.int32); ci = np.array([0, 1, 2, 1, 2, 1, 2], np.int32)
+    v = np.array([1.0, 1.0, 1.0, 1.0, 2.0, 1.0, -1.0])
+    AL, AU = np.array([4.0, -INF, -0.5]), np.array([4.0, 2.5, 0.8])
+    l, u, c = np.array([0.0, 0.0, 0.0]), np.array([10.0, 1.0, 1.0]), np.array([1.0, 3.0, 0.5])
+    model = hprlp.Model.from_csr(3, 3, rp, ci, v, AL, AU, l, u, c)
+    f0, x0, y0, z0 = highs(3, 3, rp, ci, v, AL, AU, l, u, c)
+    pre = hprlp.Presolved(model)
+    assert pre.stats["slack_cols"] == 1 and pre.reduced.m == 2 and pre.reduced.n == 2, pre.stats
+    rm, rn, rp2, ci2, v2, rAL, rAU, rl, ru, rc = reduced_arrays(pre)
+    np.testing.assert_allclose(rc, [2.0, -0.5])
+    fr, xr, yr, zr = highs(rm, rn, rp2, ci2, v2, rAL, rAU, rl, ru, rc)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-12
+    x, y, z = pre.postsolve(xr, yr, zr)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-12, k
+    assert 2.0 <= x[0] <= 4.0 and z[0] == 0.0 and y[0] == 1.0
+    pre.free(); model.free()
+
+
 def test_presolve_declines(model_mps_arrays):
     """Nothing to remove (the reference's model.mps) and infeasible input: the caller keeps the original model."""
     a = model_mps_arrays
