@@ -108,6 +108,32 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
         std::cerr << "[warn] presolve failed (" << e.what() << "); solving original model" << std::endl;
         reduced = false;
     }
+    if (!reduced && pre.solved()) {
+        // the reductions removed every row and column: the undo sequence alone produces a primal-dual optimum
+        std::cout << "Presolve solved the model (no rows or columns left)" << std::endl;
+        HPRLP_results r;
+        std::memset(r.status, 0, sizeof(r.status));
+        r.x = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->n, 1)));
+        r.y = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->m, 1)));
+        r.z = static_cast<double *>(std::malloc(sizeof(double) * std::max(model->n, 1)));
+        if (!r.x || !r.y || !r.z) {
+            std::free(r.x); std::free(r.y); std::free(r.z);
+            return make_error_result("ERROR");
+        }
+        pre.postsolve(nullptr, nullptr, nullptr, r.x, r.y, r.z);
+        const OriginalKkt k = original_kkt(model, r.x, r.y, r.z);
+        r.primal_obj = k.primal_obj;
+        r.gap = k.gap;
+        r.residuals = std::max(k.primal_feas, std::max(k.dual_feas, k.gap));
+        r.time = r.time4 = r.time6 = r.time8 = pre.stats().seconds;
+        r.iter = r.iter4 = r.iter6 = r.iter8 = 0;
+        std::strncpy(r.status, r.residuals <= p->stop_tol ? "OPTIMAL" : "ERROR", sizeof(r.status) - 1);
+        if (r.residuals <= p->stop_tol) return r;
+        // (cannot happen with exact arithmetic; with rounding trouble fall back to the iteration)
+        std::free(r.x); std::free(r.y); std::free(r.z);
+        std::cout << "Postsolve-only solution failed the KKT check; solving original model" << std::endl;
+        return HPRLP_main_solve(model, p);
+    }
     if (!reduced) {
         std::cout << "Presolve left the model unchanged; solving original model" << std::endl;
         return HPRLP_main_solve(model, p);

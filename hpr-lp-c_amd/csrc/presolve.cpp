@@ -491,7 +491,11 @@ bool Presolve::run(const LP_info_cpu *model) {
         if (row_alive[i]) row_of_.push_back(i);
     const int rm = static_cast<int>(row_of_.size()), rn = static_cast<int>(col_of_.size());
     stats_.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (rm == 0 || rn == 0) return false;       // nothing left for the iteration: solve the original
+    if (rn == 0) {  // every column was removed (and with them every row): the records alone give the optimum
+        solved_ = rm == 0;
+        return false;
+    }
+    if (rm == 0) return false;                  // columns without rows that no rule could place: the solver sees them
     if (rm == m && rn == n) return false;       // nothing removed
     std::vector<int> rrp(rm + 1, 0), rci;
     std::vector<double> rv, rAL(rm), rAU(rm), rl(rn), ru(rn), rc(rn);

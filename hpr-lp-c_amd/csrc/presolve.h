@@ -45,6 +45,8 @@ class Presolve {
     // Returns true when a smaller, non-empty model was produced (reduced() is then valid).
     bool run(const LP_info_cpu *model);
     const LP_info_cpu *reduced() const { return reduced_; }
+    // run() returned false because NOTHING was left: postsolve(nullptr, nullptr, nullptr, ...) yields the optimum
+    bool solved() const { return solved_; }
     const Stats &stats() const { return stats_; }
     int original_m() const { return m_; }
     int original_n() const { return n_; }
@@ -68,6 +70,7 @@ class Presolve {
     std::vector<int> row_of_, col_of_;  // reduced index -> original index
     std::vector<Record> stack_;
     LP_info_cpu *reduced_ = nullptr;
+    bool solved_ = false;
     Stats stats_;
 };
 

@@ -416,6 +416,24 @@ def test_implied_free_singleton_column():
     pre.free(); model.free()
 
 
+def test_model_solved_by_presolve_alone():
+    """min f + 3 x1 + 0.5 x2  s.t.  f + x1 + x2 = 4,  x1 + 2 x2 <= 2.5,  0 <= x1, x2 <= 1,  0 <= f <= 10: the reductions
+    remove every row and column (implied-free column, dual fixing, singleton row, empty column); solve() then returns
+    the postsolved optimum without a single iteration -- and without touching a GPU, so this runs on the CPU box."""
+    rp = np.array([0, 3, 5], np.int32); ci = np.array([0, 1, 2, 1, 2], np.int32); v = np.array([1.0, 1.0, 1.0, 1.0, 2.0])
+    AL, AU = np.array([4.0, -INF]), np.array([4.0, 2.5])
+    l, u, c = np.array([0.0, 0.0, 0.0]), np.array([10.0, 1.0, 1.0]), np.array([1.0, 3.0, 0.5])
+    model = hprlp.Model.from_csr(2, 3, rp, ci, v, AL, AU, l, u, c)
+    f0, x0, y0, z0 = highs(2, 3, rp, ci, v, AL, AU, l, u, c)
+    r = model.solve(hprlp.Parameters(stop_tol=1e-8, use_presolve=True))
+    assert r.status == "OPTIMAL" and r.iter == 0
+    assert abs(r.primal_obj - f0) <= 1e-12
+    np.testing.assert_allclose(r.x, x0, atol=1e-12)
+    k = hprlp.original_kkt(model, r.x, r.y, r.z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-12, k
+    model.free()
+
+
 def test_presolve_declines(model_mps_arrays):
     """Nothing to remove (the reference's model.mps) and infeasible input: the caller keeps the original model."""
     a = model_mps_arrays
