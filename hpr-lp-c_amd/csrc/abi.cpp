@@ -84,6 +84,22 @@ extern "C" HPRLP_results HPRLP_main_solve(const LP_info_cpu *model, const HPRLP_
     }
 }
 
+// NULL if the CSR arrays of `model` are consistent, else what is wrong with them.
+static const char *invalid_model_reason(const LP_info_cpu *model) {
+    const sparseMatrix *A = model->A;
+    if (model->m <= 0 || model->n <= 0) return "model dimensions must be positive";
+    if (!A || !A->rowPtr || !A->colIndex || !A->value) return "model matrix arrays missing";
+    if (!model->AL || !model->AU || !model->l || !model->u || !model->c) return "model vectors missing";
+    if (A->row != model->m || A->col != model->n) return "model matrix dimensions inconsistent";
+    if (A->rowPtr[0] != 0) return "row pointer array does not start at 0";
+    for (int i = 0; i < model->m; ++i)
+        if (A->rowPtr[i + 1] < A->rowPtr[i]) return "row pointer array is not monotone";
+    if (A->rowPtr[model->m] != A->numElements) return "row pointer array does not end at numElements";
+    for (int k = 0; k < A->numElements; ++k)
+        if (A->colIndex[k] < 0 || A->colIndex[k] >= model->n) return "column index out of range";
+    return nullptr;
+}
+
 // reference src/HPRLP.cu:493-524.  With use_presolve (the default) the model is first reduced on the
 // host (presolve.h -- our own in-process presolver where the reference forks a PSLP worker,
 // src/pslp_integration.cpp:628-713), the reduced model goes through HPRLP_main_solve and the result
@@ -97,6 +113,15 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
     HPRLP_parameters dflt;
     const HPRLP_parameters *p = param ? param : &dflt;
     if (!p->use_presolve) return HPRLP_main_solve(model, p);
+
+    // The presolver indexes its work arrays by the model's column indices and trusts rowPtr: a hand-built
+    // LP_info_cpu (create_model_from_arrays validates, a caller-filled struct does not) must be refused here, before
+    // any host array is touched -- without presolve DeviceMatrix::upload refuses the same models.
+    if (const char *why = invalid_model_reason(model)) {
+        set_last_error(why);
+        std::cerr << "[error] invalid model: " << why << std::endl;
+        return make_error_result("ERROR");
+    }
 
     Presolve pre;
     bool reduced = false;
@@ -317,12 +342,12 @@ static hprlp_solver *create_sharded(const LP_info_cpu *model, const HPRLP_parame
         return h;
     } catch (const std::exception &e) {
         set_last_error(e.what());
-        hprlp_free_shard(&sh);
-        if (h) {
+        if (h) {  // the solver first: a background tiling job may still read the shard arrays (its destructor joins it)
             Comm *c = h->comm;
             delete h;
             delete c;
         }
+        hprlp_free_shard(&sh);
         return nullptr;
     }
 }

@@ -178,7 +178,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
                 if (ok) tiled.compare_with(th);
             }
             pt.tick("  build tiled copy (device)");
-        } else if (rows >= min_rows && rows > 0 && nnz > 0) {
+        } else if (rows >= min_rows && rows > 0 && nnz > 0 && ci) {  // the host builder needs the host column indices
             planned_grid = ((rows + kTileRows - 1) / kTileRows + 7) / 8 * 8;
             tiling = std::async(std::launch::async, [=]() -> std::shared_ptr<TiledHost> {
                 (void)keep;  // keeps the host arrays alive for the duration of the build
@@ -1013,9 +1013,20 @@ void Solver::solve_loop(HPRLP_results *out) {
         const bool periodic = (iter % check_iter == 0);
         compute_residuals(iter, periodic && iter > 0, &r, &rs);
         const double elapsed = t_before + time_since(t_loop);
+        bool timed_out = elapsed > prm.time_limit;
+        if (comm && comm->size > 1) {
+            // the residuals are all-reduced, the clocks are not: every rank must take the same TIME_LIMIT decision, or
+            // one leaves the loop while its peers enter the next exchange (a collective hang).  Any rank over its limit
+            // stops the whole group at this event.
+            const double flag = timed_out ? 1.0 : 0.0;
+            HIP_CHECK(hipMemcpyAsync(scal.p + S_TMP1, &flag, sizeof(double), hipMemcpyHostToDevice, stream));
+            allreduce_slots(this, S_TMP1, 1);
+            fetch_scalars();
+            timed_out = scal_h[S_TMP1] > 0.0;
+        }
         if (r.kkt < prm.stop_tol) status = "OPTIMAL";
         else if (at_limit) status = "ITER_LIMIT";
-        else if (elapsed > prm.time_limit) status = "TIME_LIMIT";
+        else if (timed_out) status = "TIME_LIMIT";
         if (periodic && !at_limit) check_restart(&rs, iter, check_iter, sigma, verbose);
         else rs.flag = 0;
         if (trace && trace_n < trace_cap)

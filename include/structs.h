@@ -13,6 +13,7 @@
 #ifndef HPRLP_STRUCTS_H
 #define HPRLP_STRUCTS_H
 
+#include <math.h>   /* INFINITY / HUGE_VAL for callers' bounds: the reference headers pull <cmath> in transitively */
 #include <stddef.h>
 #include <stdint.h>
 

@@ -142,3 +142,52 @@ def test_banded_generator_is_row_consistent():
     assert (np.diff(c, axis=1) > 0).all() and c.min() >= 0 and c.max() < 5000
     near = np.abs(c - np.arange(5000)[:, None]) <= 121
     assert 0.90 < near.mean() < 0.99
+
+
+@pytest.mark.parametrize("bad", ["col_range", "col_negative", "decreasing", "rowptr_end", "dims"])
+def test_solve_with_presolve_refuses_a_corrupt_hand_built_model(bad, model_mps_arrays, capfd):
+    """solve() presolves by default, on the host, BEFORE anything is uploaded: a caller-filled LP_info_cpu with a bad
+    index must come back as status ERROR, not as an out-of-bounds host access (create_model_from_arrays validates;
+    a hand-built struct -- what the Julia/MATLAB bindings could pass -- does not go through it)."""
+    a = model_mps_arrays
+    rp = np.array(a["rowptr"], np.int32); ci = np.array(a["colind"], np.int32); v = np.array(a["values"])
+    vec = {k: np.array(a[k], np.float64) for k in ("AL", "AU", "l", "u", "c")}
+    if bad == "col_range": ci[3] = 1 << 20
+    if bad == "col_negative": ci[0] = -7
+    if bad == "decreasing": rp[1] = 5
+    if bad == "rowptr_end": rp[2] = 3
+    A = hprlp.CSparseMatrix(row=2, col=3 if bad == "dims" else 2, numElements=4,
+                            colIndex=ci.ctypes.data_as(hprlp.c_int_p), rowPtr=rp.ctypes.data_as(hprlp.c_int_p),
+                            value=v.ctypes.data_as(hprlp.c_dbl_p))
+    lp = hprlp.CLPInfo(m=2, n=2, A=C.pointer(A), obj_constant=0.0,
+                       **{k: x.ctypes.data_as(hprlp.c_dbl_p) for k, x in vec.items()})
+    L = hprlp.lib()
+    prm = hprlp.Parameters(use_presolve=True).to_c()
+    L.solve.restype = hprlp.CResults
+    r = L.solve(C.byref(lp), C.byref(prm))
+    assert r.status.decode() == "ERROR" and not r.x and not r.y and not r.z
+    assert "invalid model" in capfd.readouterr().err
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("src", ["examples/c/example_direct_lp.c", "examples/c/example_mps_file.c",
+                                 "examples/c/example_batched_lp.c", "examples/cpp/example_direct_lp.cpp",
+                                 "examples/cpp/example_mps_file.cpp", "src/solve_mps_file.cpp"])
+def test_reference_examples_compile_and_link_unchanged(src, tmp_path):
+    """Drop-in boundary: every example of the reference and its CLI driver must compile against include/ and link
+    against lib/libhprlp.so as they are (the reference builds the "C" ones as C++ too, examples/c/Makefile:45).
+    example_direct_lp.cpp uses INFINITY with only <iostream>/<iomanip>/HPRLP.h included."""
+    path = os.path.join(REF, src)
+    if not os.path.exists(path):
+        pytest.skip(f"{src} not in this reference checkout")
+    exe = str(tmp_path / "a.out")
+    cmd = ["g++", "-std=c++11", "-x", "c++", "-I" + INC, path, "-o", exe, "-L" + os.path.join(ROOT, "lib"), "-lhprlp",
+           "-Wl,-rpath," + os.path.join(ROOT, "lib")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # the symbols it binds are ours
+    nm = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    assert re.search(r"\b(solve|create_model_from_arrays|create_model_from_mps|solve_batched)\b", nm)

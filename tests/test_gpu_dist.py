@@ -203,3 +203,38 @@ def test_sharded_solver_other_forms_of_the_exchange(gpu, switch):
         model.free()
     finally:
         del os.environ[switch]
+
+
+def test_time_limit_is_a_collective_decision(gpu):
+    """A tiny time_limit: every rank must leave the loop with TIME_LIMIT at the SAME iteration (each rank reads its
+    own clock; the stop flag is all-reduced -- a rank that went on alone would hang in the next exchange)."""
+    import threading
+    lp = lpgen.planted_lp(401, 653, 4000, 92)
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+    world = 3
+    group = hprlp.Solver.local_group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            # rank 0 is over its limit at the first event, the others would not be for an hour
+            prm = hprlp.Parameters(stop_tol=1e-14, use_presolve=False, time_limit=0.0 if rank == 0 else 3600.0)
+            s = hprlp.Solver.create_local(model, prm, rank, world, group)
+            s.scale()
+            lam, _ = s.power_iteration()
+            s.init(-1.0, lam * 1.01)
+            out[rank] = s.run()
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            err[rank] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    hprlp.Solver.free_local_group(group)
+    assert all(e is None for e in err), err
+    assert {(o.status, o.iter) for o in out} == {("TIME_LIMIT", 0)}
+    model.free()
