@@ -92,3 +92,64 @@ def test_batched_bad_arguments(gpu, model_mps_arrays):
     L.free_batched_results(C.byref(res))
     assert not res.status and res.batch_size == 0
     model.free()
+
+
+def test_config4_full_size_against_oracle_and_single_solves(gpu):
+    """BASELINE config 4 at its real size: the config-3 matrix (33 874 x 105 728), B = 64 perturbed members (bounded:
+    the recipe's c perturbation makes members with infinite upper bounds unbounded), tolerance 1e-4.
+    (i) 8 sampled members against the oracle's solve_batched (reference src/batched_solver.cu:1017-1084 restated) run on
+    exactly those 8 -- members only share A and lambda_max, so a member's trajectory does not depend on the batch it is
+    in: same status, same stopping iteration (a member may fork at a thresholded restart decision), same objective;
+    (ii) all 64 against the single-LP path (HPRLP_main_solve, different scaling => different iteration counts): same
+    optimum within the tolerance, and the batched result passes the KKT conditions recomputed here on the unscaled LP."""
+    from scipy import sparse
+    lp = lpgen.c3_pds20_like()
+    B, tol = 64, 1e-4
+    Cm, AL, AU, L, U = make_batch(lp, B, 4)
+    m, n = lp["m"], lp["n"]
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=tol, max_iter=60000, use_presolve=False)
+    r = hprlp.solve_batched(model, Cm, AL, AU, L, U, None, prm)
+    assert r["status"] == ["OPTIMAL"] * B
+    assert np.isfinite(r["x"]).all() and np.isfinite(r["y"]).all() and np.isfinite(r["z"]).all()
+    assert (np.asarray(r["residuals"]) <= tol).all()
+
+    # (i) oracle on 8 members
+    sel = list(range(0, B, 9))[:8]
+    ref = O.solve_batched(m, n, lp["rowptr"], lp["colind"], lp["values"], len(sel), Cm[:, sel].T.ravel(), AL[:, sel].T.ravel(),
+                          AU[:, sel].T.ravel(), L[:, sel].T.ravel(), U[:, sel].T.ravel(), None,
+                          params=O.Params.default(stop_tol=tol, max_iter=60000))
+    assert ref["status"] == ["OPTIMAL"] * len(sel)
+    same = 0
+    for q, k in enumerate(sel):
+        same += int(r["iter"][k] == ref["iter"][q])
+        assert abs(r["iter"][k] - ref["iter"][q]) <= 0.1 * ref["iter"][q] + 150, (k, r["iter"][k], ref["iter"][q])
+        assert abs(r["primal_obj"][k] - ref["primal_obj"][q]) <= 10 * tol * (1 + abs(ref["primal_obj"][q]))
+    assert same >= 6, (same, [r["iter"][k] for k in sel], list(ref["iter"]))
+
+    # (ii) KKT of every member on the unscaled LP, and the single-LP path on every member
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    for k in range(B):
+        x, y, z = r["x"][:, k], r["y"][:, k], r["z"][:, k]
+        Ax = A @ x
+        rp = np.maximum(np.maximum(AL[:, k] - Ax, Ax - AU[:, k]), 0.0)
+        rp = np.where(np.isfinite(rp), rp, 0.0)
+        bnd = np.maximum(np.maximum(L[:, k] - x, x - U[:, k]), 0.0)
+        b = np.maximum(np.where(np.isfinite(AL[:, k]), np.abs(AL[:, k]), 0.0), np.where(np.isfinite(AU[:, k]), np.abs(AU[:, k]), 0.0))
+        assert np.linalg.norm(rp) <= 3 * tol * (1 + np.linalg.norm(b)), k
+        assert np.linalg.norm(bnd) <= 3 * tol * (1 + np.linalg.norm(b)), k
+        rd = Cm[:, k] - A.T @ y - z
+        assert np.linalg.norm(rd) <= 3 * tol * (1 + np.linalg.norm(Cm[:, k])), k
+        assert abs(r["primal_obj"][k] - float(Cm[:, k] @ x)) <= 1e-8 * (1 + abs(r["primal_obj"][k]))
+    model.free()
+    for k in range(B):
+        mk = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], AL[:, k], AU[:, k], L[:, k], U[:, k], Cm[:, k])
+        sv = hprlp.Solver(mk, hprlp.Parameters(stop_tol=tol, max_iter=60000, use_presolve=False))
+        sv.scale()
+        lam, _ = sv.power_iteration()
+        sv.init(-1.0, lam * 1.01)
+        s = sv.run()
+        sv.close()
+        assert s.status == "OPTIMAL", (k, s.status)
+        assert abs(s.primal_obj - r["primal_obj"][k]) <= 10 * tol * (1 + abs(s.primal_obj)), (k, s.primal_obj, r["primal_obj"][k])
+        mk.free()
