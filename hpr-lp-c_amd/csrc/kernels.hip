@@ -215,8 +215,16 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// field of sweep step r (uniform, 0..255) from the four table registers of a lane (lane l holds steps l, 64 + l, ...):
+// selects on a uniform condition, then one v_readlane -- no control flow
+__device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r) {
+    const int q = r >> 6;
+    const int v = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));
+    return __builtin_amdgcn_readlane(v, r & 63);
+}
+
 template <class Epi>
-__global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi) {
+__global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi epi) {  // 4 waves per SIMD = two workgroups per CU
     static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
     constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols, K = kTileChunk;
     constexpr int TPT = T / NT;
@@ -241,64 +249,124 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
         if (s0 < smid) {
-            d2_t va, vb;
-            uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
-            double tl[TPT];
             const int nst = smid - s0;
             const int rot = t.steps[s0].rot;  // rotated sweep (tiled_build.hip, finish_schedule)
+            const int lane = tid & 63;
             auto sidx = [&](int i) { i = min(i, nst - 1) + rot; return s0 + (i < nst ? i : i - nst); };
-            TileStep st = t.steps[sidx(0)];
-            TileStep st_next = t.steps[sidx(1)];
-            auto issue = [&](const TileStep &q) {
-                const int e = q.e_begin + K * tid;
-                const int ee = (e < q.e_end) ? e : q.e_begin;
-                va = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee));
-                vb = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee) + 1);
-                typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));  // one 12-byte load per lane
-                const u3_t w = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.tidx3 + (ee / K) * 3));
-                i0 = w.x;
-                i1 = w.y;
-                i2 = w.z;
-#pragma unroll
-                for (int j = 0; j < TPT; ++j) tl[j] = vec[min(q.col0 + tid + j * NT, ncols - 1)];
+            // The step table of the sweep lives in registers: lane l of every wave holds steps seg + l, seg + 64 + l, ... of
+            // the current segment of 256 sweep positions; a step's fields come out by v_readlane with the (uniform) sweep
+            // position.  The table loads leave the per-step path and the in-order vector-memory queue; a sweep longer than
+            // 256 steps (rare) restarts the pipeline per segment.
+            int seg = 0, lim = 0;
+            int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0, te0 = 0, te1 = 0, te2 = 0, te3 = 0;  // col0 / e_begin / e_end
+            auto getstep = [&](int k, int &col0, int &eb, int &ee) {
+                const int r = min(k, lim - 1) - seg;
+                col0 = step_field(tc0, tc1, tc2, tc3, r);
+                eb = step_field(tb0, tb1, tb2, tb3, r);
+                ee = step_field(te0, te1, te2, te3, r);
             };
-            issue(st);
-            for (int s = s0; s < smid; ++s) {
-                const TileStep cur = st;
-                const d2_t ca = va, cb = vb;
-                const uint32_t c0 = i0, c1 = i1, c2 = i2;
-                lds_barrier();  // every lane is done with the previous tile
+            struct Ent {
+                d2_t va, vb;
+                uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
+            };
+            typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));  // one 12-byte load per lane
+            auto issue_entries = [&](Ent &E, int k) {
+                int col0, eb, ee_;
+                getstep(k, col0, eb, ee_);
+                const int e = eb + K * tid;
+                const int ee = (e < ee_) ? e : eb;
+                E.va = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee));
+                E.vb = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee) + 1);
+                const u3_t w = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.tidx3 + (ee / K) * 3));
+                E.i0 = w.x;
+                E.i1 = w.y;
+                E.i2 = w.z;
+            };
+            auto issue_tile = [&](double (&tl)[TPT], int k) {
+                int col0, eb, ee_;
+                getstep(k, col0, eb, ee_);
 #pragma unroll
-                for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
-                st = st_next;
-                st_next = t.steps[sidx(s - s0 + 2)];
-                if (s + 1 < smid) issue(st);
-                lds_barrier();  // tile visible
-                if (K * tid < cur.e_end - cur.e_begin) {
-                    const double v[K] = {ca.x, ca.y, cb.x, cb.y};
+                for (int j = 0; j < TPT; ++j) tl[j] = vec[min(col0 + tid + j * NT, ncols - 1)];
+            };
+            auto process = [&](const Ent &E, int k) {
+                int col0, eb, ee_;
+                getstep(k, col0, eb, ee_);
+                if (K * tid < ee_ - eb) {
+                    const double v[K] = {E.va.x, E.va.y, E.vb.x, E.vb.y};
+                    const uint32_t c0 = E.i0, c1 = E.i1, c2 = E.i2;
                     const uint32_t id[K] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
                     uint32_t rw[K];
                     double a[K], y[K];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        rw[k] = id[k] & (R - 1);
-                        a[k] = acc[rw[k]];
-                        y[k] = ytile[id[k] >> kTileRowBits];
+                    for (int k2 = 0; k2 < K; ++k2) {
+                        rw[k2] = id[k2] & (R - 1);
+                        a[k2] = acc[rw[k2]];
+                        y[k2] = ytile[id[k2] >> kTileRowBits];
                     }
                     double sk[K];
                     sk[0] = a[0] + v[0] * y[0];
 #pragma unroll
-                    for (int k = 1; k < K; ++k) sk[k] = ((rw[k] == rw[k - 1]) ? sk[k - 1] : a[k]) + v[k] * y[k];
+                    for (int k2 = 1; k2 < K; ++k2) sk[k2] = ((rw[k2] == rw[k2 - 1]) ? sk[k2 - 1] : a[k2]) + v[k2] * y[k2];
 #pragma unroll
-                    for (int k = 0; k < K; ++k)
-                        if (k == K - 1 || rw[k] != rw[k + 1]) acc[rw[k]] = sk[k];
+                    for (int k2 = 0; k2 < K; ++k2)
+                        if (k2 == K - 1 || rw[k2] != rw[k2 + 1]) acc[rw[k2]] = sk[k2];
+                }
+            };
+            // One step k: [barrier] stage tile k (loaded during the previous step), issue the loads of tile k + 1, [barrier],
+            // fold the step's entries (loaded TWO steps ago) into the accumulators, reload their register set with the
+            // entries of step k + 2.  In the in-order vector-memory queue the entries of step k + 1 are younger than tile k:
+            // the wait for the tile leaves one step's entry loads (from HBM) in flight across both barriers.  Measured on
+            // config 5 (profiles/r02_pmc_summary.md): x-half 713 -> 673 us; a third entry set and a second tile set in
+            // flight (128 VGPRs) gave 685 us.
+            auto step = [&](Ent &E, double (&tl)[TPT], int k) {
+                lds_barrier();  // every lane is done with the previous tile
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+                issue_tile(tl, k + 1);
+                lds_barrier();  // tile visible
+                process(E, k);
+                issue_entries(E, k + 2);
+            };
+            for (seg = 0; seg < nst; seg += 256) {
+                lim = min(seg + 256, nst);
+                {
+                    const TileStep q0 = t.steps[sidx(seg + lane)], q1 = t.steps[sidx(seg + 64 + lane)];
+                    const TileStep q2 = t.steps[sidx(seg + 128 + lane)], q3 = t.steps[sidx(seg + 192 + lane)];
+                    tc0 = q0.col0; tb0 = q0.e_begin; te0 = q0.e_end;
+                    tc1 = q1.col0; tb1 = q1.e_begin; te1 = q1.e_end;
+                    tc2 = q2.col0; tb2 = q2.e_begin; te2 = q2.e_end;
+                    tc3 = q3.col0; tb3 = q3.e_begin; te3 = q3.e_end;
+                }
+                // prologue in the steady state's issue order; the scheduling barriers keep the compiler from interleaving
+                // the groups, which would force the loop header's wait down to vmcnt(0)
+                Ent E0, E1;
+                double tl[TPT];
+                __builtin_amdgcn_sched_barrier(0);
+                issue_entries(E0, seg);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_tile(tl, seg);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_entries(E1, seg + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // unrolled by four (two entry sets); the compiler's counted waits are only conservative in the first step
+                // behind the loop header, where the prologue and the back edge merge
+                for (int k = seg;;) {
+                    step(E0, tl, k);
+                    if (++k >= lim) break;
+                    step(E1, tl, k);
+                    if (++k >= lim) break;
+                    step(E0, tl, k);
+                    if (++k >= lim) break;
+                    step(E1, tl, k);
+                    if (++k >= lim) break;
                 }
             }
         }
-        // remainder entries: direct gathers; products staged in the tile buffer, one head lane per row
-        // segment adds them in order (same scheme as the stream kernel)
+        // remainder entries (propagation blocking, tiled.h): the products were written by k_far_products into this
+        // super-block's slice of P; a step streams its range of P into the tile buffer (coalesced) next to the
+        // step's entry codes in (row, CSR) order, then one head lane per row segment adds that row's products in order
         double *prod = ytile;
-        uint16_t *rows = reinterpret_cast<uint16_t *>(ytile + kTileRemCap);
+        uint32_t *rq = reinterpret_cast<uint32_t *>(ytile + kTileRemCap);
         for (int s = smid; s < s1; ++s) {
             const TileStep st = t.steps[s];
             const int cnt = st.e_end - st.e_begin;
@@ -307,25 +375,27 @@ __global__ void __launch_bounds__(kTileThreads) k_tiled_fused(CsrDev A, Epi epi)
             for (int k = 0; k < kTileRemK; ++k) {
                 const int el = tid + k * NT;
                 if (el < cnt) {
-                    const int e = st.e_begin + el;
-                    prod[el] = t.rval[e] * vec[t.rcol[e]];
-                    rows[el + 1] = t.rrow[e];
+                    prod[el] = __builtin_nontemporal_load(t.P + st.e_begin + el);
+                    rq[el + 1] = __builtin_nontemporal_load(t.rq + st.e_begin + el);
                 }
             }
-            if (tid == 0) rows[0] = 0xffffu;
+            if (tid == 0) rq[0] = 0xffffu;
             lds_barrier();
 #pragma unroll
             for (int k = 0; k < kTileRemK; ++k) {
                 const int el = tid + k * NT;
                 if (el < cnt) {
-                    const uint16_t rw = rows[el + 1];
-                    if (rows[el] != rw) {
+                    const uint32_t w = rq[el + 1];
+                    const uint32_t rw = w & 0xffffu;
+                    if ((rq[el] & 0xffffu) != rw) {
                         double sacc = acc[rw];
+                        uint32_t q = w;
                         int j = el;
                         do {
-                            sacc += prod[j];
+                            sacc += prod[q >> 16];
                             ++j;
-                        } while (j < cnt && rows[j + 1] == rw);
+                            q = rq[j + 1];
+                        } while (j < cnt && (q & 0xffffu) == rw);
                         acc[rw] = sacc;
                     }
                 }
@@ -360,9 +430,42 @@ void launch_tiled_refresh(const DeviceTiled &t, const double *csr_val, hipStream
     if (t.n_tile > 0)
         hipLaunchKernelGGL(k_tiled_refresh, dim3(static_cast<unsigned>((t.n_tile + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                            t.n_tile, t.tperm.p, csr_val, t.tval.p);
-    if (t.n_rem > 0)
+    if (t.n_rem > 0 && t.f_val.p)
         hipLaunchKernelGGL(k_tiled_refresh, dim3(static_cast<unsigned>((t.n_rem + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                           t.n_rem, t.rperm.p, csr_val, t.rval.p);
+                           t.n_rem, t.f_perm.p, csr_val, t.f_val.p);
+}
+
+// Pre-pass of a tiled launch (tiled.h): one workgroup per group of kFarGroup columns of the gathered vector.  The
+// group's slice is staged in LDS with coalesced loads; the workgroup streams its remainder entries (value, local
+// column, position in P -- ascending, so the stores of one (group, super-block) run are contiguous) and writes the
+// products.  Every gathered element is read from memory once, no 128-byte line is fetched for 8 bytes.
+__global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const double *__restrict__ vec, int ncols) {
+    __shared__ double v[kFarGroup];
+    // workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of groups, so that the runs its
+    // workgroups write side by side in P (layout [super-block][group]) meet in ONE L2 and leave it as whole lines
+    const int per = (t.n_groups + 7) / 8;
+    const int g = (blockIdx.x % 8) * per + blockIdx.x / 8, c0 = g * kFarGroup, tid = threadIdx.x;
+    if (g >= t.n_groups) return;
+    const int b = t.f_gptr[g], e = t.f_gptr[g + 1];
+    if (b >= e) return;
+    const int w = min(kFarGroup, ncols - c0);
+    for (int i = tid; i < w; i += kFarThreads) v[i] = vec[c0 + i];
+    __syncthreads();
+    int k = b + tid;
+    for (; k + 3 * kFarThreads < e; k += 4 * kFarThreads) {
+        double a[4];
+        int pos[4];
+        uint16_t lc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = __builtin_nontemporal_load(t.f_val + k + u * kFarThreads);
+            pos[u] = __builtin_nontemporal_load(t.f_pos + k + u * kFarThreads);
+            lc[u] = __builtin_nontemporal_load(t.f_lcol + k + u * kFarThreads);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t.P[pos[u]] = a[u] * v[lc[u]];
+    }
+    for (; k < e; k += kFarThreads) t.P[t.f_pos[k]] = t.f_val[k] * v[t.f_lcol[k]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -584,6 +687,8 @@ static void launch_fused(const CsrDev &M, const Epi &e, hipStream_t s) {
     if (M.nblk <= 0) return;
     if constexpr (Epi::NV == 1) {
         if (M.tiled.valid) {
+            if (M.tiled.n_groups > 0)
+                hipLaunchKernelGGL(k_far_products, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
             hipLaunchKernelGGL(k_tiled_fused<Epi>, dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
             return;
         }

@@ -165,17 +165,18 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
                 std::cerr << "[timing]   tiled copy (device build): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, "
                           << tiled.n_steps << " steps, " << tiled.dense_entries << " entries in tiles + " << tiled.padding
                           << " padding, " << tiled.n_rem << " in the remainder list" << std::endl;
-            if (ok) {
-                view.tiled = tiled.view;
-                launch_tiled_refresh(tiled, val.p, nullptr);
-                HIP_CHECK(hipDeviceSynchronize());
-            }
             const char *chk = std::getenv("HPRLP_TILING_CHECK");
             if (chk && chk[0] == '1' && ci) {
                 TiledHost th;
                 const bool hok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense);
                 if (hok != ok) throw std::runtime_error("tiling check: host and device builders disagree on acceptance");
                 if (ok) tiled.compare_with(th);
+            }
+            if (ok) {
+                tiled.build_far(cols, nullptr);  // consumes the remainder lists the check above compares
+                view.tiled = tiled.view;
+                launch_tiled_refresh(tiled, val.p, nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
             }
             pt.tick("  build tiled copy (device)");
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && ci) {  // the host builder needs the host column indices
@@ -203,6 +204,7 @@ void DeviceMatrix::finish_tiling(hipStream_t s) {
                   << th->dense_entries << " entries in tiles + " << th->padding << " padding, " << th->n_rem
                   << " in the remainder list" << std::endl;
     tiled.upload(*th);
+    tiled.build_far(view.cols, s);
     view.tiled = tiled.view;
     launch_tiled_refresh(tiled, val.p, s);
     HIP_CHECK(hipStreamSynchronize(s));

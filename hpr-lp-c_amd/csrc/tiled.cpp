@@ -236,7 +236,6 @@ void DeviceTiled::upload(const TiledHost &h) {
     rcol.alloc_zero(h.n_rem + 8);
     rperm.alloc(h.n_rem + 8);
     rrow.alloc_zero(h.n_rem + 8);
-    rval.alloc_zero(h.n_rem + 8);
     size_t to = 0, ro = 0;
     for (const TiledHost::Piece &pc : h.pieces) {
         if (!pc.tidx.empty()) {
@@ -259,9 +258,6 @@ void DeviceTiled::upload(const TiledHost &h) {
     view.tval = tval.p;
     pack_indices(nullptr);
     view.tidx3 = tidx3.p;
-    view.rval = rval.p;
-    view.rcol = rcol.p;
-    view.rrow = rrow.p;
     finish_schedule(nullptr);
 }
 

@@ -9,7 +9,12 @@
 // padding continues the previous row), so exactly one lane touches a given accumulator in a step:
 // no atomics, deterministic; the per-row summation order is fixed by the matrix (tiles in the order of
 // the super-block's rotated sweep -- finish_schedule() in tiled_build.hip -- then the remainder).
-// Segments longer than 4 and entries of sparse tiles go to a remainder list processed with direct gathers.
+// Segments longer than 4 and entries of sparse tiles (the far columns) go to a remainder list.  A random 8-byte gather
+// costs a whole 128-byte line of fabric traffic whatever the load flavour (tools/gather_probe.hip), so the remainder is
+// not gathered by the row side at all: a pre-pass kernel (k_far_products) walks the list in SOURCE order -- one workgroup
+// per group of kFarGroup columns, that slice of the vector staged in LDS with coalesced loads -- and writes every product
+// a * v[col] to its slot of a buffer P laid out in DESTINATION order ([super-block][source group]); the tiled kernel then
+// streams its super-block's slice of P and adds the products row by row (propagation blocking: both sides stream).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,7 +31,7 @@ constexpr int kTileRows = 8192;    // rows per super-block: 64 KiB of accumulato
 constexpr int kTileCols = 2048;    // columns per tile: 16 KiB of the gathered vector in LDS
 constexpr int kTileChunk = 4;      // entries per lane per step
 constexpr int kTileStepCap = kTileThreads * kTileChunk;                       // entries per tile step
-constexpr int kTileRemK = (kTileCols * 8 - 8) / (10 * kTileThreads);          // remainder entries per lane per step
+constexpr int kTileRemK = (kTileCols * 8 - 8) / (12 * kTileThreads);          // remainder entries per lane per step (8 B product + 4 B code of LDS each)
 constexpr int kTileRemCap = kTileThreads * kTileRemK;                         // (scratch aliases the tile buffer)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
 static_assert(kTileRemK >= 1, "tile buffer too small for the remainder scratch");
@@ -36,6 +41,8 @@ static_assert((1 << kTileRowBits) == kTileRows && kTileCols <= (1 << (24 - kTile
 inline uint32_t tile_code(int lcol, int row) { return (static_cast<uint32_t>(lcol) << kTileRowBits) | static_cast<uint32_t>(row); }
 
 constexpr int kTileResidentPerCu = 2;  // 80 KiB of LDS per workgroup, 160 KiB per CU
+constexpr int kFarGroup = 8192;        // source columns per workgroup of the remainder pre-pass (64 KiB of LDS)
+constexpr int kFarThreads = 512;
 
 struct TileStep {
     int col0;     // first column of the tile
@@ -56,9 +63,16 @@ struct TiledDev {
     // tile entries: 24-bit codes (local column << 13 | local row), four per lane chunk packed in three 32-bit words
     // (w0 = e0 | e1 << 24, w1 = e1 >> 8 | e2 << 16, w2 = e2 >> 16 | e3 << 8): 44 instead of 48 bytes per chunk
     const uint32_t *tidx3 = nullptr;
-    const double *rval = nullptr;  // remainder entries
-    const int *rcol = nullptr;
-    const uint16_t *rrow = nullptr;
+    // remainder entries, destination side: step [e_begin, e_end) owns P[e_begin..e_end) (products, written by the
+    // pre-pass of this launch) and rq[e_begin..e_end): the step's entries in (row, CSR) order, slot in P << 16 | local row
+    double *P = nullptr;
+    const uint32_t *rq = nullptr;
+    // remainder entries, source side (grouped by column / kFarGroup, ascending P position inside a group)
+    int n_groups = 0;
+    const int *f_gptr = nullptr;      // n_groups + 1
+    const double *f_val = nullptr;
+    const int *f_pos = nullptr;       // position in P
+    const uint16_t *f_lcol = nullptr; // column - group * kFarGroup
 };
 
 // Host-side result of the analysis; perm arrays give, for every stored entry, its index in the CSR
@@ -90,14 +104,20 @@ struct DeviceTiled {
     DBuf<TileStep> steps;
     DBuf<uint32_t> tidx;   // one code per entry: filled by the builders, released by pack_indices()
     DBuf<uint32_t> tidx3;  // packed codes, what the kernel reads
-    DBuf<uint16_t> rrow;
-    DBuf<double> tval, rval;
+    DBuf<uint16_t> rrow;  // rcol / rrow / rperm: remainder entries in (super-block, row, CSR) order as the builders emit them;
+                          // build_far() derives the two-sided lists from them and releases them
+    DBuf<double> tval;
+    DBuf<double> P, f_val;
+    DBuf<uint32_t> rq;
+    DBuf<int> f_gptr, f_pos, f_perm;
+    DBuf<uint16_t> f_lcol;
     TiledDev view;
     long n_tile = 0, n_rem = 0;
     long dense_entries = 0, padding = 0;
     int n_steps = 0;
     void upload(const TiledHost &h);
     void pack_indices(hipStream_t s);  // tidx -> tidx3
+    void build_far(int cols, hipStream_t s);  // remainder lists (rcol, rrow, rperm) -> the propagation-blocking lists
     // launch shape (persistent workgroups per XCD) and the rotation of every super-block's sweep; rot_period is the
     // alignment period in tiles (0 = no rotation)
     void finish_schedule(hipStream_t s);
@@ -110,7 +130,7 @@ struct DeviceTiled {
     void compare_with(const TiledHost &h) const;
 };
 
-// tval[e] = csr_val[tperm[e]] (0 for padding), rval likewise
+// tval[e] = csr_val[tperm[e]] (0 for padding), f_val likewise
 void launch_tiled_refresh(const DeviceTiled &t, const double *csr_val, hipStream_t s);
 
 }  // namespace hprlp

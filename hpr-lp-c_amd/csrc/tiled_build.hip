@@ -424,7 +424,6 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     rcol.alloc_zero(static_cast<size_t>(n_rem) + 8);
     rperm.alloc(static_cast<size_t>(n_rem) + 8);
     rrow.alloc_zero(static_cast<size_t>(n_rem) + 8);
-    rval.alloc_zero(static_cast<size_t>(n_rem) + 8);
     if (n_rem > 0) {
         DBuf<int> rem_k(static_cast<size_t>(n_rem)), nsel(1);
         hipcub::CountingInputIterator<int> iota(0);
@@ -451,11 +450,159 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     view.tval = tval.p;
     pack_indices(s);
     view.tidx3 = tidx3.p;
-    view.rval = rval.p;
-    view.rcol = rcol.p;
-    view.rrow = rrow.p;
     finish_schedule(s);
     return true;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Propagation-blocking lists of the remainder (tiled.h).  Input: the remainder entries in (super-block, row, CSR)
+// order (rcol, rrow, rperm) and the remainder steps (ranges of at most kTileRemCap entries that never cross a
+// super-block).  Three stable radix sorts:
+//   P order  = (super-block, source group, e): where the pre-pass writes the product of entry e -- the run of one
+//              (source group, super-block) pair is contiguous, a super-block's slice of P is what the tiled kernel streams;
+//   rq       = per step range of P: its entries in e order (= row, CSR order), as slot-in-step << 16 | local row;
+//   f order  = (source group, P position): what one pre-pass workgroup reads, ascending in its writes.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(kThreads) k_far_step_of(int nsb, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
+                                                         const TileStep *__restrict__ steps, int *__restrict__ step_of, int *__restrict__ sb_of) {
+    // one workgroup per super-block: every remainder entry learns its step and its super-block
+    const int sb = blockIdx.x;
+    if (sb >= nsb) return;
+    for (int s = sb_mid[sb]; s < sb_ptr[sb + 1]; ++s) {
+        const TileStep st = steps[s];
+        for (int e = st.e_begin + threadIdx.x; e < st.e_end; e += kThreads) {
+            step_of[e] = s;
+            sb_of[e] = sb;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) k_far_key_p(int n, const int *__restrict__ sb_of, const int *__restrict__ rcol,
+                                                       unsigned long long *__restrict__ key, int *__restrict__ val) {
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= n) return;
+    key[e] = (static_cast<unsigned long long>(sb_of[e]) << 32) | static_cast<unsigned long long>(rcol[e] / kFarGroup);
+    val[e] = e;
+}
+
+// p -> key (step of p, entry), value p.  The step ranges are ranges of the P index space as well: a super-block's
+// entries occupy the same index range in either order.
+__global__ void __launch_bounds__(kThreads) k_far_key_q(int n, const int *__restrict__ step_of, const int *__restrict__ e_of_p,
+                                                       unsigned long long *__restrict__ key, int *__restrict__ val) {
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= n) return;
+    key[p] = (static_cast<unsigned long long>(step_of[p]) << 32) | static_cast<unsigned long long>(e_of_p[p]);
+    val[p] = p;
+}
+
+__global__ void __launch_bounds__(kThreads) k_far_fill_q(int n, const unsigned long long *__restrict__ skey, const int *__restrict__ p_sorted,
+                                                        const TileStep *__restrict__ steps, const uint16_t *__restrict__ rrow,
+                                                        uint32_t *__restrict__ rq) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int step = static_cast<int>(skey[i] >> 32), e = static_cast<int>(skey[i] & 0xffffffffu);
+    const int slot = p_sorted[i] - steps[step].e_begin;
+    rq[i] = (static_cast<uint32_t>(slot) << 16) | static_cast<uint32_t>(rrow[e]);
+}
+
+__global__ void __launch_bounds__(kThreads) k_far_key_f(int n, const int *__restrict__ e_of_p, const int *__restrict__ rcol,
+                                                       unsigned long long *__restrict__ key, int *__restrict__ val) {
+    const int p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= n) return;
+    key[p] = (static_cast<unsigned long long>(rcol[e_of_p[p]] / kFarGroup) << 32) | static_cast<unsigned long long>(p);
+    val[p] = e_of_p[p];
+}
+
+__global__ void __launch_bounds__(kThreads) k_far_fill_f(int n, const unsigned long long *__restrict__ skey, const int *__restrict__ e_sorted,
+                                                        const int *__restrict__ rcol, const int *__restrict__ rperm, int *__restrict__ f_pos,
+                                                        uint16_t *__restrict__ f_lcol, int *__restrict__ f_perm) {
+    const int f = blockIdx.x * kThreads + threadIdx.x;
+    if (f >= n) return;
+    const int g = static_cast<int>(skey[f] >> 32), e = e_sorted[f];
+    f_pos[f] = static_cast<int>(skey[f] & 0xffffffffu);
+    f_lcol[f] = static_cast<uint16_t>(rcol[e] - g * kFarGroup);
+    f_perm[f] = rperm[e];
+}
+
+// gptr[g] = first f whose group is >= g
+__global__ void __launch_bounds__(kThreads) k_far_gptr(int ngroups, int n, const unsigned long long *__restrict__ skey, int *__restrict__ gptr) {
+    const int g = blockIdx.x * kThreads + threadIdx.x;
+    if (g > ngroups) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (static_cast<int>(skey[mid] >> 32) < g) lo = mid + 1;
+        else hi = mid;
+    }
+    gptr[g] = lo;
+}
+
+void sort_pairs(DBuf<unsigned long long> &kin, DBuf<unsigned long long> &kout, DBuf<int> &vin, DBuf<int> &vout, int n, int end_bit, hipStream_t s) {
+    size_t bytes = 0;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin.p, kout.p, vin.p, vout.p, n, 0, end_bit, s));
+    DBuf<char> tmp(bytes + 16);
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, kin.p, kout.p, vin.p, vout.p, n, 0, end_bit, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+int bits_for(long v) {
+    int b = 1;
+    while ((1L << b) <= v) ++b;
+    return b;
+}
+
+}  // namespace
+
+void DeviceTiled::build_far(int cols, hipStream_t s) {
+    static_assert(kFarGroup <= 65536 && kTileRemCap <= 65536 && kTileRows <= 65536, "16-bit local columns, slots and rows");
+    view.P = nullptr;
+    view.rq = nullptr;
+    view.n_groups = 0;
+    if (!view.valid || n_rem <= 0) {
+        rcol.release(); rrow.release(); rperm.release();
+        return;
+    }
+    const int n = static_cast<int>(n_rem), nsb = view.nsb;
+    const int ngroups = (cols + kFarGroup - 1) / kFarGroup;
+    DBuf<int> step_of(static_cast<size_t>(n)), sb_of(static_cast<size_t>(n));
+    hipLaunchKernelGGL(k_far_step_of, dim3(nsb), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, step_of.p, sb_of.p);
+    DBuf<unsigned long long> kin(static_cast<size_t>(n)), kout(static_cast<size_t>(n));
+    DBuf<int> vin(static_cast<size_t>(n)), e_of_p(static_cast<size_t>(n));
+    // P order
+    hipLaunchKernelGGL(k_far_key_p, dim3(grid_for(n)), dim3(kThreads), 0, s, n, sb_of.p, rcol.p, kin.p, vin.p);
+    sort_pairs(kin, kout, vin, e_of_p, n, 32 + bits_for(nsb), s);
+    sb_of.release();
+    // rq: the entries of every step range of P in e order
+    DBuf<int> p_sorted(static_cast<size_t>(n));
+    hipLaunchKernelGGL(k_far_key_q, dim3(grid_for(n)), dim3(kThreads), 0, s, n, step_of.p, e_of_p.p, kin.p, vin.p);
+    sort_pairs(kin, kout, vin, p_sorted, n, 32 + bits_for(n_steps), s);
+    rq.alloc_zero(static_cast<size_t>(n) + 8);
+    hipLaunchKernelGGL(k_far_fill_q, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kout.p, p_sorted.p, steps.p, rrow.p, rq.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+    step_of.release();
+    // source side
+    hipLaunchKernelGGL(k_far_key_f, dim3(grid_for(n)), dim3(kThreads), 0, s, n, e_of_p.p, rcol.p, kin.p, vin.p);
+    sort_pairs(kin, kout, vin, p_sorted, n, 32 + bits_for(ngroups), s);  // p_sorted now holds e in f order
+    f_pos.alloc_zero(static_cast<size_t>(n) + 8);
+    f_lcol.alloc_zero(static_cast<size_t>(n) + 8);
+    f_perm.alloc(static_cast<size_t>(n) + 8);
+    f_val.alloc_zero(static_cast<size_t>(n) + 8);
+    f_gptr.alloc(static_cast<size_t>(ngroups) + 1);
+    hipLaunchKernelGGL(k_far_fill_f, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kout.p, p_sorted.p, rcol.p, rperm.p, f_pos.p, f_lcol.p, f_perm.p);
+    hipLaunchKernelGGL(k_far_gptr, dim3(grid_for(ngroups + 1)), dim3(kThreads), 0, s, ngroups, n, kout.p, f_gptr.p);
+    P.alloc_zero(static_cast<size_t>(n) + 8);
+    HIP_CHECK(hipStreamSynchronize(s));
+    rcol.release(); rrow.release(); rperm.release();
+    view.P = P.p;
+    view.rq = rq.p;
+    view.n_groups = ngroups;
+    view.f_gptr = f_gptr.p;
+    view.f_val = f_val.p;
+    view.f_pos = f_pos.p;
+    view.f_lcol = f_lcol.p;
 }
 
 }  // namespace hprlp
