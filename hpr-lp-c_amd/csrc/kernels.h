@@ -61,7 +61,8 @@ struct CsrDev {
     int csr_grid() const { return (nblk + kWavesPerBlock - 1) / kWavesPerBlock; }
     int finish_grid() const { return (nlong + kThreads - 1) / kThreads; }
     // workgroups of a fused launch on this matrix = number of reduction partials it writes
-    int grid() const { return tiled.valid ? tiled.grid : csr_grid() + finish_grid(); }
+    int tiled_finish_grid() const { return (rows + kThreads - 1) / kThreads; }
+    int grid() const { return tiled.valid ? (tiled.n_pieces > 0 ? tiled_finish_grid() : tiled.grid) : csr_grid() + finish_grid(); }
 };
 
 // Device-resident iteration scalars (reference Halpern_params[4] + halpern_inner,

@@ -223,13 +223,248 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
     return __builtin_amdgcn_readlane(v, r & 63);
 }
 
-template <class Epi>
-__global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi epi) {  // 4 waves per SIMD = two workgroups per CU
-    static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
+// Sweep of `count` consecutive tile steps of a super-block, starting at position `first` of its cyclic step list
+// [s0, s0 + nst): every step stages its tile of the gathered vector in `ytile` and folds its entries into `acc`.
+// Called by all kTileThreads threads of the workgroup; acc must be initialised and visible (a barrier comes first).
+// ED / TD: how many steps ahead the entry loads (HBM) and the tile loads (L2) are issued.  Full chip (two workgroups on
+// every CU): <2, 1> -- deeper gains nothing there, the fabric is busy (profiles/r02_pmc_summary.md).  Few workgroups
+// (the split form): a step cannot be shorter than the HBM latency / ED, so <3, 2>.
+template <int ED, int TD, bool REP, bool STAMP = false>
+__device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, int first, int count, const double *__restrict__ vec,
+                                            int ncols, double *acc, double *ytile, int tid, unsigned long long *stamp = nullptr) {
     constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols, K = kTileChunk;
     constexpr int TPT = T / NT;
-    constexpr int NACC = Epi::NACC;
     typedef double d2_t __attribute__((ext_vector_type(2)));
+    const int lane = tid & 63;
+    auto sidx = [&](int i) { i = min(i, count - 1) + first; return s0 + (i < nst ? i : i - nst); };
+    // The step table of the sweep lives in registers: lane l of every wave holds steps seg + l, seg + 64 + l, ... of
+    // the current segment of 256 sweep positions; a step's fields come out by v_readlane with the (uniform) sweep
+    // position.  The table loads leave the per-step path and the in-order vector-memory queue; a sweep longer than
+    // 256 steps (rare) restarts the pipeline per segment.
+    int seg = 0, lim = 0;
+    int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0, te0 = 0, te1 = 0, te2 = 0, te3 = 0;  // col0 / e_begin / e_end
+    auto getstep = [&](int k, int &col0, int &eb, int &ee) {
+        const int r = min(k, lim - 1) - seg;
+        col0 = step_field(tc0, tc1, tc2, tc3, r);
+        eb = step_field(tb0, tb1, tb2, tb3, r);
+        ee = step_field(te0, te1, te2, te3, r);
+    };
+    struct Ent {
+        d2_t va, vb;
+        uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
+    };
+    typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));  // one 12-byte load per lane
+    auto issue_entries = [&](Ent &E, int k) {
+        int col0, eb, ee_;
+        getstep(k, col0, eb, ee_);
+        const int e = eb + K * tid;
+        const int ee = (e < ee_) ? e : eb;
+        E.va = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee));
+        E.vb = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee) + 1);
+        const u3_t w = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.tidx3 + (ee / K) * 3));
+        E.i0 = w.x;
+        E.i1 = w.y;
+        E.i2 = w.z;
+    };
+    auto issue_tile = [&](double (&tl)[TPT], int k) {
+        int col0, eb, ee_;
+        getstep(k, col0, eb, ee_);
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) tl[j] = vec[min(col0 + tid + j * NT, ncols - 1)];
+    };
+    auto process = [&](const Ent &E, int k) {
+        int col0, eb, ee_;
+        getstep(k, col0, eb, ee_);
+        if (K * tid < ee_ - eb) {
+            const double v[K] = {E.va.x, E.va.y, E.vb.x, E.vb.y};
+            const uint32_t c0 = E.i0, c1 = E.i1, c2 = E.i2;
+            const uint32_t id[K] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
+            uint32_t rw[K];
+            double y[K];
+#pragma unroll
+            for (int k2 = 0; k2 < K; ++k2) {
+                rw[k2] = id[k2] & (R - 1);
+                y[k2] = ytile[id[k2] >> kTileRowBits];
+            }
+            double a[K];
+#pragma unroll
+            for (int k2 = 0; k2 < K; ++k2) a[k2] = acc[rw[k2]];
+            double sk[K];
+            sk[0] = a[0] + v[0] * y[0];
+#pragma unroll
+            for (int k2 = 1; k2 < K; ++k2) sk[k2] = ((rw[k2] == rw[k2 - 1]) ? sk[k2 - 1] : a[k2]) + v[k2] * y[k2];
+#pragma unroll
+            for (int k2 = 0; k2 < K; ++k2)
+                if (k2 == K - 1 || rw[k2] != rw[k2 + 1]) acc[rw[k2]] = sk[k2];
+        }
+    };
+    // REP (matrices with tiles of more than kTileStepCap entries, i.e. several steps per tile): a step whose tile is the
+    // previous step's neither loads nor stages it again -- one barrier (the accumulators change owners between steps).
+    // A separate instantiation: the extra control flow costs the common case its counted waits.
+    auto same_tile = [&](int k) {
+        if (k <= seg || k >= lim) return false;  // first step of a segment always stages; clamped look-ahead never loads
+        int c0, c1, eb, ee_;
+        getstep(k, c0, eb, ee_);
+        getstep(k - 1, c1, eb, ee_);
+        return c0 == c1;
+    };
+    // STAMP (diagnostic instantiation only, HPRLP_TILE_STAMPS=1): shader-clock time of wave 0 in the five phases of a step
+    unsigned long long tq[6] = {0, 0, 0, 0, 0, 0}, ph[7] = {0, 0, 0, 0, 0, 0, 0};  // sums stay in registers until the sweep ends
+    auto step = [&](Ent &E, double (&tl)[TPT], int k) {
+        if (STAMP) tq[0] = __builtin_amdgcn_s_memtime();
+        lds_barrier();  // every lane is done with the previous step (tile and accumulators)
+        if (STAMP) tq[1] = __builtin_amdgcn_s_memtime();
+        if (STAMP) {
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+            tq[2] = __builtin_amdgcn_s_memtime();  // tile data arrived and written
+            issue_tile(tl, k + TD);
+            tq[3] = __builtin_amdgcn_s_memtime();
+            lds_barrier();
+            tq[4] = __builtin_amdgcn_s_memtime();
+            process(E, k);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tq[5] = __builtin_amdgcn_s_memtime();
+            issue_entries(E, k + ED);
+            const unsigned long long t6 = __builtin_amdgcn_s_memtime();
+            ph[0] += tq[1] - tq[0];  // barrier A (waiting for the slowest wave of the previous step)
+            ph[1] += tq[2] - tq[1];  // wait for the tile loads + LDS stores
+            ph[2] += tq[3] - tq[2];  // issue of the next tile's loads
+            ph[3] += tq[4] - tq[3];  // barrier B
+            ph[4] += tq[5] - tq[4];  // entries arrived + LDS gather / accumulate
+            ph[5] += t6 - tq[5];     // issue of the entry loads
+            ph[6] += 1;
+            return;
+        }
+        if (REP) {
+            const bool keep = same_tile(k);  // uniform
+            if (!keep) {
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+            }
+            if (!same_tile(k + TD)) issue_tile(tl, k + TD);
+            if (!keep) lds_barrier();  // tile visible
+        } else {
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+            issue_tile(tl, k + TD);
+            lds_barrier();  // tile visible
+        }
+        process(E, k);
+        issue_entries(E, k + ED);
+    };
+    for (seg = 0; seg < count; seg += 256) {
+        lim = min(seg + 256, count);
+        {
+            const TileStep q0 = t.steps[sidx(seg + lane)], q1 = t.steps[sidx(seg + 64 + lane)];
+            const TileStep q2 = t.steps[sidx(seg + 128 + lane)], q3 = t.steps[sidx(seg + 192 + lane)];
+            tc0 = q0.col0; tb0 = q0.e_begin; te0 = q0.e_end;
+            tc1 = q1.col0; tb1 = q1.e_begin; te1 = q1.e_end;
+            tc2 = q2.col0; tb2 = q2.e_begin; te2 = q2.e_end;
+            tc3 = q3.col0; tb3 = q3.e_begin; te3 = q3.e_end;
+        }
+        // prologue in the steady state's issue order (step j issues tile j + TD, then entries j + ED); the scheduling
+        // barriers keep the compiler from interleaving the groups, which would force the loop's waits down to vmcnt(0)
+        Ent E[ED];
+        double tl[TD][TPT];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = -(ED > TD ? ED : TD); j < 0; ++j) {
+            if (j + TD >= 0) {
+                issue_tile(tl[(j + TD) % TD], seg + j + TD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j + ED >= 0) {
+                issue_entries(E[(j + ED) % ED], seg + j + ED);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // unrolled over the register sets (and twice that for <2, 1>): the compiler's counted waits are only conservative
+        // in the first step behind the loop header, where the prologue and the back edge merge
+        constexpr int U = (ED * TD) % 2 == 0 && ED * TD > 2 ? ED * TD : 2 * ED * TD;
+        static_assert(U % ED == 0 && U % TD == 0, "the unrolled body must return every register set to its role");
+        bool done = false;
+        for (int k = seg; !done;) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                step(E[u % ED], tl[u % TD], k);
+                if (++k >= lim) {
+                    done = true;
+                    break;
+                }
+            }
+        }
+    }
+    if (STAMP && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) stamp[i] += ph[i];
+    }
+}
+
+// Remainder steps [smid, s1) of a super-block (propagation blocking, tiled.h): the products were written by
+// k_far_products into this super-block's slice of P; a step streams its range of P into the tile buffer (coalesced)
+// next to the step's entry codes in (row, CSR) order, then one head lane per row segment adds that row's products in order.
+__device__ __forceinline__ void tiled_remainder(const TiledDev &t, int smid, int s1, double *acc, double *ytile, int tid) {
+    constexpr int NT = kTileThreads;
+    if (smid >= s1) return;
+    double *prod = ytile;
+    uint32_t *rq = reinterpret_cast<uint32_t *>(ytile + kTileRemCap);
+    // the loads of step s + 1 (P and the entry codes: two HBM round trips without it) are in flight while step s is folded
+    double pv[kTileRemK];
+    uint32_t qv[kTileRemK];
+    TileStep st = t.steps[smid];
+    auto issue = [&](const TileStep &q) {
+#pragma unroll
+        for (int k = 0; k < kTileRemK; ++k) {
+            const int el = min(tid + k * NT, max(q.e_end - q.e_begin - 1, 0));  // clamped: branch-free, the surplus lanes' values are not stored
+            pv[k] = __builtin_nontemporal_load(t.P + q.e_begin + el);
+            qv[k] = __builtin_nontemporal_load(t.rq + q.e_begin + el);
+        }
+    };
+    issue(st);
+    for (int s = smid; s < s1; ++s) {
+        const int cnt = st.e_end - st.e_begin;
+        const TileStep nxt = t.steps[min(s + 1, s1 - 1)];
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < kTileRemK; ++k) {
+            const int el = tid + k * NT;
+            if (el < cnt) {
+                prod[el] = pv[k];
+                rq[el + 1] = qv[k];
+            }
+        }
+        if (tid == 0) rq[0] = 0xffffu;
+        if (s + 1 < s1) issue(nxt);
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < kTileRemK; ++k) {
+            const int el = tid + k * NT;
+            if (el < cnt) {
+                const uint32_t w = rq[el + 1];
+                const uint32_t rw = w & 0xffffu;
+                if ((rq[el] & 0xffffu) != rw) {
+                    double sacc = acc[rw];
+                    uint32_t q = w;
+                    int j = el;
+                    do {
+                        sacc += prod[q >> 16];
+                        ++j;
+                        q = rq[j + 1];
+                    } while (j < cnt && (q & 0xffffu) == rw);
+                    acc[rw] = sacc;
+                }
+            }
+        }
+        st = nxt;
+    }
+}
+
+template <class Epi, bool REP>
+__global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi epi) {  // 4 waves per SIMD = two workgroups per CU
+    static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
+    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols;
+    constexpr int NACC = Epi::NACC;
     __shared__ double acc[R];
     __shared__ double ytile[T];
     const TiledDev &t = A.tiled;
@@ -248,159 +483,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         const int ncols = A.cols;
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
-        if (s0 < smid) {
-            const int nst = smid - s0;
-            const int rot = t.steps[s0].rot;  // rotated sweep (tiled_build.hip, finish_schedule)
-            const int lane = tid & 63;
-            auto sidx = [&](int i) { i = min(i, nst - 1) + rot; return s0 + (i < nst ? i : i - nst); };
-            // The step table of the sweep lives in registers: lane l of every wave holds steps seg + l, seg + 64 + l, ... of
-            // the current segment of 256 sweep positions; a step's fields come out by v_readlane with the (uniform) sweep
-            // position.  The table loads leave the per-step path and the in-order vector-memory queue; a sweep longer than
-            // 256 steps (rare) restarts the pipeline per segment.
-            int seg = 0, lim = 0;
-            int tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0, te0 = 0, te1 = 0, te2 = 0, te3 = 0;  // col0 / e_begin / e_end
-            auto getstep = [&](int k, int &col0, int &eb, int &ee) {
-                const int r = min(k, lim - 1) - seg;
-                col0 = step_field(tc0, tc1, tc2, tc3, r);
-                eb = step_field(tb0, tb1, tb2, tb3, r);
-                ee = step_field(te0, te1, te2, te3, r);
-            };
-            struct Ent {
-                d2_t va, vb;
-                uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
-            };
-            typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));  // one 12-byte load per lane
-            auto issue_entries = [&](Ent &E, int k) {
-                int col0, eb, ee_;
-                getstep(k, col0, eb, ee_);
-                const int e = eb + K * tid;
-                const int ee = (e < ee_) ? e : eb;
-                E.va = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee));
-                E.vb = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(t.tval + ee) + 1);
-                const u3_t w = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.tidx3 + (ee / K) * 3));
-                E.i0 = w.x;
-                E.i1 = w.y;
-                E.i2 = w.z;
-            };
-            auto issue_tile = [&](double (&tl)[TPT], int k) {
-                int col0, eb, ee_;
-                getstep(k, col0, eb, ee_);
-#pragma unroll
-                for (int j = 0; j < TPT; ++j) tl[j] = vec[min(col0 + tid + j * NT, ncols - 1)];
-            };
-            auto process = [&](const Ent &E, int k) {
-                int col0, eb, ee_;
-                getstep(k, col0, eb, ee_);
-                if (K * tid < ee_ - eb) {
-                    const double v[K] = {E.va.x, E.va.y, E.vb.x, E.vb.y};
-                    const uint32_t c0 = E.i0, c1 = E.i1, c2 = E.i2;
-                    const uint32_t id[K] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
-                    uint32_t rw[K];
-                    double a[K], y[K];
-#pragma unroll
-                    for (int k2 = 0; k2 < K; ++k2) {
-                        rw[k2] = id[k2] & (R - 1);
-                        a[k2] = acc[rw[k2]];
-                        y[k2] = ytile[id[k2] >> kTileRowBits];
-                    }
-                    double sk[K];
-                    sk[0] = a[0] + v[0] * y[0];
-#pragma unroll
-                    for (int k2 = 1; k2 < K; ++k2) sk[k2] = ((rw[k2] == rw[k2 - 1]) ? sk[k2 - 1] : a[k2]) + v[k2] * y[k2];
-#pragma unroll
-                    for (int k2 = 0; k2 < K; ++k2)
-                        if (k2 == K - 1 || rw[k2] != rw[k2 + 1]) acc[rw[k2]] = sk[k2];
-                }
-            };
-            // One step k: [barrier] stage tile k (loaded during the previous step), issue the loads of tile k + 1, [barrier],
-            // fold the step's entries (loaded TWO steps ago) into the accumulators, reload their register set with the
-            // entries of step k + 2.  In the in-order vector-memory queue the entries of step k + 1 are younger than tile k:
-            // the wait for the tile leaves one step's entry loads (from HBM) in flight across both barriers.  Measured on
-            // config 5 (profiles/r02_pmc_summary.md): x-half 713 -> 673 us; a third entry set and a second tile set in
-            // flight (128 VGPRs) gave 685 us.
-            auto step = [&](Ent &E, double (&tl)[TPT], int k) {
-                lds_barrier();  // every lane is done with the previous tile
-#pragma unroll
-                for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
-                issue_tile(tl, k + 1);
-                lds_barrier();  // tile visible
-                process(E, k);
-                issue_entries(E, k + 2);
-            };
-            for (seg = 0; seg < nst; seg += 256) {
-                lim = min(seg + 256, nst);
-                {
-                    const TileStep q0 = t.steps[sidx(seg + lane)], q1 = t.steps[sidx(seg + 64 + lane)];
-                    const TileStep q2 = t.steps[sidx(seg + 128 + lane)], q3 = t.steps[sidx(seg + 192 + lane)];
-                    tc0 = q0.col0; tb0 = q0.e_begin; te0 = q0.e_end;
-                    tc1 = q1.col0; tb1 = q1.e_begin; te1 = q1.e_end;
-                    tc2 = q2.col0; tb2 = q2.e_begin; te2 = q2.e_end;
-                    tc3 = q3.col0; tb3 = q3.e_begin; te3 = q3.e_end;
-                }
-                // prologue in the steady state's issue order; the scheduling barriers keep the compiler from interleaving
-                // the groups, which would force the loop header's wait down to vmcnt(0)
-                Ent E0, E1;
-                double tl[TPT];
-                __builtin_amdgcn_sched_barrier(0);
-                issue_entries(E0, seg);
-                __builtin_amdgcn_sched_barrier(0);
-                issue_tile(tl, seg);
-                __builtin_amdgcn_sched_barrier(0);
-                issue_entries(E1, seg + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                // unrolled by four (two entry sets); the compiler's counted waits are only conservative in the first step
-                // behind the loop header, where the prologue and the back edge merge
-                for (int k = seg;;) {
-                    step(E0, tl, k);
-                    if (++k >= lim) break;
-                    step(E1, tl, k);
-                    if (++k >= lim) break;
-                    step(E0, tl, k);
-                    if (++k >= lim) break;
-                    step(E1, tl, k);
-                    if (++k >= lim) break;
-                }
-            }
-        }
-        // remainder entries (propagation blocking, tiled.h): the products were written by k_far_products into this
-        // super-block's slice of P; a step streams its range of P into the tile buffer (coalesced) next to the
-        // step's entry codes in (row, CSR) order, then one head lane per row segment adds that row's products in order
-        double *prod = ytile;
-        uint32_t *rq = reinterpret_cast<uint32_t *>(ytile + kTileRemCap);
-        for (int s = smid; s < s1; ++s) {
-            const TileStep st = t.steps[s];
-            const int cnt = st.e_end - st.e_begin;
-            lds_barrier();
-#pragma unroll
-            for (int k = 0; k < kTileRemK; ++k) {
-                const int el = tid + k * NT;
-                if (el < cnt) {
-                    prod[el] = __builtin_nontemporal_load(t.P + st.e_begin + el);
-                    rq[el + 1] = __builtin_nontemporal_load(t.rq + st.e_begin + el);
-                }
-            }
-            if (tid == 0) rq[0] = 0xffffu;
-            lds_barrier();
-#pragma unroll
-            for (int k = 0; k < kTileRemK; ++k) {
-                const int el = tid + k * NT;
-                if (el < cnt) {
-                    const uint32_t w = rq[el + 1];
-                    const uint32_t rw = w & 0xffffu;
-                    if ((rq[el] & 0xffffu) != rw) {
-                        double sacc = acc[rw];
-                        uint32_t q = w;
-                        int j = el;
-                        do {
-                            sacc += prod[q >> 16];
-                            ++j;
-                            q = rq[j + 1];
-                        } while (j < cnt && (q & 0xffffu) == rw);
-                        acc[rw] = sacc;
-                    }
-                }
-            }
-        }
+        if (s0 < smid) tiled_sweep<2, 1, REP>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
+        tiled_remainder(t, smid, s1, acc, ytile, tid);
         lds_barrier();
         const int r0 = sb * R;
         const int nr = min(R, A.rows - r0);
@@ -416,6 +500,70 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         __syncthreads();
         block_store_partials_in<NACC, kTileThreads / kWave>(racc, epi.partials, epi.stride, reinterpret_cast<double(*)[NACC]>(ytile));
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Piece form, for matrices with fewer super-blocks than the chip has workgroup slots (a 1/8 row shard of config 5 has 153,
+// a 1/4 shard 306; a workgroup's sweep is a chain of dependent steps, so the chip only streams when every slot has one).
+// The tile steps of all super-blocks, laid end to end, are cut into equal pieces (tiled_build.hip, finish_schedule); a
+// workgroup sweeps the segments of its piece -- each a range of one super-block's steps -- into fresh accumulators and
+// stores them (the super-block's last segment adds the remainder); k_tiled_finish adds a row's segments in order and
+// runs the epilogue.  Per-row summation order: tiles ascending, remainder last -- fixed by the matrix and the piece count.
+// ------------------------------------------------------------------------------------------------
+template <bool REP, bool STAMP = false>
+__global__ void __launch_bounds__(kTileThreads, 4) k_tiled_part(CsrDev A, const double *__restrict__ vec) {
+    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols;
+    __shared__ double acc[R];
+    __shared__ double ytile[T];
+    const TiledDev &t = A.tiled;
+    const int tid = threadIdx.x;
+    // XCD-aware: a contiguous range of pieces per XCD (neighbouring pieces read the same vector tiles)
+    const int per = (t.n_pieces + 7) / 8;
+    const int pc = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (pc >= t.n_pieces) return;
+    for (int sg = t.piece_ptr[pc]; sg < t.piece_ptr[pc + 1]; ++sg) {
+        const int4 d = t.segs[sg];
+        const int sb = d.x;
+        lds_barrier();  // the previous segment's store is done with acc
+        for (int i = tid; i < R; i += NT) acc[i] = 0.0;
+        const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
+        unsigned long long *st = STAMP ? t.stamps + static_cast<size_t>(pc) * 16 : nullptr;
+        unsigned long long c0 = 0, c1 = 0, c2 = 0;
+        if (STAMP) c0 = __builtin_amdgcn_s_memtime();
+        if (d.z > 0) tiled_sweep<3, 2, REP, STAMP>(t, s0, smid - s0, d.y, d.z, vec, A.cols, acc, ytile, tid, st);
+        if (STAMP) c1 = __builtin_amdgcn_s_memtime();
+        if (d.w) tiled_remainder(t, smid, s1, acc, ytile, tid);
+        lds_barrier();
+        if (STAMP) c2 = __builtin_amdgcn_s_memtime();
+        double *out = t.parts + static_cast<size_t>(sg) * R;
+        for (int i = tid; i < R; i += NT) out[i] = acc[i];
+        if (STAMP && tid == 0) {
+            st[8] += c1 - c0;   // whole sweep (table loads and pipeline fill included)
+            st[9] += c2 - c1;   // remainder
+            st[10] += __builtin_amdgcn_s_memtime() - c2;  // issue of the partial-sum stores
+        }
+    }
+}
+
+template <class Epi>
+__global__ void __launch_bounds__(kThreads) k_tiled_finish(CsrDev A, Epi epi) {
+    constexpr int NACC = Epi::NACC, R = kTileRows;
+    double racc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
+    epi.begin();
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r < A.rows) {
+        const int sb = r / R;
+        const int a = A.tiled.slot_ptr[sb], b = A.tiled.slot_ptr[sb + 1];
+        const double *p = A.tiled.parts + (r % R);
+        double sum = 0.0;
+        for (int k = a; k < b; ++k) sum = (k == a) ? p[static_cast<size_t>(k) * R] : sum + p[static_cast<size_t>(k) * R];
+        const double sv[1] = {sum};
+        typename Epi::Row rw = epi.load_row(r);
+        epi.apply(r, rw, sv, racc);
+    }
+    if constexpr (NACC > 0) block_store_partials<NACC>(racc, epi.partials, epi.stride);
 }
 
 __global__ void __launch_bounds__(kThreads) k_tiled_refresh(long n, const int *perm, const double *csr_val, double *out) {
@@ -689,7 +837,15 @@ static void launch_fused(const CsrDev &M, const Epi &e, hipStream_t s) {
         if (M.tiled.valid) {
             if (M.tiled.n_groups > 0)
                 hipLaunchKernelGGL(k_far_products, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
-            hipLaunchKernelGGL(k_tiled_fused<Epi>, dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+            if (M.tiled.n_pieces > 0) {
+                if (M.tiled.stamps) hipLaunchKernelGGL((k_tiled_part<false, true>), dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
+                else if (M.tiled.repeats) hipLaunchKernelGGL(k_tiled_part<true>, dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
+                else hipLaunchKernelGGL(k_tiled_part<false>, dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
+                hipLaunchKernelGGL(k_tiled_finish<Epi>, dim3(M.tiled_finish_grid()), dim3(kThreads), 0, s, M, e);
+                return;
+            }
+            if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+            else hipLaunchKernelGGL((k_tiled_fused<Epi, false>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
             return;
         }
     }

@@ -153,7 +153,8 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         const char *md = std::getenv("HPRLP_TILED_MIN_DENSE");
         // measured on shard-shaped matrices of the banded benchmark: 305 super-blocks 0.31 ms tiled vs
         // 0.38 ms stream, 153 super-blocks 0.21 ms both -> one super-block per CU is the break-even
-        const int min_rows = mr ? std::atoi(mr) : 256 * kTileRows;
+        // (round 2: matrices with fewer super-blocks than CUs run the split form -- several workgroups per super-block)
+        const int min_rows = mr ? std::atoi(mr) : 32 * kTileRows;
         const double min_dense = md ? std::atof(md) : 0.5;
         const char *ht = std::getenv("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
@@ -180,7 +181,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
             }
             pt.tick("  build tiled copy (device)");
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && ci) {  // the host builder needs the host column indices
-            planned_grid = ((rows + kTileRows - 1) / kTileRows + 7) / 8 * 8;
+            planned_grid = std::max(((rows + kTileRows - 1) / kTileRows + 7) / 8 * 8, (rows + kThreads - 1) / kThreads);  // fused grid or the split form's finish grid
             tiling = std::async(std::launch::async, [=]() -> std::shared_ptr<TiledHost> {
                 (void)keep;  // keeps the host arrays alive for the duration of the build
                 auto th = std::make_shared<TiledHost>();
@@ -217,6 +218,8 @@ void DeviceMatrix::refresh_tiled(hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 Solver::~Solver() {
+    A.tiled.dump_stamps();
+    AT.tiled.dump_stamps();
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
     if (ev_ready) (void)hipEventDestroy(ev_ready);
     if (ev_done_x) (void)hipEventDestroy(ev_done_x);

@@ -56,6 +56,16 @@ struct TiledDev {
     int nsb = 0;               // super-blocks
     int per = 0;               // super-blocks per XCD: nsb rounded up to a multiple of 8, / 8
     int grid = 0;              // launch grid: 8 * min(per, resident workgroups of one XCD)
+    bool repeats = false;      // some tile has more than one step: the kernels skip re-staging an unchanged tile
+    // piece form (k_tiled_part / k_tiled_finish, kernels.hip): n_pieces > 0 -- the tile steps of all super-blocks, laid end
+    // to end, are cut into n_pieces equal ranges, one workgroup each; a piece is a list of segments (a range of one
+    // super-block's steps), every segment stores its partial row sums in its own slot of `parts`
+    int n_pieces = 0;
+    const int *piece_ptr = nullptr;    // n_pieces + 1: segments of a piece
+    const int4 *segs = nullptr;        // {super-block, first step (relative), steps, 1 if the super-block's last segment}
+    const int *slot_ptr = nullptr;     // nsb + 1: segments (= slots of `parts`) of a super-block, in summation order
+    double *parts = nullptr;           // (number of segments) * kTileRows partial row sums
+    unsigned long long *stamps = nullptr;  // HPRLP_TILE_STAMPS=1 (diagnostic): 16 shader-clock sums per piece
     const int *sb_ptr = nullptr;   // nsb+1: steps of a super-block
     const int *sb_mid = nullptr;   // nsb: first remainder step
     const TileStep *steps = nullptr;
@@ -122,6 +132,11 @@ struct DeviceTiled {
     // alignment period in tiles (0 = no rotation)
     void finish_schedule(hipStream_t s);
     int rot_period = 0;
+    DBuf<double> parts;
+    DBuf<int> piece_ptr, slot_ptr;
+    DBuf<unsigned long long> stamps;
+    void dump_stamps() const;  // diagnostic: phase times of the piece form on stderr
+    DBuf<int4> segs;
     // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,
     // too scattered, or too large for 32-bit entry offsets) and nothing is valid.
     bool build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,

@@ -257,6 +257,9 @@ __global__ void __launch_bounds__(kThreads) k_window_widths(int nsb, const int *
     const int w = (steps[smid - 1].col0 - steps[s0].col0) / T + 1;
     atomicAdd(out, static_cast<unsigned long long>(w));  // integer sums: order-independent
     atomicAdd(out + 1, 1ull);
+    int rep = 0;  // tiles with more than one step (dense tiles: more than kTileStepCap entries)
+    for (int s = s0 + 1; s < smid; ++s) rep += steps[s].col0 == steps[s - 1].col0;
+    if (rep) atomicAdd(out + 2, static_cast<unsigned long long>(rep));
 }
 
 __global__ void __launch_bounds__(kThreads) k_rotation(int nsb, int period, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
@@ -286,18 +289,90 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
     const int resident = std::max(1, cus / 8) * kTileResidentPerCu;
     view.per = (nsb + 7) / 8;
     view.grid = 8 * std::min(view.per, resident);
+    // Fewer super-blocks than resident workgroup slots (row shards of a multi-GPU run, mid-size LPs): one workgroup per
+    // super-block leaves CUs idle and every workgroup with a full-length sweep.  The piece form cuts the tile steps of
+    // all super-blocks, laid end to end, into as many equal pieces as there are slots (tiled.h).  HPRLP_TILE_PIECES
+    // forces a piece count (tests), 0 disables.
+    view.n_pieces = 0;
+    int want = (nsb > 0 && nsb <= resident * 8) ? resident * 8 : 0;
+    if (const char *e = std::getenv("HPRLP_TILE_PIECES")) want = std::max(0, std::atoi(e));
+    if (want > 0 && nsb > 0) {
+        std::vector<int> h_ptr(static_cast<size_t>(nsb) + 1), h_mid(static_cast<size_t>(nsb));
+        sb_ptr.download(h_ptr.data(), h_ptr.size());
+        sb_mid.download(h_mid.data(), h_mid.size());
+        // positions: a super-block's tile steps, then its remainder steps (which stay with its last segment but count as
+        // work, so the pieces that carry a remainder get fewer tile steps)
+        long total = 0;
+        for (int sb = 0; sb < nsb; ++sb) total += h_ptr[sb + 1] - h_ptr[sb];
+        const int np = static_cast<int>(std::max<long>(1, std::min<long>(want, std::max<long>(total, 1))));
+        std::vector<int4> h_segs;
+        std::vector<int> h_piece(static_cast<size_t>(np) + 1, 0), h_slot(static_cast<size_t>(nsb) + 1, 0);
+        // walk the super-blocks; global step position g; piece of a position = g * np / total
+        long g = 0;
+        std::vector<std::vector<int4>> by_piece(static_cast<size_t>(np));
+        for (int sb = 0; sb < nsb; ++sb) {
+            const int nst = h_mid[sb] - h_ptr[sb];
+            h_slot[sb] = 0;  // filled below
+            if (nst == 0) {  // remainder only (or an empty super-block): one segment, attached to the piece of position g
+                const int pc = static_cast<int>(total > 0 ? std::min<long>(np - 1, g * np / total) : 0);
+                by_piece[pc].push_back(make_int4(sb, 0, 0, 1));
+                g += h_ptr[sb + 1] - h_mid[sb];
+                continue;
+            }
+            int done = 0;
+            while (done < nst) {
+                const int pc = static_cast<int>(std::min<long>(np - 1, (g + done) * np / total));
+                // first position of the next piece: the smallest q with q * np / total >= pc + 1
+                const long nxt = pc + 1 >= np ? total : ((static_cast<long>(pc) + 1) * total + np - 1) / np;
+                const int cnt = static_cast<int>(std::min<long>(nst - done, std::max<long>(1, nxt - (g + done))));
+                by_piece[pc].push_back(make_int4(sb, done, cnt, done + cnt == nst ? 1 : 0));
+                done += cnt;
+            }
+            g += h_ptr[sb + 1] - h_ptr[sb];
+        }
+        // segments in piece order; a super-block's segments are consecutive in that order (pieces are ranges of the global
+        // step sequence), so its slots are a contiguous range in summation order
+        for (int pc = 0; pc < np; ++pc) {
+            h_piece[pc] = static_cast<int>(h_segs.size());
+            for (const int4 &sg : by_piece[pc]) h_segs.push_back(sg);
+        }
+        h_piece[np] = static_cast<int>(h_segs.size());
+        {
+            size_t i = 0;
+            for (int sb = 0; sb < nsb; ++sb) {
+                h_slot[sb] = static_cast<int>(i);
+                while (i < h_segs.size() && h_segs[i].x == sb) ++i;
+            }
+            h_slot[nsb] = static_cast<int>(i);
+            if (i != h_segs.size()) throw std::runtime_error("piece schedule: segments out of super-block order");
+        }
+        piece_ptr.alloc(h_piece.size()); piece_ptr.upload(h_piece.data(), h_piece.size());
+        slot_ptr.alloc(h_slot.size()); slot_ptr.upload(h_slot.data(), h_slot.size());
+        segs.alloc(h_segs.size()); segs.upload(h_segs.data(), h_segs.size());
+        parts.alloc_zero(h_segs.size() * static_cast<size_t>(kTileRows));
+        view.n_pieces = np;
+        view.piece_ptr = piece_ptr.p;
+        view.slot_ptr = slot_ptr.p;
+        view.segs = segs.p;
+        view.parts = parts.p;
+        if (const char *e = std::getenv("HPRLP_TILE_STAMPS"); e && e[0] == '1' && !view.repeats) {
+            stamps.alloc_zero(static_cast<size_t>(np) * 16);
+            view.stamps = stamps.p;
+        }
+    }
     rot_period = 0;
     if (nsb <= 0 || n_steps <= 0) return;
-    if (const char *e = std::getenv("HPRLP_TILE_ROT")) rot_period = std::atoi(e);
-    else {
-        DBuf<unsigned long long> acc(2);
-        HIP_CHECK(hipMemsetAsync(acc.p, 0, 2 * sizeof(unsigned long long), s));
+    {
+        DBuf<unsigned long long> acc(3);
+        HIP_CHECK(hipMemsetAsync(acc.p, 0, 3 * sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_window_widths, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, acc.p);
-        unsigned long long h[2] = {0, 0};
+        unsigned long long h[3] = {0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         if (h[1] > 0) rot_period = static_cast<int>((h[0] + h[1] - 1) / h[1]);
+        view.repeats = h[2] > 0;
     }
+    if (const char *e = std::getenv("HPRLP_TILE_ROT")) rot_period = std::atoi(e);
     if (rot_period > 0) hipLaunchKernelGGL(k_rotation, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, rot_period, sb_ptr.p, sb_mid.p, steps.p);
     HIP_CHECK(hipStreamSynchronize(s));
 }
@@ -603,6 +678,21 @@ void DeviceTiled::build_far(int cols, hipStream_t s) {
     view.f_val = f_val.p;
     view.f_pos = f_pos.p;
     view.f_lcol = f_lcol.p;
+}
+
+void DeviceTiled::dump_stamps() const {
+    if (!stamps.p || view.n_pieces <= 0) return;
+    std::vector<unsigned long long> h(static_cast<size_t>(view.n_pieces) * 16);
+    stamps.download(h.data(), h.size());
+    double sum[16] = {0};
+    for (int p = 0; p < view.n_pieces; ++p)
+        for (int k = 0; k < 16; ++k) sum[k] += static_cast<double>(h[static_cast<size_t>(p) * 16 + k]);
+    const double steps = std::max(sum[6], 1.0);
+    static const char *name[6] = {"barrier A", "tile wait + LDS store", "tile load issue", "barrier B", "entries wait + LDS accumulate", "entry load issue"};
+    std::fprintf(stderr, "[tile stamps] %d pieces, %.0f steps; shader cycles per step (wave 0):\n", view.n_pieces, sum[6]);
+    for (int k = 0; k < 6; ++k) std::fprintf(stderr, "[tile stamps]   %-32s %9.1f\n", name[k], sum[k] / steps);
+    std::fprintf(stderr, "[tile stamps]   whole sweep per step %9.1f; per piece: remainder %.0f, store issue %.0f cycles\n", sum[8] / steps,
+                 sum[9] / view.n_pieces, sum[10] / view.n_pieces);
 }
 
 }  // namespace hprlp

@@ -105,3 +105,36 @@ def test_tiled_runs_are_bit_reproducible(gpu, force_tiled):
     for k in states[0][2]:
         assert np.array_equal(states[0][2][k], states[1][2][k]), k
     model.free()
+
+
+@pytest.mark.parametrize("pieces", [3, 7, 64])
+def test_piece_form_matches_oracle(gpu, force_tiled, pieces):
+    """Matrices with fewer super-blocks than workgroup slots run the piece form: the tile steps of all super-blocks, end
+    to end, cut into equal pieces (3: a piece spans super-blocks; 64: several pieces per super-block), one workgroup
+    each, partial row sums added by a finish kernel that runs the epilogue (kernels.hip: k_tiled_part /
+    k_tiled_finish).  Same numbers as the oracle to rounding, check variants and reductions included."""
+    os.environ["HPRLP_TILE_PIECES"] = str(pieces)
+    try:
+        m = n = 30000
+        lp, model = build(m, n, 12, 600)
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+        assert s.info()["tiled"] == 3
+        ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                         O.Params.default(use_CR_scaling=0))
+        s.scale()
+        adopt_gpu_data(s, ref)
+        st = run_steps(s, ref, 0.6, 1.4, [(23, True), (5, True), (11, False)])
+        for name in NAMES_N + NAMES_M:
+            np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+        got = s.residuals(40, True)
+        assert np.isfinite(got["kkt"])
+        lam, it = s.power_iteration()
+        lam_ref, it_ref = ref.power_iteration()
+        assert it == it_ref and abs(lam - lam_ref) <= 1e-11 * lam_ref
+        s.close()
+        r = model.solve(hprlp.Parameters(stop_tol=1e-4, use_presolve=False, max_iter=3000))
+        if r.status == "OPTIMAL":
+            assert abs(r.primal_obj - lp["obj_star"]) <= 1e-4 * (1 + abs(lp["obj_star"]))
+        model.free()
+    finally:
+        os.environ.pop("HPRLP_TILE_PIECES", None)
