@@ -45,7 +45,11 @@ WORKLOADS = {
     "c5_shard_like": (1_250_000, 1_250_000, 20, 100_000),  # rows and band of one of 8 shards of c5 (kernel-shape experiments)
     "c5_small": (1_000_000, 1_000_000, 20, 10_000),
     "c5_tiny": (100_000, 100_000, 20, 1_000),
+    # config 5 handed over in a RANDOM row / column order: what the set-up time locality ordering (csrc/reorder.cpp) is for
+    "c5_permuted": (10_000_000, 10_000_000, 20, 100_000),
+    "c5_small_permuted": (2_000_000, 2_000_000, 20, 20_000),
 }
+PERMUTED = {"c5_permuted", "c5_small_permuted"}
 
 
 def log(*a):
@@ -65,6 +69,25 @@ def gen_banded(m, n, per_row, band, seed=5, row0=0, rows=None, threads=0):
     if rc != 0:
         raise RuntimeError(H.last_error())
     return rp, ci, v
+
+
+def permute_lp(lp, seed=99):
+    """The same LP with rows and columns renumbered at random (the matrix through hprlp_permute_csr_host)."""
+    m, n = lp["m"], lp["n"]
+    rng = np.random.default_rng(seed)
+    pr = rng.permutation(m).astype(np.int32)   # new -> old
+    pc = rng.permutation(n).astype(np.int32)
+    c_old2new = np.empty(n, np.int32); c_old2new[pc] = np.arange(n, dtype=np.int32)
+    rp, ci, v = lp["rowptr"], lp["colind"], lp["values"]
+    rp2 = np.zeros(m + 1, np.int32); ci2 = np.zeros(len(ci), np.int32); v2 = np.zeros(len(v), np.float64)
+    L = H.lib()
+    ip, dp = H.c_int_p, H.c_dbl_p
+    rc = L.hprlp_permute_csr_host(m, n, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), v.ctypes.data_as(dp), pr.ctypes.data_as(ip),
+                                  c_old2new.ctypes.data_as(ip), rp2.ctypes.data_as(ip), ci2.ctypes.data_as(ip), v2.ctypes.data_as(dp), 0)
+    if rc != 0:
+        raise RuntimeError(H.last_error())
+    return dict(m=m, n=n, rowptr=rp2, colind=ci2, values=v2, AL=lp["AL"][pr], AU=lp["AU"][pr], l=lp["l"][pc], u=lp["u"][pc],
+                c=lp["c"][pc], obj_star=lp["obj_star"])
 
 
 def banded_lp(m, n, per_row, band, seed=5):
@@ -254,6 +277,8 @@ def main():
     m, n, per_row, band = WORKLOADS[args.workload]
     t0 = time.time()
     lp = banded_lp(m, n, per_row, band)
+    if args.workload in PERMUTED:
+        lp = permute_lp(lp)
     nnz = len(lp["values"])
     if rank == 0:
         log(f"[bench] generated {args.workload}: {m}x{n}, nnz={nnz} in {time.time() - t0:.1f}s")
@@ -280,7 +305,8 @@ def main():
     lam, pw_it = s.power_iteration()
     s.init(-1.0, lam * 1.01)
     sc = s.scalars()
-    tiled = s.info()["tiled"]
+    info = s.info()
+    tiled = info["tiled"]
     if rank == 0:
         log(f"[bench] setup {time.time() - t0:.1f}s (device setup {sc['setup_time']:.2f}s, scaling {sc['scaling_time']:.2f}s, "
             f"power iteration {sc['power_time']:.2f}s / {pw_it} its, lambda_max={lam:.4g})")
@@ -326,8 +352,11 @@ def main():
             "metric": "HPR iterations/sec (FP64)", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": P, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 5: banded-random CSR LP {m}x{n}, nnz={nnz} "
+            "config": {"workload": (f"BASELINE config 5: banded-random CSR LP {m}x{n}, nnz={nnz} " if args.workload == "c5" else
+                                    f"{args.workload}: banded-random CSR LP {m}x{n}, nnz={nnz}"
+                                    f"{', rows and columns renumbered at random' if args.workload in PERMUTED else ''} ") +
                                    f"({'row-partitioned over %d GPUs, 2 RCCL exchanges per iteration' % P if P > 1 else 'one GPU'})",
+                       "reordered_at_setup": bool(info.get("reordered")),
                        "m": m, "n": n, "nnz": nnz, "parallelism": f"rowpart{P}",
                        "exchange": None if dinfo is None else {
                            "kind_m": "neighbour send/recv" if dinfo["m_sparse"] else "all-gather",

@@ -10,6 +10,7 @@
 #include "hprlp_amd.h"
 #include "dist.h"
 #include "presolve.h"
+#include "reorder.h"
 #include "solver.h"
 #include "version.h"
 
@@ -496,39 +497,57 @@ namespace {
 struct VecRef {
     double *p;
     long n;
+    char kind;  // 'r': per row of A, 'c': per column, '-': raw (matrix values)
 };
 VecRef find_vector(Solver &s, const std::string &name) {
-    if (name == "x") return {s.x.p, s.n_loc};
-    if (name == "last_x") return {s.last_x.p, s.n_loc};
-    if (name == "x_hat") return {s.x_hat, s.n_loc};
-    if (name == "x_bar") return {s.x_bar, s.n_loc};
-    if (name == "z_bar") return {s.z_bar.p, s.n_loc};
-    if (name == "x_temp") return {s.x_temp, s.n_loc};
-    if (name == "y") return {s.y, s.m_loc};
-    if (name == "last_y") return {s.last_y.p, s.m_loc};
-    if (name == "y_bar") return {s.y_bar, s.m_loc};
-    if (name == "y_obj") return {s.y_obj.p, s.m_loc};
-    if (name == "y_temp") return {s.y_temp.p, s.m_loc};
-    if (name == "AL") return {s.AL.p, s.m_loc};
-    if (name == "AU") return {s.AU.p, s.m_loc};
-    if (name == "l") return {s.l.p, s.n_loc};
-    if (name == "u") return {s.u.p, s.n_loc};
-    if (name == "c") return {s.c.p, s.n_loc};
-    if (name == "row_norm") return {s.row_norm.p, s.m_loc};
-    if (name == "col_norm") return {s.col_norm.p, s.n_loc};
-    if (name == "A_val") return {s.A.val.p, s.A.view.nnz};
-    if (name == "AT_val") return {s.AT.val.p, s.AT.view.nnz};
-    return {nullptr, -1};
+    if (name == "x") return {s.x.p, s.n_loc, 'c'};
+    if (name == "last_x") return {s.last_x.p, s.n_loc, 'c'};
+    if (name == "x_hat") return {s.x_hat, s.n_loc, 'c'};
+    if (name == "x_bar") return {s.x_bar, s.n_loc, 'c'};
+    if (name == "z_bar") return {s.z_bar.p, s.n_loc, 'c'};
+    if (name == "x_temp") return {s.x_temp, s.n_loc, 'c'};
+    if (name == "y") return {s.y, s.m_loc, 'r'};
+    if (name == "last_y") return {s.last_y.p, s.m_loc, 'r'};
+    if (name == "y_bar") return {s.y_bar, s.m_loc, 'r'};
+    if (name == "y_obj") return {s.y_obj.p, s.m_loc, 'r'};
+    if (name == "y_temp") return {s.y_temp.p, s.m_loc, 'r'};
+    if (name == "AL") return {s.AL.p, s.m_loc, 'r'};
+    if (name == "AU") return {s.AU.p, s.m_loc, 'r'};
+    if (name == "l") return {s.l.p, s.n_loc, 'c'};
+    if (name == "u") return {s.u.p, s.n_loc, 'c'};
+    if (name == "c") return {s.c.p, s.n_loc, 'c'};
+    if (name == "row_norm") return {s.row_norm.p, s.m_loc, 'r'};
+    if (name == "col_norm") return {s.col_norm.p, s.n_loc, 'c'};
+    if (name == "A_val") return {s.A.val.p, s.A.view.nnz, '-'};
+    if (name == "AT_val") return {s.AT.val.p, s.AT.view.nnz, '-'};
+    return {nullptr, -1, '-'};
+}
+// the permutation (device index -> caller's index) that applies to a vector, or null
+const std::vector<int> *perm_of(const Solver &s, const VecRef &v) {
+    if (v.kind == 'r' && !s.perm_r.empty()) return &s.perm_r;
+    if (v.kind == 'c' && !s.perm_c.empty()) return &s.perm_c;
+    return nullptr;
 }
 }  // namespace
 
+// Vectors travel in the caller's numbering: with a set-up time locality ordering in place (solver.h: perm_r / perm_c)
+// the device order is un-permuted on the way out and permuted on the way in.  A_val / AT_val are the device arrays as
+// they are (entries of the permuted matrix).
 extern "C" long hprlp_solver_get_vector(hprlp_solver *h, const char *name, double *out, long cap) {
     GUARD_BEGIN
     VecRef v = find_vector(h->s, name ? name : "");
     if (v.n < 0) throw std::runtime_error(std::string("unknown vector name: ") + (name ? name : "(null)"));
     if (cap < v.n) throw std::runtime_error("output buffer too small");
     HIP_CHECK(hipStreamSynchronize(h->s.stream));
-    if (v.n > 0) HIP_CHECK(hipMemcpy(out, v.p, sizeof(double) * v.n, hipMemcpyDeviceToHost));
+    if (v.n > 0) {
+        if (const std::vector<int> *perm = perm_of(h->s, v)) {
+            std::vector<double> tmp(static_cast<size_t>(v.n));
+            HIP_CHECK(hipMemcpy(tmp.data(), v.p, sizeof(double) * v.n, hipMemcpyDeviceToHost));
+            for (long i = 0; i < v.n; ++i) out[(*perm)[i]] = tmp[i];
+        } else {
+            HIP_CHECK(hipMemcpy(out, v.p, sizeof(double) * v.n, hipMemcpyDeviceToHost));
+        }
+    }
     return v.n;
     GUARD_END(-1)
 }
@@ -539,9 +558,40 @@ extern "C" int hprlp_solver_set_vector(hprlp_solver *h, const char *name, const 
     if (v.n < 0) throw std::runtime_error(std::string("unknown vector name: ") + (name ? name : "(null)"));
     if (len != v.n) throw std::runtime_error("length mismatch");
     HIP_CHECK(hipStreamSynchronize(h->s.stream));
-    if (v.n > 0) HIP_CHECK(hipMemcpy(v.p, in, sizeof(double) * v.n, hipMemcpyHostToDevice));
+    if (v.n > 0) {
+        if (const std::vector<int> *perm = perm_of(h->s, v)) {
+            std::vector<double> tmp(static_cast<size_t>(v.n));
+            for (long i = 0; i < v.n; ++i) tmp[i] = in[(*perm)[i]];
+            HIP_CHECK(hipMemcpy(v.p, tmp.data(), sizeof(double) * v.n, hipMemcpyHostToDevice));
+        } else {
+            HIP_CHECK(hipMemcpy(v.p, in, sizeof(double) * v.n, hipMemcpyHostToDevice));
+        }
+    }
     return 0;
     GUARD_END(-1)
+}
+
+// Locality ordering of a CSR pattern (reorder.cpp), host only: out = {accepted (0/1), tiled share of the entries before,
+// after, clusters, components, seconds}; the permutations (new -> old) are written only when accepted.
+extern "C" int hprlp_locality_ordering(int m, int n, const int *rowptr, const int *col, int *row_new2old, int *col_new2old, double out[6]) {
+    try {
+        if (m <= 0 || n <= 0 || !rowptr || !col || !row_new2old || !col_new2old) throw std::runtime_error("bad arguments");
+        std::vector<int> pr, pc;
+        ReorderStats st;
+        const bool ok = locality_ordering(m, n, rowptr, col, &pr, &pc, &st);
+        if (ok) {
+            std::copy(pr.begin(), pr.end(), row_new2old);
+            std::copy(pc.begin(), pc.end(), col_new2old);
+        }
+        if (out) {
+            out[0] = ok ? 1.0 : 0.0; out[1] = st.fraction_before; out[2] = st.fraction_after;
+            out[3] = st.clusters; out[4] = st.components; out[5] = st.seconds;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return -1;
+    }
 }
 
 extern "C" int hprlp_solver_get_scalars(hprlp_solver *h, double out[16]) {
@@ -566,7 +616,8 @@ extern "C" int hprlp_solver_info(hprlp_solver *h, long out[8]) {
     out[3] = s.A.view.nblk; out[4] = s.AT.view.nblk;
     out[5] = s.A.view.grid(); out[6] = s.AT.view.grid();
     // bit0: A tiled, bit1: A^T tiled, bit2: normal iterations run in the single-workgroup small-LP kernel
-    out[7] = (s.A.view.tiled.valid ? 1 : 0) + (s.AT.view.tiled.valid ? 2 : 0) + (s.use_small && !s.comm ? 4 : 0);
+    // bit3: a set-up time locality ordering is in place (the device works on P A Q)
+    out[7] = (s.A.view.tiled.valid ? 1 : 0) + (s.AT.view.tiled.valid ? 2 : 0) + (s.use_small && !s.comm ? 4 : 0) + (s.perm_r.empty() ? 0 : 8);
     return 0;
     GUARD_END(-1)
 }

@@ -90,3 +90,47 @@ extern "C" int hprlp_gen_banded_csr(int m, int n, int per_row, int band, unsigne
         return -1;
     }
 }
+
+// P A Q for the benchmark's permuted workload: out row i = row row_new2old[i] of A with columns renumbered by
+// col_old2new and sorted.  Multi-threaded over row ranges; out arrays sized like the inputs.  Not part of the solve path.
+extern "C" int hprlp_permute_csr_host(int m, int n, const int *rowptr, const int *col, const double *val, const int *row_new2old,
+                                      const int *col_old2new, int *rowptr_out, int *col_out, double *val_out, int nthreads) {
+    try {
+        if (m <= 0 || n <= 0 || !rowptr || !col || !val || !row_new2old || !col_old2new || !rowptr_out || !col_out || !val_out)
+            throw std::runtime_error("hprlp_permute_csr_host: bad arguments");
+        rowptr_out[0] = 0;
+        for (int i = 0; i < m; ++i) {
+            const int o = row_new2old[i];
+            if (o < 0 || o >= m) throw std::runtime_error("hprlp_permute_csr_host: row permutation out of range");
+            rowptr_out[i + 1] = rowptr_out[i] + (rowptr[o + 1] - rowptr[o]);
+        }
+        if (nthreads <= 0) nthreads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+        nthreads = std::min(nthreads, std::max(1, m / 4096));
+        auto work = [&](int b, int e) {
+            std::vector<std::pair<int, double>> row;
+            for (int i = b; i < e; ++i) {
+                const int o = row_new2old[i];
+                row.clear();
+                for (int k = rowptr[o]; k < rowptr[o + 1]; ++k) row.emplace_back(col_old2new[col[k]], val[k]);
+                std::sort(row.begin(), row.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b2) { return a.first < b2.first; });
+                int p = rowptr_out[i];
+                for (auto &pr : row) {
+                    col_out[p] = pr.first;
+                    val_out[p++] = pr.second;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        const int chunk = (m + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t) {
+            const int b = t * chunk, e = std::min(m, b + chunk);
+            if (b >= e) break;
+            th.emplace_back(work, b, e);
+        }
+        for (auto &t : th) t.join();
+        return 0;
+    } catch (const std::exception &e) {
+        hprlp::set_last_error(e.what());
+        return -1;
+    }
+}

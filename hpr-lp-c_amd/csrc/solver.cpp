@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "dist.h"
+#include "reorder.h"
 
 namespace hprlp {
 
@@ -111,6 +112,10 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
 // rowptr / col / val on the device (rp / ci: the same index arrays on the host).
 void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep) {
     PhaseTimer pt;
+    view.longrows = nullptr;  // (describe() may run again on a permuted copy of the matrix: start from a clean view)
+    view.nlong = 0;
+    view.long_partial = nullptr;
+    view.tiled = TiledDev();
     const int nnz = rp[rows];
     std::vector<int4> lr;
     std::vector<int4> b = build_row_blocks(rows, rp, &lr);
@@ -287,6 +292,10 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             AT.val.alloc(static_cast<size_t>(nnz));
             device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
             pt.tick("device transpose");
+            if (try_reorder(model)) {  // A now holds P A Q: transpose that
+                device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
+                pt.tick("locality ordering + device transpose of the permuted matrix");
+            }
             trp.resize(static_cast<size_t>(n) + 1);
             AT.rowptr.download(trp.data(), trp.size());
             // the column indices of A^T are only needed on the host by the host tiled builder (or its check)
@@ -335,11 +344,23 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             small_posA.upload(posA.data(), posA.size());
         }
     }
-    AL.alloc(m); AL.upload(model->AL, m);
-    AU.alloc(m); AU.upload(model->AU, m);
-    l.alloc(n); l.upload(model->l, n);
-    u.alloc(n); u.upload(model->u, n);
-    c.alloc(n); c.upload(model->c, n);
+    {
+        auto upload_vec = [](DBuf<double> &d, const double *src, int len, const std::vector<int> &perm) {
+            d.alloc(len);
+            if (perm.empty()) {
+                d.upload(src, len);
+            } else {
+                std::vector<double> tmp(static_cast<size_t>(len));
+                for (int i = 0; i < len; ++i) tmp[i] = src[perm[i]];
+                d.upload(tmp.data(), len);
+            }
+        };
+        upload_vec(AL, model->AL, m, perm_r);
+        upload_vec(AU, model->AU, m, perm_r);
+        upload_vec(l, model->l, n, perm_c);
+        upload_vec(u, model->u, n, perm_c);
+        upload_vec(c, model->c, n, perm_c);
+    }
     alloc_work();
     // the tiled copy of A was built from the model's own arrays, which the caller may free once we return; the
     // job of A^T owns its arrays and keeps running under scale()
@@ -347,6 +368,65 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     pt.tick("vectors, work space, tiled copy of A");
     HIP_CHECK(hipDeviceSynchronize());
     setup_time = time_since(t0);
+}
+
+// Large matrix whose given order failed the tiling test: look for a locality ordering (reorder.cpp).  On entry A (device
+// CSR of the model) and the arrays of AT (device transpose, not yet described) are in place.  On success A's device
+// arrays hold P A Q, A is re-described (row blocks, tiled copy) and perm_r / perm_c are set.
+bool Solver::try_reorder(const LP_info_cpu *model) {
+    const char *no = std::getenv("HPRLP_NO_REORDER");
+    if (no && no[0] == '1') return false;
+    const char *nt = std::getenv("HPRLP_NO_TILED");
+    if (nt && nt[0] == '1') return false;
+    const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
+    const int min_rows = mr ? std::atoi(mr) : 32 * kTileRows;
+    if (comm || A.view.tiled.valid || m < min_rows || n < min_rows) return false;
+    const auto t0 = time_now();
+    const sparseMatrix *As = model->A;
+    const long nnz = As->numElements;
+    ReorderStats st;
+    st.fraction_before = tiling_dense_fraction(m, n, As->rowPtr, As->colIndex, nullptr, nullptr);
+    reorder_before = st.fraction_before;
+    if (st.fraction_before >= 0.5) return false;  // the tiled build declined for another reason
+    // pattern of A^T back to the host for the clustering
+    std::vector<int> trp(static_cast<size_t>(n) + 1), tci(static_cast<size_t>(nnz));
+    AT.rowptr.download(trp.data(), trp.size());
+    AT.col.download(tci.data(), tci.size());
+    std::vector<double> pr, pc;
+    cluster_positions(m, n, As->rowPtr, As->colIndex, trp.data(), tci.data(), &pr, &pc, &st);
+    std::vector<int>().swap(tci);
+    DBuf<double> dpr(static_cast<size_t>(m)), dpc(static_cast<size_t>(n));
+    dpr.upload(pr.data(), pr.size());
+    dpc.upload(pc.data(), pc.size());
+    DBuf<int> d_r(static_cast<size_t>(m)), d_c(static_cast<size_t>(n));
+    device_refine_order(m, n, A.rowptr.p, A.col.p, AT.rowptr.p, AT.col.p, dpr.p, dpc.p, 3, d_r.p, d_c.p, stream);
+    std::vector<int> hr(static_cast<size_t>(m)), hc(static_cast<size_t>(n)), c_old2new(static_cast<size_t>(n));
+    d_r.download(hr.data(), hr.size());
+    d_c.download(hc.data(), hc.size());
+    for (int j = 0; j < n; ++j) c_old2new[hc[j]] = j;
+    st.fraction_after = tiling_dense_fraction(m, n, As->rowPtr, As->colIndex, hr.data(), c_old2new.data());
+    reorder_after = st.fraction_after;
+    if (verbose || std::getenv("HPRLP_TIMING"))
+        std::cerr << "[reorder] tiled share of the entries " << st.fraction_before << " -> " << st.fraction_after << " (" << st.clusters
+                  << " clusters, " << st.components << " components, " << time_since(t0) << " s)" << std::endl;
+    if (st.fraction_after < 0.5) {
+        reorder_time = time_since(t0);
+        return false;
+    }
+    // P A Q on the device, swapped into A
+    DBuf<int> nrp(static_cast<size_t>(m) + 1), nci(static_cast<size_t>(nnz));
+    DBuf<double> nval(static_cast<size_t>(nnz));
+    device_permute_csr(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, d_r.p, d_c.p, nrp.p, nci.p, nval.p, stream);
+    A.rowptr = std::move(nrp);
+    A.col = std::move(nci);
+    A.val = std::move(nval);
+    std::vector<int> hrp(static_cast<size_t>(m) + 1);
+    A.rowptr.download(hrp.data(), hrp.size());
+    A.describe(m, n, hrp.data(), nullptr, nullptr);
+    perm_r = std::move(hr);
+    perm_c = std::move(hc);
+    reorder_time = time_since(t0);
+    return true;
 }
 
 void Solver::finish_tiling() {
@@ -650,6 +730,11 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
     {
         std::vector<double> z0(static_cast<size_t>(std::max(m_loc, 1)));
         power_start_vector(m_loc, 1ULL, row_off, z0.data());
+        if (!perm_r.empty()) {  // the start vector is defined in the caller's row numbering
+            std::vector<double> zp(z0.size());
+            for (int i = 0; i < m_loc; ++i) zp[i] = z0[perm_r[i]];
+            z0.swap(zp);
+        }
         HIP_CHECK(hipMemcpyAsync(z, z0.data(), sizeof(double) * m_loc, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
@@ -1101,6 +1186,15 @@ void Solver::collect_solution(HPRLP_results *out) {
     HIP_CHECK(hipMemcpyAsync(out->y, sm1.p, sizeof(double) * m_loc, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(out->z, zo, sizeof(double) * n_loc, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    if (!perm_r.empty()) {  // back to the caller's numbering (reference collect_solution returns the model's order)
+        auto unpermute = [](double *v, const std::vector<int> &perm) {
+            std::vector<double> tmp(v, v + perm.size());
+            for (size_t i = 0; i < perm.size(); ++i) v[perm[i]] = tmp[i];
+        };
+        unpermute(out->x, perm_c);
+        unpermute(out->z, perm_c);
+        unpermute(out->y, perm_r);
+    }
 }
 
 }  // namespace hprlp

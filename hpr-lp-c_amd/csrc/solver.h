@@ -83,6 +83,12 @@ struct Solver {
     Comm *comm = nullptr;
 
     DeviceMatrix A, AT;  // A: m_loc x n (global columns); AT: n_loc x m (global columns)
+    // Set-up time locality ordering (reorder.cpp): when set, the device holds P A Q and all per-row / per-column vectors
+    // in the permuted numbering; perm_r[i] / perm_c[j] = the caller's index of permuted row i / column j.  The C ABI
+    // (get / set_vector, collect_solution) speaks the caller's numbering.
+    std::vector<int> perm_r, perm_c;
+    double reorder_time = 0.0, reorder_before = 0.0, reorder_after = 0.0;
+    bool try_reorder(const LP_info_cpu *model);  // called by setup() for a large matrix that failed the tiling test
     HaloPlan halo_m, halo_n;  // exchange of length-m / length-n gathered vectors (multi-GPU only)
     DBuf<double> AL, AU, l, u, c, row_norm, col_norm;
     // local work vectors

@@ -475,7 +475,10 @@ class Solver:
         out = (C.c_long * 8)()
         self._chk(lib().hprlp_solver_info(self.h, out))
         keys = ("m", "n", "nnz", "blocks_A", "blocks_AT", "grid_y", "grid_x", "tiled")
-        return dict(zip(keys, [int(v) for v in out]))
+        d = dict(zip(keys, [int(v) for v in out]))
+        d["reordered"] = bool(d["tiled"] & 8)  # set-up time locality ordering in place (csrc/reorder.cpp)
+        d["tiled"] &= 7
+        return d
 
     def run(self, max_trace=4096):
         res = CResults()

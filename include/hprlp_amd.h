@@ -80,6 +80,11 @@ int hprlp_solver_time_iterations(hprlp_solver *s, int warmup, int steps, int mod
 int hprlp_gen_banded_csr(int m, int n, int per_row, int band, unsigned long long seed, int row0, int rows,
                          int *rowptr, int *col, double *val, int nthreads);
 
+/* Benchmark utility: P A Q on the host (row i of the result = row row_new2old[i] of A, columns renumbered by col_old2new and
+ * sorted) -- builds the randomly permuted variant of config 5 that the set-up time locality ordering has to undo. */
+int hprlp_permute_csr_host(int m, int n, const int *rowptr, const int *col, const double *val, const int *row_new2old,
+                           const int *col_old2new, int *rowptr_out, int *col_out, double *val_out, int nthreads);
+
 /* ---- row-partitioned multi-GPU solve (new design; the reference is single-GPU) -----------------
  * Rank p owns rows [p*ceil(m/P),...) of A with y/AL/AU and rows [p*ceil(n/P),...) of A^T with
  * x/c/l/u; one in-place RCCL all-gather of the fresh vector slice follows each half-step. */
@@ -141,6 +146,13 @@ void hprlp_presolve_free(hprlp_presolve *p);
 /* out = {primal infeasibility, dual infeasibility, gap (all relative), primal objective, dual objective} on the
  * model as given (reference compute_original_kkt_metrics, src/pslp_integration.cpp:499-580) */
 int hprlp_original_kkt(const LP_info_cpu *model, const double *x, const double *y, const double *z, double out[5]);
+
+/* Set-up time locality ordering (host; hpr-lp-c_amd/csrc/reorder.cpp): row / column permutations (new -> old) that make
+ * the pattern band-like so that the column-tiled kernels apply; the solver runs it by itself when a large matrix
+ * fails the tiling test in its given order (HPRLP_NO_REORDER=1 disables) and returns x, y, z in the caller's numbering
+ * like the reference's collect_solution (src/utils.cu:143-200).  out = {accepted, tiled share before, after, clusters,
+ * components, seconds}. */
+int hprlp_locality_ordering(int m, int n, const int *rowptr, const int *col, int *row_new2old, int *col_new2old, double out[6]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,84 @@
+"""GPU: a large LP handed over in a random row / column order.  The solver finds a locality ordering at set-up
+(csrc/reorder.cpp + reorder_dev.hip), runs the column-tiled kernels on P A Q and speaks the caller's numbering at the
+boundary: vectors and the solution must match the oracle, which works on the LP exactly as given."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import bench_helpers as bh
+from conftest import hprlp
+from oracle import oracle as O
+from test_gpu_kernels import NAMES_M, NAMES_N, run_steps
+
+pytestmark = pytest.mark.gpu
+
+
+def permuted_lp(m, n, per_row, band, seed):
+    lp = bh.banded_lp(m, n, per_row, band)
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    rng = np.random.default_rng(seed)
+    pr, pc = rng.permutation(m), rng.permutation(n)
+    inv_pc = np.empty(n, np.int64); inv_pc[pc] = np.arange(n)
+    B = A[pr]
+    B = sparse.csr_matrix((B.data, inv_pc[B.indices], B.indptr), shape=(m, n))
+    B.sort_indices()
+    out = dict(m=m, n=n, rowptr=B.indptr.astype(np.int32), colind=B.indices.astype(np.int32), values=B.data.copy(),
+               AL=lp["AL"][pr], AU=lp["AU"][pr], l=lp["l"][pc], u=lp["u"][pc], c=lp["c"][pc], obj_star=lp["obj_star"])
+    return out
+
+
+@pytest.fixture(scope="module")
+def lp():
+    return permuted_lp(1_600_000, 1_600_000, 10, 16000, 11)
+
+
+def test_reordered_iterates_match_oracle(gpu, lp):
+    m, n = lp["m"], lp["n"]
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+    info = s.info()
+    assert info["reordered"] and info["tiled"] == 3, info
+    ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                     O.Params.default(use_CR_scaling=0))
+    s.scale()
+    # the data vectors come back in the caller's numbering; sums (Pock-Chambolle row sums, norms) run in another order
+    for name, want in (("AL", ref.AL), ("AU", ref.AU), ("l", ref.l), ("u", ref.u), ("c", ref.c), ("row_norm", ref.row_norm),
+                       ("col_norm", ref.col_norm)):
+        got = s.get(name)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin), name
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-12, err_msg=name)
+    st = run_steps(s, ref, 0.6, 1.4, [(17, True), (5, True), (9, False)])
+    for name in NAMES_N + NAMES_M:
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-12, err_msg=name)
+    lam, it = s.power_iteration()
+    lam_ref, it_ref = ref.power_iteration()
+    assert it == it_ref and abs(lam - lam_ref) <= 1e-10 * lam_ref
+    s.close(); model.free()
+
+
+def test_reordered_solve_returns_the_callers_numbering(gpu, lp):
+    m, n = lp["m"], lp["n"]
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=1e-4, use_presolve=False, max_iter=20000)
+    r = model.solve(prm)
+    os.environ["HPRLP_NO_REORDER"] = "1"
+    try:
+        r0 = model.solve(prm)  # same LP, given order, stream kernel
+    finally:
+        os.environ.pop("HPRLP_NO_REORDER", None)
+    assert r.status == r0.status == "OPTIMAL"
+    assert abs(r.iter - r0.iter) <= 0.1 * r0.iter + 150
+    assert abs(r.primal_obj - lp["obj_star"]) <= 1e-3 * (1 + abs(lp["obj_star"]))
+    np.testing.assert_allclose(r.x, r0.x, rtol=1e-3, atol=1e-3)
+    # KKT on the LP as given
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    Ax = A @ r.x
+    viol = np.maximum(np.maximum(np.where(np.isfinite(lp["AL"]), lp["AL"] - Ax, 0), np.where(np.isfinite(lp["AU"]), Ax - lp["AU"], 0)), 0)
+    b = np.maximum(np.where(np.isfinite(lp["AL"]), np.abs(lp["AL"]), 0), np.where(np.isfinite(lp["AU"]), np.abs(lp["AU"]), 0))
+    assert np.linalg.norm(viol) <= 3e-4 * (1 + np.linalg.norm(b))
+    rd = lp["c"] - A.T @ r.y - r.z
+    assert np.linalg.norm(rd) <= 3e-4 * (1 + np.linalg.norm(lp["c"]))
+    model.free()
