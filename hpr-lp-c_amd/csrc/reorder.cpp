@@ -13,11 +13,12 @@
 //   1. Voronoi clusters: K evenly spaced seed rows, multi-source BFS, every node takes the label of the first
 //      labelled neighbour (a few hops: clusters are local wherever most edges are local);
 //   2. cluster graph: edge counts between clusters; a pair linked only by stray far edges is two orders of magnitude
-//      lighter than a true neighbour pair and is dropped (5 % of the row's heaviest link);
-//   3. spectral ordering of the (small) cluster graph per connected component: second eigenvector of the lazy random
-//      walk by power iteration from a BFS-level start vector;
-//   4. fine positions: a node starts at its cluster's rank; three sweeps "column = median of its rows' positions, row =
-//      median of its columns' positions" (the median ignores the far neighbours), rank-normalised after each half-sweep;
+//      lighter than a true neighbour pair and is dropped (below 15 % of the lighter end's heaviest link);
+//   3. spectral ordering of the (small) cluster graph per connected component: the Fiedler vector (second eigenvector of
+//      the normalised adjacency) by Lanczos from a BFS-level start vector;
+//   4. fine positions: a node starts at its cluster's rank; kReorderSweeps sweeps "column = robust centre (trimmed mean) of
+//      its rows' positions, row = robust centre of its columns' positions" -- the trimming ignores the far neighbours --,
+//      rank-normalised after each half-sweep;
 //   5. the permutations are the argsorts; accepted only if the permuted pattern passes the tiling test that the
 //      given order failed.
 // Everything is deterministic (fixed seeds, no races: the parallel loops write disjoint outputs from read-only inputs).
@@ -82,22 +83,25 @@ void rank_normalise(std::vector<double> &pos, int T) {
     });
 }
 
-// out[i] = median of src[adj] over the neighbours of i (up to 64 of them, evenly sampled); nodes without neighbours keep theirs
-void median_sweep(int rows, const int *rp, const int *ci, const std::vector<double> &src, std::vector<double> &out, int T) {
+// out[i] = robust centre of src over the neighbours of i (at most 32 of them, evenly sampled): the mean of the middle 60 % of
+// the sorted sample.  The trimming drops the few far neighbours like a median does, the averaging has a third of a
+// median's variance on the (roughly uniform) spread of the near neighbours.  Nodes without neighbours keep their value.
+// Same rule as k_centre_sweep (reorder_dev.hip).
+void centre_sweep(int rows, const int *rp, const int *ci, const std::vector<double> &src, std::vector<double> &out, int T) {
     parallel_chunks(rows, T, [&](int, long b, long e) {
-        double buf[64];
+        double buf[32];
         for (long i = b; i < e; ++i) {
             const int k0 = rp[i], len = rp[i + 1] - k0;
             if (len <= 0) continue;
-            const int take = std::min(len, 64);
-            for (int q = 0; q < take; ++q) buf[q] = src[ci[k0 + static_cast<long>(q) * len / take]];
-            std::nth_element(buf, buf + take / 2, buf + take);
-            double med = buf[take / 2];
-            if (take % 2 == 0) {  // even count: mean of the two middle values (keeps pairs of nodes apart)
-                const double lo = *std::max_element(buf, buf + take / 2);
-                med = 0.5 * (med + lo);
-            }
-            out[i] = med;
+            const int take = std::min(len, 32);
+            for (int q = 0; q < take; ++q) buf[q] = src[ci[k0 + static_cast<int>(static_cast<long>(q) * len / take)]];
+            std::sort(buf, buf + take);
+            static const int trim_env = std::getenv("HPRLP_REORDER_TRIM") ? std::atoi(std::getenv("HPRLP_REORDER_TRIM")) : 20;  // percent per side
+            int lo = take * trim_env / 100, hi = take - lo;
+            if (trim_env >= 50 || hi <= lo) { lo = (take - 1) / 2; hi = take / 2 + 1; }  // median
+            double sum = 0.0;
+            for (int q = lo; q < hi; ++q) sum += buf[q];
+            out[i] = sum / static_cast<double>(hi - lo);
         }
     });
 }
@@ -151,7 +155,11 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
     const int *trp = trp_, *tci = tci_;
     // ---- 1. Voronoi clusters
     const long N = static_cast<long>(m) + n;
-    const int K = static_cast<int>(std::max<long>(2, std::min<long>(65536, std::min<long>(m, N / 4096 + 1))));
+    // about 16k nodes per cluster: a BFS ball of that size is as wide as the matrix' natural window anyway, and the
+    // spectral ordering of the cluster graph (dense-ish: every cluster links to all that overlap it) stays cheap
+    long per_cluster = 16384;
+    if (const char *e = std::getenv("HPRLP_REORDER_CLUSTER")) per_cluster = std::max(64L, std::atol(e));
+    const int K = static_cast<int>(std::max<long>(2, std::min<long>(65536, std::min<long>(m, N / per_cluster + 1))));
     S.clusters = K;
     std::vector<int> lab_r(static_cast<size_t>(m), -1), lab_c(static_cast<size_t>(n), -1);
     for (int k = 0; k < K; ++k) lab_r[static_cast<size_t>(static_cast<long>(k) * m / K)] = k;
@@ -195,6 +203,43 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
         if (ch == 0) break;
     }
 
+    // A seed row with a far entry grows a satellite blob around that entry's column (a few percent of the cluster, far
+    // away); such a cluster links two distant places of the cluster graph and folds the spectral order.  Two rounds of
+    // "take the label most of your neighbours have" dissolve the satellites into the clusters around them.
+    {
+        auto majority = [&](int cnt_nodes, const int *xp, const int *xi, const std::vector<int> &src, std::vector<int> &dst) {
+            parallel_chunks(cnt_nodes, T, [&](int, long b, long e) {
+                int buf[32];
+                for (long i = b; i < e; ++i) {
+                    const int k0 = xp[i], len = xp[i + 1] - k0;
+                    int take = 0;
+                    const int want = std::min(len, 32);
+                    for (int q = 0; q < want; ++q) {
+                        const int l = src[xi[k0 + static_cast<int>(static_cast<long>(q) * len / want)]];
+                        if (l >= 0) buf[take++] = l;
+                    }
+                    if (take == 0) continue;
+                    std::sort(buf, buf + take);
+                    int best = buf[0], best_n = 0, run = 0;
+                    for (int q = 0; q < take; ++q) {
+                        run = (q > 0 && buf[q] == buf[q - 1]) ? run + 1 : 1;
+                        if (run > best_n) {
+                            best_n = run;
+                            best = buf[q];
+                        }
+                    }
+                    dst[i] = best;
+                }
+            });
+        };
+        for (int round = 0; round < 2; ++round) {
+            std::vector<int> nc_lab(lab_c), nr_lab(lab_r);
+            majority(n, trp, tci, lab_r, nc_lab);
+            lab_c.swap(nc_lab);
+            majority(m, rp, ci, lab_c, nr_lab);
+            lab_r.swap(nr_lab);
+        }
+    }
     tick("Voronoi clusters");
     // ---- 2. cluster graph from the row side: W[a] = {(b, #edges between rows of a and columns of b)}
     std::vector<int> cl_ptr(static_cast<size_t>(K) + 1, 0), cl_rows;
@@ -255,7 +300,7 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
             auto &g = G[a];
             size_t w = 0;
             for (auto &pr : g)
-                if (pr.second >= 0.05f * std::min(heavy[a], heavy[pr.first]) && pr.second >= 2.0f) g[w++] = pr;
+                if (pr.second >= 0.15f * std::min(heavy[a], heavy[pr.first]) && pr.second >= 2.0f) g[w++] = pr;
             g.resize(w);
         }
     }
@@ -301,51 +346,127 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
             };
             const int far1 = bfs_levels(nodes[0]);
             bfs_levels(far1);
-            // lazy random walk x <- (x + D^-1 S x) / 2, deflated against the stationary vector (degree-weighted mean)
+            // Second eigenvector of the normalised adjacency N = D^-1/2 S D^-1/2 (the Fiedler vector of the component) by
+            // Lanczos with full reorthogonalisation, started from the BFS levels; x = D^-1/2 v orders the clusters.  (A
+            // power iteration needs ~(chain length)^2 steps; stopped early it leaves a share of the third eigenvector --
+            // a full cosine period, i.e. a FOLD in the order that no local refinement repairs.)
             std::vector<int> loc(static_cast<size_t>(K), -1);
             for (int q = 0; q < nc; ++q) loc[nodes[q]] = q;
-            std::vector<double> x(static_cast<size_t>(nc)), y(static_cast<size_t>(nc)), deg(static_cast<size_t>(nc), 0.0);
-            double dsum = 0.0;
+            std::vector<double> x(static_cast<size_t>(nc)), dsq(static_cast<size_t>(nc), 0.0);
             for (int q = 0; q < nc; ++q) {
-                for (auto &pr : G[nodes[q]]) deg[q] += pr.second;
-                dsum += deg[q];
-                x[q] = static_cast<double>(level[nodes[q]]);
+                double d = 0.0;
+                for (auto &pr : G[nodes[q]]) d += pr.second;
+                dsq[q] = std::sqrt(std::max(d, 1e-300));
+                x[q] = static_cast<double>(level[nodes[q]]) * dsq[q];
             }
-            auto deflate = [&](std::vector<double> &v) {
-                double mean = 0.0;
-                for (int q = 0; q < nc; ++q) mean += deg[q] * v[q];
-                mean /= dsum;
+            std::vector<double> v1(dsq);  // top eigenvector D^1/2 1, normalised
+            {
                 double nrm = 0.0;
-                for (int q = 0; q < nc; ++q) {
-                    v[q] -= mean;
-                    nrm += deg[q] * v[q] * v[q];
-                }
-                nrm = std::sqrt(std::max(nrm, 1e-300));
-                for (int q = 0; q < nc; ++q) v[q] /= nrm;
-            };
-            deflate(x);
-            std::vector<int> ord_prev, ord(static_cast<size_t>(nc));
-            const int max_it = 4000;
-            int it = 0;
-            for (; it < max_it; ++it) {
+                for (double d : v1) nrm += d * d;
+                nrm = std::sqrt(nrm);
+                for (double &d : v1) d /= nrm;
+            }
+            auto apply_N = [&](const std::vector<double> &in, std::vector<double> &out) {
                 for (int q = 0; q < nc; ++q) {
                     double sacc = 0.0;
-                    for (auto &pr : G[nodes[q]]) sacc += pr.second * x[loc[pr.first]];
-                    y[q] = 0.5 * (x[q] + (deg[q] > 0 ? sacc / deg[q] : x[q]));
-                }
-                deflate(y);
-                x.swap(y);
-                if ((it + 1) % 100 == 0) {  // stop when the order has settled
-                    std::iota(ord.begin(), ord.end(), 0);
-                    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return x[a] < x[b]; });
-                    if (!ord_prev.empty()) {
-                        long moved = 0;
-                        for (int q = 0; q < nc; ++q) moved += std::abs(ord[q] - ord_prev[q]) > 0;
-                        if (moved * 50 < nc) break;
+                    for (auto &pr : G[nodes[q]]) {
+                        const int r = loc[pr.first];
+                        sacc += pr.second * in[r] / dsq[r];
                     }
-                    ord_prev = ord;
+                    out[q] = sacc / dsq[q];
                 }
+            };
+            auto dot = [&](const std::vector<double> &a2, const std::vector<double> &b2) {
+                double sacc = 0.0;
+                for (int q = 0; q < nc; ++q) sacc += a2[q] * b2[q];
+                return sacc;
+            };
+            const int max_steps = std::min(nc - 1, 400);
+            std::vector<std::vector<double>> Q;
+            std::vector<double> alpha, beta, w(static_cast<size_t>(nc));
+            {
+                const double c1 = dot(x, v1);
+                for (int q = 0; q < nc; ++q) x[q] -= c1 * v1[q];
+                const double nrm = std::sqrt(dot(x, x));
+                if (nrm < 1e-300) {  // degenerate start (all levels equal): any vector orthogonal to v1
+                    for (int q = 0; q < nc; ++q) x[q] = (q % 2 ? 1.0 : -1.0);
+                    const double c2 = dot(x, v1);
+                    for (int q = 0; q < nc; ++q) x[q] -= c2 * v1[q];
+                }
+                const double n2 = std::sqrt(dot(x, x));
+                for (double &d : x) d /= n2;
             }
+            Q.push_back(x);
+            std::vector<double> ritz;  // coefficients of the wanted Ritz vector in the Lanczos basis
+            int it = 0;
+            for (; it < max_steps; ++it) {
+                apply_N(Q[it], w);
+                const double al = dot(w, Q[it]);
+                alpha.push_back(al);
+                // full reorthogonalisation (twice) against v1 and every Lanczos vector so far
+                for (int pass = 0; pass < 2; ++pass) {
+                    const double c1 = dot(w, v1);
+                    for (int q = 0; q < nc; ++q) w[q] -= c1 * v1[q];
+                    for (const auto &qv : Q) {
+                        const double cq = dot(w, qv);
+                        for (int q = 0; q < nc; ++q) w[q] -= cq * qv[q];
+                    }
+                }
+                const double be = std::sqrt(dot(w, w));
+                const int j = static_cast<int>(alpha.size());
+                if ((j % 20 == 0) || be < 1e-12 || it + 1 == max_steps) {
+                    // largest eigenpair of the tridiagonal T_j: bisection on the Sturm count, then inverse iteration
+                    double lo = -2.0, hi = 2.0;
+                    auto count_below = [&](double mu) {  // eigenvalues of T_j smaller than mu
+                        int cnt = 0;
+                        double d = 1.0;
+                        for (int i = 0; i < j; ++i) {
+                            d = alpha[i] - mu - (i > 0 ? beta[i - 1] * beta[i - 1] / d : 0.0);
+                            if (std::abs(d) < 1e-300) d = -1e-300;
+                            if (d < 0) ++cnt;
+                        }
+                        return cnt;
+                    };
+                    for (int bis = 0; bis < 100; ++bis) {
+                        const double mid = 0.5 * (lo + hi);
+                        if (count_below(mid) >= j) hi = mid; else lo = mid;  // all j below mid: the top one is below mid
+                    }
+                    const double theta = 0.5 * (lo + hi);
+                    std::vector<double> sv(static_cast<size_t>(j), 1.0), dd(static_cast<size_t>(j)), rhs(static_cast<size_t>(j));
+                    for (int rep = 0; rep < 3; ++rep) {  // (T - (theta + eps)) sv_new = sv  by the Thomas algorithm
+                        const double mu = theta + 1e-10 * std::max(1.0, std::abs(theta));
+                        rhs = sv;
+                        dd[0] = alpha[0] - mu;
+                        for (int i = 1; i < j; ++i) {
+                            if (std::abs(dd[i - 1]) < 1e-300) dd[i - 1] = 1e-300;
+                            const double f = beta[i - 1] / dd[i - 1];
+                            dd[i] = alpha[i] - mu - f * beta[i - 1];
+                            rhs[i] -= f * rhs[i - 1];
+                        }
+                        if (std::abs(dd[j - 1]) < 1e-300) dd[j - 1] = 1e-300;
+                        sv[j - 1] = rhs[j - 1] / dd[j - 1];
+                        for (int i = j - 2; i >= 0; --i) sv[i] = (rhs[i] - beta[i] * sv[i + 1]) / dd[i];
+                        double nrm = 0.0;
+                        for (double d : sv) nrm += d * d;
+                        nrm = std::sqrt(std::max(nrm, 1e-300));
+                        for (double &d : sv) d /= nrm;
+                    }
+                    ritz = sv;
+                    const double resid = std::abs(be * sv[j - 1]);  // |N y - theta y| of the Ritz pair
+                    if (resid < 1e-6 || be < 1e-12) {
+                        ++it;
+                        break;
+                    }
+                }
+                beta.push_back(be);
+                for (double &d : w) d /= be;
+                Q.push_back(w);
+            }
+            std::fill(x.begin(), x.end(), 0.0);
+            for (size_t i = 0; i < ritz.size(); ++i)
+                for (int q = 0; q < nc; ++q) x[q] += ritz[i] * Q[i][q];
+            for (int q = 0; q < nc; ++q) x[q] /= dsq[q];
+            std::vector<int> ord(static_cast<size_t>(nc));
             S.spectral_iterations += it;
             std::iota(ord.begin(), ord.end(), 0);
             std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return x[a] < x[b]; });
@@ -393,10 +514,11 @@ bool locality_ordering(int m, int n, const int *rp, const int *ci, std::vector<i
     cluster_positions(m, n, rp, ci, trp.data(), tci.data(), &pr_, &pc_, &S);
     tphase = time_now();
     rank_normalise(pr_, T);
-    for (int sweep = 0; sweep < 3; ++sweep) {
-        median_sweep(n, trp.data(), tci.data(), pr_, pc_, T);
+    const int nsweeps = std::getenv("HPRLP_REORDER_SWEEPS") ? std::atoi(std::getenv("HPRLP_REORDER_SWEEPS")) : kReorderSweeps;
+    for (int sweep = 0; sweep < nsweeps; ++sweep) {
+        centre_sweep(n, trp.data(), tci.data(), pr_, pc_, T);
         rank_normalise(pc_, T);
-        median_sweep(m, rp, ci, pc_, pr_, T);
+        centre_sweep(m, rp, ci, pc_, pr_, T);
         rank_normalise(pr_, T);
     }
 

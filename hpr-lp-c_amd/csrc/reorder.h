@@ -7,6 +7,8 @@
 
 namespace hprlp {
 
+constexpr int kReorderSweeps = 3;  // refinement sweeps of the fine positions (host and device paths)
+
 struct ReorderStats {
     double fraction_before = 0.0;  // share of the entries in tiles dense enough to be staged (the tiling test), given order
     double fraction_after = 0.0;   // same, permuted

@@ -14,8 +14,9 @@ namespace {
 
 inline unsigned grid_for(long n) { return static_cast<unsigned>((n + kThreads - 1) / kThreads); }
 
-// out[i] = median of src over the neighbours of i (at most 32, evenly sampled); nodes without neighbours keep their value
-__global__ void __launch_bounds__(kThreads) k_median_sweep(int rows, const int *__restrict__ rp, const int *__restrict__ ci,
+// out[i] = robust centre of src over the neighbours of i (at most 32, evenly sampled): mean of the middle 60 % of the sorted
+// sample (reorder.cpp, centre_sweep: same rule); nodes without neighbours keep their value
+__global__ void __launch_bounds__(kThreads) k_centre_sweep(int rows, const int *__restrict__ rp, const int *__restrict__ ci,
                                                           const double *__restrict__ src, double *__restrict__ out) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= rows) return;
@@ -32,7 +33,10 @@ __global__ void __launch_bounds__(kThreads) k_median_sweep(int rows, const int *
         }
         buf[p] = v;
     }
-    out[i] = (take & 1) ? buf[take / 2] : 0.5 * (buf[take / 2 - 1] + buf[take / 2]);
+    const int lo = take / 5, hi = take - take / 5;
+    double sum = 0.0;
+    for (int q = lo; q < hi; ++q) sum += buf[q];
+    out[i] = sum / static_cast<double>(hi - lo);
 }
 
 __global__ void __launch_bounds__(kThreads) k_pos_keys(int n, const double *__restrict__ pos, unsigned long long *__restrict__ key,
@@ -109,9 +113,9 @@ void device_refine_order(int m, int n, const int *rp, const int *ci, const int *
     DBuf<int> vin(static_cast<size_t>(big));
     rank_normalise(m, pos_r, kin, kout, vin, row_new2old, s);
     for (int sw = 0; sw < sweeps; ++sw) {
-        hipLaunchKernelGGL(k_median_sweep, dim3(grid_for(n)), dim3(kThreads), 0, s, n, trp, tci, pos_r, pos_c);
+        hipLaunchKernelGGL(k_centre_sweep, dim3(grid_for(n)), dim3(kThreads), 0, s, n, trp, tci, pos_r, pos_c);
         rank_normalise(n, pos_c, kin, kout, vin, col_new2old, s);
-        hipLaunchKernelGGL(k_median_sweep, dim3(grid_for(m)), dim3(kThreads), 0, s, m, rp, ci, pos_c, pos_r);
+        hipLaunchKernelGGL(k_centre_sweep, dim3(grid_for(m)), dim3(kThreads), 0, s, m, rp, ci, pos_c, pos_r);
         rank_normalise(m, pos_r, kin, kout, vin, row_new2old, s);
     }
     if (sweeps <= 0) rank_normalise(n, pos_c, kin, kout, vin, col_new2old, s);

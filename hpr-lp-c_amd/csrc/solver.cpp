@@ -399,7 +399,7 @@ bool Solver::try_reorder(const LP_info_cpu *model) {
     dpr.upload(pr.data(), pr.size());
     dpc.upload(pc.data(), pc.size());
     DBuf<int> d_r(static_cast<size_t>(m)), d_c(static_cast<size_t>(n));
-    device_refine_order(m, n, A.rowptr.p, A.col.p, AT.rowptr.p, AT.col.p, dpr.p, dpc.p, 3, d_r.p, d_c.p, stream);
+    device_refine_order(m, n, A.rowptr.p, A.col.p, AT.rowptr.p, AT.col.p, dpr.p, dpc.p, kReorderSweeps, d_r.p, d_c.p, stream);
     std::vector<int> hr(static_cast<size_t>(m)), hc(static_cast<size_t>(n)), c_old2new(static_cast<size_t>(n));
     d_r.download(hr.data(), hr.size());
     d_c.download(hc.data(), hc.size());
