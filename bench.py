@@ -34,6 +34,7 @@ def _load(name, rel):
 
 H = _load("hprlp_amd", os.path.join("hpr-lp-c_amd", "hprlp.py"))
 G = _load("hprlp_lpgen", os.path.join("hpr-lp-c_amd", "lpgen.py"))
+SH = _load("hprlp_shard", os.path.join("hpr-lp-c_amd", "shard.py"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
 
@@ -90,25 +91,55 @@ def permute_lp(lp, seed=99):
                 c=lp["c"][pc], obj_star=lp["obj_star"])
 
 
-def banded_lp(m, n, per_row, band, seed=5):
-    """Planted LP on the banded matrix: box 0<=x<=u, half equality rows, half active/inactive '<=' rows."""
-    from scipy import sparse
-    rp, ci, v = gen_banded(m, n, per_row, band, seed)
-    A = sparse.csr_matrix((v, ci, rp), shape=(m, n), copy=False)
+def planted_vectors(m, n, seed=5):
+    """The matrix-independent draws of the planted LP (full length; cheap next to the matrix), in banded_lp's order."""
     rng = np.random.default_rng(seed + 1)
     at_lower = rng.random(n) < 0.5
     x = np.where(at_lower, 0.0, rng.uniform(0.5, 2.0, size=n))
     z = np.where(at_lower, rng.uniform(0.0, 1.0, size=n), 0.0)
     l = np.zeros(n)
     u = np.where(rng.random(n) < 0.2, x + rng.uniform(0.5, 2.0, size=n), np.inf)
-    b = A @ x
     is_eq = rng.random(m) < 0.5
     active = rng.random(m) < 0.6
-    AL = np.where(is_eq, b, -np.inf)
-    AU = np.where(is_eq | active, b, b + rng.uniform(0.5, 2.0, size=m))
+    slack = rng.uniform(0.5, 2.0, size=m)
     y = np.where(is_eq, rng.normal(size=m), np.where(active, -rng.uniform(0.0, 1.0, size=m), 0.0))
-    c = A.T @ y + z
-    return dict(m=m, n=n, rowptr=rp, colind=ci, values=v, AL=AL, AU=AU, l=l, u=u, c=c, obj_star=float(c @ x))
+    return dict(x=x, z=z, l=l, u=u, is_eq=is_eq, active=active, slack=slack, y=y)
+
+
+def banded_lp(m, n, per_row, band, seed=5):
+    """Planted LP on the banded matrix: box 0<=x<=u, half equality rows, half active/inactive '<=' rows."""
+    from scipy import sparse
+    rp, ci, v = gen_banded(m, n, per_row, band, seed)
+    A = sparse.csr_matrix((v, ci, rp), shape=(m, n), copy=False)
+    p = planted_vectors(m, n, seed)
+    b = A @ p["x"]
+    AL = np.where(p["is_eq"], b, -np.inf)
+    AU = np.where(p["is_eq"] | p["active"], b, b + p["slack"])
+    c = A.T @ p["y"] + p["z"]
+    return dict(m=m, n=n, rowptr=rp, colind=ci, values=v, AL=AL, AU=AU, l=p["l"], u=p["u"], c=c, obj_star=float(c @ p["x"]))
+
+
+def banded_lp_shard(m, n, per_row, band, rank, world, dist, seed=5):
+    """This rank's shard of the SAME planted LP, built from its own rows only (hpr-lp-c_amd/shard.py): the rows of A^T
+    arrive through one all-to-all; no rank generates or holds the whole matrix."""
+    from scipy import sparse
+    _, row_off, m_loc = SH.partition(m, world, rank)
+    _, col_off, n_loc = SH.partition(n, world, rank)
+    rp, ci, v = gen_banded(m, n, per_row, band, seed, row0=row_off, rows=m_loc)
+    trp, tci, tv = SH.transpose_rows_distributed(m, n, row_off, rp, ci, v, rank, world, dist)
+    p = planted_vectors(m, n, seed)
+    A_loc = sparse.csr_matrix((v, ci, rp), shape=(m_loc, n), copy=False)
+    AT_loc = sparse.csr_matrix((tv, tci, trp), shape=(n_loc, m), copy=False)
+    b = A_loc @ p["x"]
+    rs, cs = slice(row_off, row_off + m_loc), slice(col_off, col_off + n_loc)
+    AL = np.where(p["is_eq"][rs], b, -np.inf)
+    AU = np.where(p["is_eq"][rs] | p["active"][rs], b, b + p["slack"][rs])
+    c = AT_loc @ p["y"] + p["z"][cs]
+    import torch
+    obj = torch.tensor([float(c @ p["x"][cs])], dtype=torch.float64)
+    dist.all_reduce(obj)
+    shard = SH.ShardArrays(H, m, n, rank, world, rp, ci, v, trp, tci, tv, AL, AU, p["l"][cs], p["u"][cs], c)
+    return shard, float(obj[0]), len(v)
 
 
 def bytes_per_iteration(m, n, nnz):
@@ -276,31 +307,44 @@ def main():
 
     m, n, per_row, band = WORKLOADS[args.workload]
     t0 = time.time()
-    lp = banded_lp(m, n, per_row, band)
-    if args.workload in PERMUTED:
-        lp = permute_lp(lp)
-    nnz = len(lp["values"])
-    if rank == 0:
-        log(f"[bench] generated {args.workload}: {m}x{n}, nnz={nnz} in {time.time() - t0:.1f}s")
-    model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
-    lp.pop("rowptr"); lp.pop("colind"); lp.pop("values")
     prm = H.Parameters(stop_tol=1e-4, use_presolve=False, device_number=local_rank)
-    t0 = time.time()
+    model = None
     if world > 1:
+        if args.workload in PERMUTED:
+            raise SystemExit("the permuted workloads are single-GPU (the locality ordering runs on the whole matrix)")
+        # every rank generates ITS rows only; the rows of A^T come through one all-to-all (no rank holds the whole LP)
+        shard, obj_star, nnz_loc = banded_lp_shard(m, n, per_row, band, rank, world, dist)
+        tn = torch.tensor([nnz_loc], dtype=torch.int64)
+        dist.all_reduce(tn)
+        nnz = int(tn[0])
+        if rank == 0:
+            import resource
+            log(f"[bench] rank 0 assembled its shard of {args.workload} ({m}x{n}, nnz={nnz} over {world} ranks; {nnz_loc} here) "
+                f"in {time.time() - t0:.1f}s, peak host RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.2f} GB")
+        t0 = time.time()
         uid = np.zeros(128, np.uint8)
         if rank == 0 and H.lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 128) != 0:
             raise RuntimeError(H.last_error())
         tu = torch.from_numpy(uid)
         dist.broadcast(tu, src=0)
-        s = H.Solver.create_dist(model, prm, rank, world, uid)
+        s = H.Solver.create_dist_from_shard(shard, prm, rank, world, uid)
         dinfo = s.dist_info()
+        del shard
     else:
+        lp = banded_lp(m, n, per_row, band)
+        if args.workload in PERMUTED:
+            lp = permute_lp(lp)
+        nnz = len(lp["values"])
+        log(f"[bench] generated {args.workload}: {m}x{n}, nnz={nnz} in {time.time() - t0:.1f}s")
+        model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        lp.pop("rowptr"); lp.pop("colind"); lp.pop("values")
+        t0 = time.time()
         s = H.Solver(model, prm)
         dinfo = None
-    obj_star = lp["obj_star"]
-    if world > 1 or args.no_solve:
-        model.free()
-        model = None
+        obj_star = lp["obj_star"]
+        if args.no_solve:
+            model.free()
+            model = None
     s.scale()
     lam, pw_it = s.power_iteration()
     s.init(-1.0, lam * 1.01)

@@ -358,6 +358,52 @@ extern "C" hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, cons
     return create_sharded(model, param, rank, size, unique_id, id_bytes, nullptr);
 }
 
+// The same from a shard the caller built itself (no rank ever holds the whole matrix: SURVEY.md 8d, config 5 "generated per
+// shard"); the shard stays the caller's.
+static hprlp_solver *create_from_shard(const hprlp_shard *sh, const HPRLP_parameters *param, int rank, int size, const void *unique_id,
+                                       int id_bytes, hprlp_local_group *group) {
+    hprlp_solver *h = nullptr;
+    try {
+        if (!sh || !sh->A_rowptr || !sh->AT_rowptr || (sh->m_loc > 0 && !(sh->AL && sh->AU)) || (sh->n_loc > 0 && !(sh->l && sh->u && sh->c)))
+            throw std::runtime_error("incomplete shard");
+        if (sh->A_rowptr[sh->m_loc] > 0 && !(sh->A_col && sh->A_val)) throw std::runtime_error("incomplete shard (A)");
+        if (sh->AT_rowptr[sh->n_loc] > 0 && !(sh->AT_col && sh->AT_val)) throw std::runtime_error("incomplete shard (A^T)");
+        HPRLP_parameters dflt;
+        const HPRLP_parameters *p = param ? param : &dflt;
+        h = new hprlp_solver();
+        h->s.verbose = false;
+        HIP_CHECK(hipSetDevice(p->device_number));
+        if (group) h->comm = make_local_comm(group->g, rank);
+        else if (size > 1 || (unique_id && id_bytes >= 128))
+            h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
+        h->s.setup_shard(sh->m, sh->n, sh->row_off, sh->m_loc, sh->col_off, sh->n_loc, sh->A_rowptr, sh->A_col, sh->A_val, sh->AT_rowptr,
+                         sh->AT_col, sh->AT_val, sh->AL, sh->AU, sh->l, sh->u, sh->c, sh->obj_constant, p, h->comm);
+        return h;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        if (h) {
+            Comm *c = h->comm;
+            delete h;
+            delete c;
+        }
+        return nullptr;
+    }
+}
+
+extern "C" hprlp_solver *hprlp_solver_create_dist_from_shard(const hprlp_shard *shard, const HPRLP_parameters *param, int rank, int size,
+                                                             const void *unique_id, int id_bytes) {
+    return create_from_shard(shard, param, rank, size, unique_id, id_bytes, nullptr);
+}
+
+extern "C" hprlp_solver *hprlp_solver_create_local_from_shard(const hprlp_shard *shard, const HPRLP_parameters *param, int rank, int size,
+                                                              hprlp_local_group *group) {
+    if (!group) {
+        set_last_error("null local group");
+        return nullptr;
+    }
+    return create_from_shard(shard, param, rank, size, nullptr, 0, group);
+}
+
 extern "C" hprlp_solver *hprlp_solver_create_local(const LP_info_cpu *model, const HPRLP_parameters *param, int rank,
                                                    int size, hprlp_local_group *group) {
     if (!group) {

@@ -60,6 +60,14 @@ class CLPInfo(C.Structure):
                 ("obj_constant", C.c_double)]
 
 
+class CShard(C.Structure):
+    """hprlp_shard (include/hprlp_amd.h): one rank's rows of A and of A^T with its vector slices."""
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("row_off", C.c_int), ("m_loc", C.c_int), ("col_off", C.c_int),
+                ("n_loc", C.c_int), ("A_rowptr", c_int_p), ("A_col", c_int_p), ("A_val", c_dbl_p),
+                ("AT_rowptr", c_int_p), ("AT_col", c_int_p), ("AT_val", c_dbl_p),
+                ("AL", c_dbl_p), ("AU", c_dbl_p), ("l", c_dbl_p), ("u", c_dbl_p), ("c", c_dbl_p), ("obj_constant", C.c_double)]
+
+
 class CTraceRow(C.Structure):
     _fields_ = [("iter", C.c_int), ("restart_flag", C.c_int)] + [
         (k, C.c_double)
@@ -349,6 +357,30 @@ class Solver:
         if not self.h:
             raise RuntimeError("hprlp_solver_create_dist failed: " + last_error())
         self._set_local_sizes(rank, size)
+        return self
+
+    @classmethod
+    def create_dist_from_shard(cls, shard, param, rank, size, unique_id=None, group=None):
+        """One rank of the row-partitioned solve from a shard assembled by the caller (shard.ShardArrays): no rank holds the
+        whole matrix.  group: a local_group() handle runs the ranks as threads of this process (tests) instead of RCCL."""
+        L = lib()
+        self = cls.__new__(cls)
+        self.model = shard            # has .m / .n; keeps the arrays alive until the solver is created
+        cp = (param or Parameters()).to_c()
+        if group is not None:
+            L.hprlp_solver_create_local_from_shard.restype = C.c_void_p
+            L.hprlp_solver_create_local_from_shard.argtypes = [C.POINTER(CShard), C.POINTER(CParameters), C.c_int, C.c_int, C.c_void_p]
+            self.h = L.hprlp_solver_create_local_from_shard(C.byref(shard.c_shard), C.byref(cp), rank, size, group)
+        else:
+            L.hprlp_solver_create_dist_from_shard.restype = C.c_void_p
+            L.hprlp_solver_create_dist_from_shard.argtypes = [C.POINTER(CShard), C.POINTER(CParameters), C.c_int, C.c_int,
+                                                              C.c_void_p, C.c_int]
+            uid = None if unique_id is None else unique_id.ctypes.data_as(C.c_void_p)
+            self.h = L.hprlp_solver_create_dist_from_shard(C.byref(shard.c_shard), C.byref(cp), rank, size, uid,
+                                                           0 if unique_id is None else 128)
+        if not self.h:
+            raise RuntimeError("hprlp_solver_create_dist_from_shard failed: " + last_error())
+        self.row_off, self.m_loc, self.col_off, self.n_loc = shard.row_off, shard.m_loc, shard.col_off, shard.n_loc
         return self
 
     def _set_local_sizes(self, rank, size):

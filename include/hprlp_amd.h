@@ -112,6 +112,12 @@ int hprlp_dist_unique_id(void *out, int bytes);
  * get_vector/run then return this rank's slices; scalars/residuals are global. */
 hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
                                        const void *unique_id, int id_bytes);
+/* The same from a shard the caller assembled itself -- rows [row_off, row_off + m_loc) of A and rows [col_off, col_off + n_loc)
+ * of A^T in the block partition of hprlp_partition(), global column indices, arrays owned by the caller (copied to the
+ * device during the call).  No rank has to hold the whole matrix (config 5 is generated per shard);
+ * hpr-lp-c_amd/shard.py builds the A^T rows of every rank from the ranks' A rows with one all-to-all. */
+hprlp_solver *hprlp_solver_create_dist_from_shard(const hprlp_shard *shard, const HPRLP_parameters *param, int rank, int size,
+                                                  const void *unique_id, int id_bytes);
 /* How the fresh slices travel: if the shards' column indices name at most half of the remote entries
  * (banded / block-structured LPs) each rank sends exactly the entries its peers read (pack kernel, one grouped
  * RCCL send/recv, scatter kernel); otherwise one in-place all-gather.  HPRLP_DIST_EXCHANGE=sparse|allgather
@@ -129,6 +135,8 @@ hprlp_local_group *hprlp_local_group_create(int size);
 void hprlp_local_group_destroy(hprlp_local_group *g);
 hprlp_solver *hprlp_solver_create_local(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
                                         hprlp_local_group *group);
+hprlp_solver *hprlp_solver_create_local_from_shard(const hprlp_shard *shard, const HPRLP_parameters *param, int rank, int size,
+                                                   hprlp_local_group *group);
 
 /* ---- presolve / postsolve as separate host-side steps (what solve() does around the iteration when
  * use_presolve is set; replaces the reference's forked PSLP worker, src/pslp_integration.cpp:628-787).

@@ -23,6 +23,7 @@ def _load(name, rel):
 
 hprlp = _load("hprlp_amd", os.path.join("hpr-lp-c_amd", "hprlp.py"))
 lpgen = _load("hprlp_lpgen", os.path.join("hpr-lp-c_amd", "lpgen.py"))
+shardlib = _load("hprlp_shard", os.path.join("hpr-lp-c_amd", "shard.py"))
 
 
 def pytest_configure(config):

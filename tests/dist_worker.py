@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from conftest import hprlp, lpgen  # noqa: E402
+from conftest import hprlp, lpgen, shardlib  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
@@ -67,6 +67,13 @@ def main():
     ATci = arr(sh.AT_col, nzT, np.int32); ATv = arr(sh.AT_val, nzT, np.float64)
     k0, k1 = ref.ATrp[sh.col_off], ref.ATrp[sh.col_off + sh.n_loc]
     assert np.array_equal(ATci, ref.ATci[k0:k1]) and np.array_equal(ATv, ref.ATv[k0:k1])
+    # the from-shard path (bench.py --gpus N): a rank that only ever sees ITS rows of A gets its rows of A^T through one
+    # all-to-all (hpr-lp-c_amd/shard.py) -- identical, entry for entry, to the slice cut out of the full transpose
+    my_rp = (ref.Arp[sh.row_off:sh.row_off + sh.m_loc + 1] - ref.Arp[sh.row_off]).astype(np.int32)
+    t_rp, t_ci, t_v = shardlib.transpose_rows_distributed(m, n, sh.row_off, my_rp, Aci, Av, rank, world, dist)
+    assert np.array_equal(t_rp, ATrp) and np.array_equal(t_ci, ATci) and np.array_equal(t_v, ATv)
+    assert shardlib.partition(m, world, rank) == (chunk_m, sh.row_off, sh.m_loc)
+    assert shardlib.partition(n, world, rank) == (chunk_n, sh.col_off, sh.n_loc)
     AL = arr(sh.AL, sh.m_loc, float); AU = arr(sh.AU, sh.m_loc, float)
     l = arr(sh.l, sh.n_loc, float); u = arr(sh.u, sh.n_loc, float); c = arr(sh.c, sh.n_loc, float)
     assert np.array_equal(c, ref.c[sh.col_off:sh.col_off + sh.n_loc])

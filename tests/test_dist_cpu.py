@@ -38,6 +38,26 @@ def test_sharded_iteration_equals_single_process(world):
         assert f"rank {rank} ok" in out
 
 
+def test_bench_shard_generation():
+    """bench.py --gpus N: per-rank generation (no rank holds the whole LP) gives the shards of the LP generated whole."""
+    world = 2
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker_shard.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, f"rank {rank} failed:\n{out.decode()[-3000:]}"
+        assert f"rank {rank} ok" in out.decode()
+
+
 def test_partition_edge_cases():
     import ctypes as C
     from conftest import hprlp

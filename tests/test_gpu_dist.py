@@ -238,3 +238,53 @@ def test_time_limit_is_a_collective_decision(gpu):
     assert all(e is None for e in err), err
     assert {(o.status, o.iter) for o in out} == {("TIME_LIMIT", 0)}
     model.free()
+
+
+def test_solver_from_caller_built_shards(gpu):
+    """hprlp_solver_create_*_from_shard: the ranks get shards assembled outside the library (bench.py --gpus N builds them from
+    per-rank rows, hpr-lp-c_amd/shard.py); same iterates and optimum as the single-GPU solver."""
+    import threading
+
+    from scipy import sparse
+
+    from conftest import shardlib
+    lp = lpgen.planted_lp(401, 653, 4000, 93)
+    m, n = lp["m"], lp["n"]
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+    ref = single(model, prm, 37)
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    AT = A.T.tocsr(); AT.sort_indices()
+    world = 3
+    group = hprlp.Solver.local_group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            _, ro, ml = shardlib.partition(m, world, rank)
+            _, co, nl = shardlib.partition(n, world, rank)
+            Ar, Tr = A[ro:ro + ml], AT[co:co + nl]
+            sh = shardlib.ShardArrays(hprlp, m, n, rank, world, Ar.indptr, Ar.indices, Ar.data, Tr.indptr, Tr.indices, Tr.data,
+                                      lp["AL"][ro:ro + ml], lp["AU"][ro:ro + ml], lp["l"][co:co + nl], lp["u"][co:co + nl], lp["c"][co:co + nl])
+            s = hprlp.Solver.create_dist_from_shard(sh, prm, rank, world, group=group)
+            s.scale()
+            lam, it = s.power_iteration()
+            s.init(-1.0, lam * 1.01)
+            s.iterate(37, True)
+            res = s.residuals(38, True)
+            state = {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}
+            r = s.run()
+            out[rank] = dict(lam=lam, it=it, res=res, state=state, run=r, info=s.dist_info(), off=(s.row_off, s.m_loc, s.col_off, s.n_loc))
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            err[rank] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    hprlp.Solver.free_local_group(group)
+    assert all(e is None for e in err), err
+    check_against_single(ref, out, m, n, lp["obj_star"])
+    model.free()
