@@ -408,7 +408,8 @@ def main():
                            "rank0_entries_received_per_iteration": (dinfo["m_received"] if dinfo["m_sparse"] else m - m // P)
                                                                    + (dinfo["n_received"] if dinfo["n_sparse"] else n - n // P)},
                        "bytes_per_iteration_algorithmic": bytes_per_iteration(m, n, nnz)},
-            "roofline": {"bound": "hbm", "kernel": (("k_tiled_fused" if tiled & 2 else "k_spmv_fused") + "<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern)")
+            "roofline": {"bound": "hbm", "kernel": (("k_far_products + k_tiled_fused" if tiled & 2 else "k_spmv_fused") + "<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern"
+                                                     + ("; avg_launch_ms = remainder pre-pass + fused kernel, the two launches of the half-step)" if tiled & 2 else ")"))
                          if P == 1 else "x-half window of one rank: local-column SpMV beside the exchange of y, then the remote-column fused kernel "
                                         "(k_spmv_fused<WithBase<XEpi<false>>>); avg_launch_ms is that window, exchange wait included",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -30,6 +30,24 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 for k, d in res.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["bytes_per_launch"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+# the remainder pre-pass (k_far_products) belongs to every tiled launch: a half-step = pre-pass + fused kernel
+far = {}
+for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    vals = []
+    for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == ctr and "k_far_products" in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+    if vals:
+        far[ctr] = sum(vals) / len(vals)
+if "FETCH_SIZE" in far and "WRITE_SIZE" in far:
+    far["bytes_per_launch"] = (2 * far["FETCH_SIZE"] + far["WRITE_SIZE"]) * 1024
+    res["k_far_products"] = far
+def half(tag):
+    k = [v for n, v in res.items() if "k_tiled_fused" in n and tag in n and "bytes_per_launch" in v]
+    return (k[0]["bytes_per_launch"] + far.get("bytes_per_launch", 0.0)) if k else None
+res["_half_steps"] = {"xhalf_hbm_bytes_per_launch": half("XEpi<false>"), "yhalf_hbm_bytes_per_launch": half("YEpi<false>"),
+                      "note": "fused kernel + remainder pre-pass; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (profiles/r01_pmc_summary.md: calibration)"}
 json.dump(res, open(f"{out}/pmc_traffic_per_kernel.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
