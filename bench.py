@@ -43,6 +43,7 @@ WORKLOADS = {
     "c5": (10_000_000, 10_000_000, 20, 100_000),
     "c5_eighth": (1_250_000, 10_000_000, 20, 100_000),
     "c5_quarter": (2_500_000, 10_000_000, 20, 100_000),
+    "c5_half": (5_000_000, 10_000_000, 20, 100_000),
     "c5_shard_like": (1_250_000, 1_250_000, 20, 100_000),  # rows and band of one of 8 shards of c5 (kernel-shape experiments)
     "c5_small": (1_000_000, 1_000_000, 20, 10_000),
     "c5_tiny": (100_000, 100_000, 20, 1_000),
