@@ -603,6 +603,7 @@ extern "C" int hprlp_solver_set_vector(hprlp_solver *h, const char *name, const 
     VecRef v = find_vector(h->s, name ? name : "");
     if (v.n < 0) throw std::runtime_error(std::string("unknown vector name: ") + (name ? name : "(null)"));
     if (len != v.n) throw std::runtime_error("length mismatch");
+    h->s.invalidate_far();
     HIP_CHECK(hipStreamSynchronize(h->s.stream));
     if (v.n > 0) {
         if (const std::vector<int> *perm = perm_of(h->s, v)) {
@@ -687,6 +688,7 @@ extern "C" int hprlp_solver_time_iterations(hprlp_solver *h, int warmup, int ste
         HIP_CHECK(hipEventSynchronize(e1));
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     } else if (mode == 2) {
+        s.invalidate_far();
         // the bare SpMVs of the path (A^T y into scratch, A x_hat into scratch): no half-step update, no state change
         std::vector<hipEvent_t> ev(static_cast<size_t>(steps) * 3);
         for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));

@@ -445,8 +445,10 @@ void launch_half_pair(BatchWS &w, bool check) {
         // no reduction partials in the normal variant: one pass over the rows, as many workgroups as rows need
         const Geo g = make_geo(w.Bp);
         const int rpb = wide ? 4 * kRowsPerWave : g.rows_per_block;
-        const dim3 fx((AT.rows + rpb - 1) / rpb, w.kchunks);
-        const dim3 fy((A.rows + rpb - 1) / rpb, w.kchunks);
+        static const int grid_cap = std::getenv("HPRLP_BATCH_GRID") ? std::atoi(std::getenv("HPRLP_BATCH_GRID")) : 0;  // experiment knob
+        auto cap = [&](int g) { return grid_cap > 0 ? std::min(g, grid_cap) : g; };
+        const dim3 fx(cap((AT.rows + rpb - 1) / rpb), w.kchunks);
+        const dim3 fy(cap((A.rows + rpb - 1) / rpb), w.kchunks);
         if (wide) {
             hipLaunchKernelGGL((kb_half64<true, false>), fx, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
             hipLaunchKernelGGL((kb_half64<false, false>), fy, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);

@@ -74,6 +74,18 @@ struct Ctrl {
     int pad0, pad1;
 };
 
+// Hand-off of the remainder products between the two kernels of an iteration (tiled.h, propagation blocking): the
+// half-step that PRODUCES a gathered vector (x_hat or y) holds a super-block's fresh values in LDS at its epilogue and
+// writes the products a * v[col] of the OTHER matrix' remainder entries whose source group is that super-block straight
+// into the other matrix' P -- the consumer then skips its pre-pass (k_far_products).  gptr == nullptr: no hand-off.
+struct FarPush {
+    const int *gptr = nullptr;       // n_groups + 1 of the consumer matrix (group g = rows of the producer's super-block g)
+    const double *val = nullptr;
+    const int *pos = nullptr;
+    const uint16_t *lcol = nullptr;
+    double *P = nullptr;
+};
+
 struct XHalfArgs {
     const double *y_full;  // gather source (all rows of y)
     double *x, *x_hat;     // local slices (x_hat points into the gathered x_hat buffer)
@@ -82,6 +94,8 @@ struct XHalfArgs {
     Ctrl *ctrl;
     double *partials;  // check variant: 3 x stride
     int stride;
+    FarPush push;            // x_hat's products into the remainder buffer of A (consumed by the y-half)
+    bool far_ready = false;  // A^T's remainder buffer already holds the products of y_full (pushed by the y-half before)
 };
 
 struct YHalfArgs {
@@ -92,6 +106,8 @@ struct YHalfArgs {
     Ctrl *ctrl;
     double *partials;  // check variant: 2 x stride
     int stride;
+    FarPush push;            // y's products into the remainder buffer of A^T (consumed by the next x-half)
+    bool far_ready = false;  // A's remainder buffer already holds the products of xhat_full
 };
 
 struct FinalizeItem {
@@ -104,8 +120,11 @@ struct FinalizeArgs {
     int n;
 };
 
-void launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s);
-void launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s);
+// return true if the launch filled the `push` buffer (the fused tiled kernel ran and a hand-off was requested)
+bool launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s);
+bool launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s);
+// the hand-off lists of a tiled matrix as a consumer (empty if it has no remainder lists)
+FarPush far_push_of(const CsrDev &consumer);
 // normal half-steps over the remote-column part of a split matrix; base = row sums of the local-column part
 void launch_x_half_base(const CsrDev &AT_remote, const XHalfArgs &a, const double *base, hipStream_t s);
 void launch_y_half_base(const CsrDev &A_remote, const YHalfArgs &a, const double *base, hipStream_t s);

@@ -460,7 +460,7 @@ __device__ __forceinline__ void tiled_remainder(const TiledDev &t, int smid, int
     }
 }
 
-template <class Epi, bool REP>
+template <class Epi, bool REP, bool PUSH = false>
 __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi epi) {  // 4 waves per SIMD = two workgroups per CU
     static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
     constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols;
@@ -491,7 +491,32 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         for (int i = tid; i < nr; i += NT) {
             const double sv[1] = {acc[i]};
             typename Epi::Row rw = epi.load_row(r0 + i);
-            epi.apply(r0 + i, rw, sv, racc);
+            if constexpr (PUSH) acc[i] = epi.apply(r0 + i, rw, sv, racc);  // the published value replaces the row sum
+            else epi.apply(r0 + i, rw, sv, racc);
+        }
+        if constexpr (PUSH) {
+            // Hand-off (kernels.h: FarPush): this super-block's fresh values are the source group `sb` of the OTHER matrix'
+            // remainder; write its products straight into that matrix' P -- what k_far_products would do in a launch of
+            // its own after re-reading the vector from memory.  Same products bit for bit, same slots.
+            static_assert(kFarGroup == kTileRows, "a source group of the remainder = the rows of one super-block");
+            lds_barrier();
+            const FarPush &f = epi.push;
+            const int b = f.gptr[sb], e = f.gptr[sb + 1];
+            int k = b + tid;
+            for (; k + 3 * NT < e; k += 4 * NT) {
+                double a4[4];
+                int p4[4];
+                uint16_t c4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a4[u] = __builtin_nontemporal_load(f.val + k + u * NT);
+                    p4[u] = __builtin_nontemporal_load(f.pos + k + u * NT);
+                    c4[u] = __builtin_nontemporal_load(f.lcol + k + u * NT);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) f.P[p4[u]] = a4[u] * acc[c4[u]];
+            }
+            for (; k < e; k += NT) f.P[f.pos[k]] = f.val[k] * acc[f.lcol[k]];
         }
     }
     if constexpr (NACC > 0) {
@@ -634,6 +659,8 @@ struct XEpi {
     int stride;
     // filled by begin()
     double sigma, f1, f2;
+    FarPush push;  // hand-off of x_hat's remainder products to the y-half (kernels.h)
+    static constexpr bool kPublishes = true;
     struct Row {
         double xi, ci, li, ui, lx;
     };
@@ -645,7 +672,8 @@ struct XEpi {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->ky = k;
     }
     __device__ __forceinline__ Row load_row(int r) const { return Row{x[r], c[r], l[r], u[r], last_x[r]}; }
-    __device__ __forceinline__ void apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 3 : 1]) const {
+    // returns the value the half-step publishes for the other half's gather (x_hat)
+    __device__ __forceinline__ double apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 3 : 1]) const {
         const double gc = s[0] - w.ci;
         const double zt = w.xi + sigma * gc;
         const double xb = fmin(w.ui, fmax(w.li, zt));
@@ -663,6 +691,7 @@ struct XEpi {
             acc[1] += xb * zb;
             acc[2] += dx * dx;
         }
+        return xh;
     }
 };
 
@@ -680,6 +709,8 @@ struct YEpi {
     double *partials;
     int stride;
     double fact1, fact2, hf1, hf2;
+    FarPush push;  // hand-off of y's remainder products to the next x-half (kernels.h)
+    static constexpr bool kPublishes = true;
     struct Row {
         double yi, lo, hi, ly;
     };
@@ -692,7 +723,8 @@ struct YEpi {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->kx = k + 1;
     }
     __device__ __forceinline__ Row load_row(int r) const { return Row{y[r], AL[r], AU[r], last_y[r]}; }
-    __device__ __forceinline__ void apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 2 : 1]) const {
+    // returns the value the half-step publishes for the other half's gather (y)
+    __device__ __forceinline__ double apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 2 : 1]) const {
         const double v = s[0] - fact1 * w.yi;
         const double d = fmax(w.lo - v, fmin(w.hi - v, 0.0));
         const double yb = fact2 * d;
@@ -708,6 +740,7 @@ struct YEpi {
             acc[0] += yo * yb;
             acc[1] += dy * dy;
         }
+        return yn;
     }
 };
 
@@ -830,48 +863,73 @@ __global__ void __launch_bounds__(kThreads) k_long_finish(CsrDev A, Epi epi, int
     }
 }
 
+template <class Epi, class = void>
+struct Publishes : std::false_type {};
 template <class Epi>
-static void launch_fused(const CsrDev &M, const Epi &e, hipStream_t s) {
-    if (M.nblk <= 0) return;
+struct Publishes<Epi, std::void_t<decltype(Epi::kPublishes)>> : std::true_type {};
+
+// far_ready: M's remainder buffer already holds the products of e.gv[0] (pushed by the producing half-step): no pre-pass.
+// Returns true if the launch pushed (fused tiled kernel with a hand-off requested in e.push).
+template <class Epi>
+static bool launch_fused(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready = false) {
+    if (M.nblk <= 0) return false;
     if constexpr (Epi::NV == 1) {
         if (M.tiled.valid) {
-            if (M.tiled.n_groups > 0)
+            if (M.tiled.n_groups > 0 && !far_ready)
                 hipLaunchKernelGGL(k_far_products, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
             if (M.tiled.n_pieces > 0) {
                 if (M.tiled.stamps) hipLaunchKernelGGL((k_tiled_part<false, true>), dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
                 else if (M.tiled.repeats) hipLaunchKernelGGL(k_tiled_part<true>, dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
                 else hipLaunchKernelGGL(k_tiled_part<false>, dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
                 hipLaunchKernelGGL(k_tiled_finish<Epi>, dim3(M.tiled_finish_grid()), dim3(kThreads), 0, s, M, e);
-                return;
+                return false;
+            }
+            if constexpr (Publishes<Epi>::value) {
+                if (e.push.gptr) {
+                    if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+                    else hipLaunchKernelGGL((k_tiled_fused<Epi, false, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+                    return true;
+                }
             }
             if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
             else hipLaunchKernelGGL((k_tiled_fused<Epi, false>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
-            return;
+            return false;
         }
     }
     hipLaunchKernelGGL(k_spmv_fused<Epi>, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, e);
     if (M.nlong > 0)
         hipLaunchKernelGGL(k_long_finish<Epi>, dim3(M.finish_grid()), dim3(kThreads), 0, s, M, e, M.csr_grid());
+    return false;
 }
 
-void launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s) {
-    if (check) {
-        XEpi<true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, a.x_bar, a.z_bar, a.x_temp, a.ctrl, a.partials, a.stride, 0, 0, 0};
-        launch_fused(AT, e, s);
-    } else {
-        XEpi<false> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0};
-        launch_fused(AT, e, s);
+FarPush far_push_of(const CsrDev &consumer) {
+    FarPush f;
+    if (consumer.tiled.valid && consumer.tiled.n_groups > 0) {
+        f.gptr = consumer.tiled.f_gptr;
+        f.val = consumer.tiled.f_val;
+        f.pos = consumer.tiled.f_pos;
+        f.lcol = consumer.tiled.f_lcol;
+        f.P = consumer.tiled.P;
     }
+    return f;
 }
 
-void launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s) {
+bool launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s) {
     if (check) {
-        YEpi<true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, a.y_bar, a.y_obj, a.y_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, 0};
-        launch_fused(A, e, s);
-    } else {
-        YEpi<false> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0};
-        launch_fused(A, e, s);
+        XEpi<true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, a.x_bar, a.z_bar, a.x_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, a.push};
+        return launch_fused(AT, e, s, a.far_ready);
     }
+    XEpi<false> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push};
+    return launch_fused(AT, e, s, a.far_ready);
+}
+
+bool launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s) {
+    if (check) {
+        YEpi<true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, a.y_bar, a.y_obj, a.y_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, 0, a.push};
+        return launch_fused(A, e, s, a.far_ready);
+    }
+    YEpi<false> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, a.push};
+    return launch_fused(A, e, s, a.far_ready);
 }
 
 // Second kernel of a half-step whose matrix was split by columns (multi-GPU overlap): `base[r]` is the row sum over
@@ -885,19 +943,19 @@ struct WithBase : Epi {
         double b;
     };
     __device__ __forceinline__ Row load_row(int r) const { return Row{Epi::load_row(r), base[r]}; }
-    __device__ __forceinline__ void apply(int r, const Row &w, const double (&s)[1], double (&acc)[Epi::NACC > 0 ? Epi::NACC : 1]) const {
+    __device__ __forceinline__ auto apply(int r, const Row &w, const double (&s)[1], double (&acc)[Epi::NACC > 0 ? Epi::NACC : 1]) const {
         const double t[1] = {w.b + s[0]};
-        Epi::apply(r, w.w, t, acc);
+        return Epi::apply(r, w.w, t, acc);
     }
 };
 
 void launch_x_half_base(const CsrDev &AT_remote, const XHalfArgs &a, const double *base, hipStream_t s) {
-    WithBase<XEpi<false>> e{{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0}, base};
+    WithBase<XEpi<false>> e{{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, FarPush{}}, base};
     launch_fused(AT_remote, e, s);
 }
 
 void launch_y_half_base(const CsrDev &A_remote, const YHalfArgs &a, const double *base, hipStream_t s) {
-    WithBase<YEpi<false>> e{{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0}, base};
+    WithBase<YEpi<false>> e{{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, FarPush{}}, base};
     launch_fused(A_remote, e, s);
 }
 

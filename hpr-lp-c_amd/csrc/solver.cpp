@@ -430,6 +430,7 @@ bool Solver::try_reorder(const LP_info_cpu *model) {
 }
 
 void Solver::finish_tiling() {
+    if (A.tiling.valid() || AT.tiling.valid()) invalidate_far();
     if (A.tiling.valid()) A.finish_tiling(stream);
     if (AT.tiling.valid()) AT.finish_tiling(stream);
 }
@@ -642,6 +643,7 @@ static double bnorm_sq(Solver *s) {
 // that the column-side scaling of each stored matrix can index the full vector.
 // ------------------------------------------------------------------------------------------------
 void Solver::scale() {
+    invalidate_far();
     const auto t0 = time_now();
     overlap_ready = false;  // the split copies of the shards carry matrix values
     ovA.reset();
@@ -725,6 +727,7 @@ void Solver::scale() {
 // ------------------------------------------------------------------------------------------------
 double Solver::power_iteration(int max_iter, double tol, int *iters) {
     finish_tiling();
+    invalidate_far();
     const auto t0 = time_now();
     double *q = gsm.p + row_off, *ATq = gsn.p + col_off, *z = sm1.p;
     {
@@ -795,6 +798,7 @@ void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
 
 void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
     finish_tiling();
+    invalidate_far();
     if (overlap_enabled && !overlap_ready) prepare_overlap();  // set-up work, not part of the first iteration
     const double s0 = (norm_b > 1e-8 && norm_c > 1e-8) ? norm_b / norm_c : 1.0;
     set_sigma_lambda(s0, lambda_max, true);
@@ -839,19 +843,33 @@ void Solver::prepare_overlap() {
     overlap_ready = true;
 }
 
+// The hand-off needs the PRODUCER to run the fused tiled kernel on one GPU (a super-block's rows = one source group of
+// the consumer's remainder) and the consumer to have remainder lists; HPRLP_NO_FAR_PUSH=1 keeps the pre-pass (A/B runs).
+FarPush Solver::push_into(const DeviceMatrix &consumer, const DeviceMatrix &producer) const {
+    static const bool off = std::getenv("HPRLP_NO_FAR_PUSH") && std::getenv("HPRLP_NO_FAR_PUSH")[0] == '1';
+    const TiledDev &pt = producer.view.tiled;
+    if (off || comm || !pt.valid || pt.n_pieces > 0) return FarPush{};
+    return far_push_of(consumer.view);
+}
+
 void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev) {
     XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
-    YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
+    YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};  // (push / far_ready set below)
     if (ev) HIP_CHECK(hipEventRecord(ev[0], stream));
     if (!overlap_enabled) {
-        launch_x_half(AT.view, xa, false, stream);
+        xa.push = push_into(A, AT);
+        xa.far_ready = far_AT_ready;
+        far_A_ready = launch_x_half(AT.view, xa, false, stream);
         if (ev) HIP_CHECK(hipEventRecord(ev[1], stream));
         gather(gxh.p, false);
-        launch_y_half(A.view, ya, false, stream);
+        ya.push = push_into(AT, A);
+        ya.far_ready = far_A_ready;
+        far_AT_ready = launch_y_half(A.view, ya, false, stream);
         if (ev) HIP_CHECK(hipEventRecord(ev[2], stream));
         gather(gy.p, true);
         return;
     }
+    invalidate_far();
     if (!overlap_ready) prepare_overlap();
     // Exchange on comm_stream behind ev_ready, beside the local-column SpMV on the solver stream.  RCCL only enqueues,
     // so the exchange goes first and its workgroups are placed before the SpMV's grid fills the chip; the in-process
@@ -894,10 +912,14 @@ void Solver::step(bool check) {
         return;
     }
     XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, x_bar, z_bar.p, x_temp, ctrl.p, part_x.p, stride_x};
-    launch_x_half(AT.view, xa, true, stream);
+    xa.push = push_into(A, AT);
+    xa.far_ready = far_AT_ready;
+    far_A_ready = launch_x_half(AT.view, xa, true, stream);
     gather(gxh.p, false);
     YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, y_bar, y_obj.p, y_temp.p, ctrl.p, part_y.p, stride_y};
-    launch_y_half(A.view, ya, true, stream);
+    ya.push = push_into(AT, A);
+    ya.far_ready = far_A_ready;
+    far_AT_ready = launch_y_half(A.view, ya, true, stream);
     gather(gy.p, true);
     FinalizeArgs f{};
     const int gx = AT.view.grid(), gyy = A.view.grid();
@@ -915,9 +937,15 @@ hipGraphExec_t Solver::graph_for(int len) {
     if (it != graphs.end()) return it->second;
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
+    // a replayed graph cannot look at the hand-off flags: it always starts with the pre-pass of A^T (as if nothing had been
+    // handed over) and ends with both buffers handed over, whatever ran before it
+    far_AT_ready = false;
     HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < len; ++i) launch_normal_pair();
     HIP_CHECK(hipStreamEndCapture(stream, &g));
+    graph_end_A = far_A_ready;
+    graph_end_AT = far_AT_ready;
+    invalidate_far();  // nothing has run yet
     HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     HIP_CHECK(hipGraphDestroy(g));
     graphs[len] = ge;
@@ -941,6 +969,8 @@ void Solver::run_normal(int count) {
     while (count > 0) {
         const int len = std::min(count, kMaxGraphIters);
         HIP_CHECK(hipGraphLaunch(graph_for(len), stream));
+        far_A_ready = graph_end_A;
+        far_AT_ready = graph_end_AT;
         count -= len;
     }
 }
@@ -966,6 +996,7 @@ static double weighted_norm_from(Solver *s, double dot_adx_dy, double dy2, doubl
 }
 
 void Solver::compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs) {
+    invalidate_far();  // the residual SpMVs refill the remainder buffers for x_bar / y_bar
     finish_tiling();
     const int gx = AT.view.grid(), gyy = A.view.grid();
     const int rstride = std::max(stride_x, stride_y);
@@ -999,6 +1030,7 @@ void Solver::compute_residuals(int iter, bool compute_gap, Residuals *r, Restart
 }
 
 double Solver::weighted_norm_after_restart() {
+    invalidate_far();
     gather(gxt.p, false);
     launch_gap(A.view, gxt.p, y_temp.p, part_r.p, stream);
     FinalizeArgs f{};
@@ -1062,6 +1094,7 @@ void Solver::update_sigma_and_restart(RestartState *rs, const Residuals &r) {
         new_sigma = kappa * sigma_cand;
     }
     // do_restart (main_iterate.cu:312-322) + Halpern reset (:54-66)
+    invalidate_far();  // y changes under the remainder buffer of A^T
     launch_restart_copy(n_loc, m_loc, x_bar, x.p, last_x.p, y_bar, y, last_y.p, ctrl.p, stream);
     gather(gy.p, true);
     set_sigma_lambda(new_sigma, lambda_max, true);

@@ -88,7 +88,14 @@ struct Solver {
     // (get / set_vector, collect_solution) speaks the caller's numbering.
     std::vector<int> perm_r, perm_c;
     double reorder_time = 0.0, reorder_before = 0.0, reorder_after = 0.0;
-    bool try_reorder(const LP_info_cpu *model);  // called by setup() for a large matrix that failed the tiling test
+    bool try_reorder(const LP_info_cpu *model);
+    // Hand-off of the remainder products between the two kernels of an iteration (kernels.h: FarPush).  far_A_ready: A's
+    // remainder buffer holds the products of the current x_hat (written by the x-half's epilogue); far_AT_ready likewise
+    // for y.  Every other launch on a tiled matrix refills its buffer for another vector: invalidate_far().
+    bool far_A_ready = false, far_AT_ready = false;
+    bool graph_end_A = false, graph_end_AT = false;  // what a replayed iteration graph leaves behind
+    void invalidate_far() { far_A_ready = far_AT_ready = false; }
+    FarPush push_into(const DeviceMatrix &consumer, const DeviceMatrix &producer) const;  // called by setup() for a large matrix that failed the tiling test
     HaloPlan halo_m, halo_n;  // exchange of length-m / length-n gathered vectors (multi-GPU only)
     DBuf<double> AL, AU, l, u, c, row_norm, col_norm;
     // local work vectors

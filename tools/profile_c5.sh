@@ -43,11 +43,19 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 if "FETCH_SIZE" in far and "WRITE_SIZE" in far:
     far["bytes_per_launch"] = (2 * far["FETCH_SIZE"] + far["WRITE_SIZE"]) * 1024
     res["k_far_products"] = far
+# with the producer-side hand-off (kernels.h: FarPush) the normal half-steps run WITHOUT a pre-pass of their own: the few
+# k_far_products launches left belong to residual / power-iteration SpMVs.  Count launches to tell the two builds apart.
+calls = collections.Counter()
+for f in glob.glob(f"{out}/fetch/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            calls["far" if "k_far_products" in r["Kernel_Name"] else ("half" if ("XEpi<false>" in r["Kernel_Name"] or "YEpi<false>" in r["Kernel_Name"]) else "other")] += 1
+handoff = calls["half"] > 0 and calls["far"] < calls["half"] + calls["other"] * 0 + 0 and calls["far"] - calls["other"] < 0.5 * calls["half"]
 def half(tag):
     k = [v for n, v in res.items() if "k_tiled_fused" in n and tag in n and "bytes_per_launch" in v]
-    return (k[0]["bytes_per_launch"] + far.get("bytes_per_launch", 0.0)) if k else None
+    return (k[0]["bytes_per_launch"] + (0.0 if handoff else far.get("bytes_per_launch", 0.0))) if k else None
 res["_half_steps"] = {"xhalf_hbm_bytes_per_launch": half("XEpi<false>"), "yhalf_hbm_bytes_per_launch": half("YEpi<false>"),
-                      "note": "fused kernel + remainder pre-pass; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (profiles/r01_pmc_summary.md: calibration)"}
+                      "handoff": handoff, "launches": dict(calls), "note": "fused kernel (+ remainder pre-pass unless handed over by the producing half-step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (profiles/r01_pmc_summary.md: calibration)"}
 json.dump(res, open(f"{out}/pmc_traffic_per_kernel.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
