@@ -110,7 +110,7 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
 
 // Row blocks, kernel views and the background job for the tiled copy, for a matrix whose CSR arrays are already in
 // rowptr / col / val on the device (rp / ci: the same index arrays on the host).
-void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep) {
+void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep, double min_dense_override) {
     PhaseTimer pt;
     view.longrows = nullptr;  // (describe() may run again on a permuted copy of the matrix: start from a clean view)
     view.nlong = 0;
@@ -160,13 +160,15 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         // 0.38 ms stream, 153 super-blocks 0.21 ms both -> one super-block per CU is the break-even
         // (round 2: matrices with fewer super-blocks than CUs run the split form -- several workgroups per super-block)
         const int min_rows = mr ? std::atoi(mr) : 32 * kTileRows;
-        const double min_dense = md ? std::atof(md) : 0.5;
+        const double min_dense = min_dense_override >= 0.0 ? min_dense_override : (md ? std::atof(md) : 0.5);
+        declined_sparse = false;
         const char *ht = std::getenv("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
         if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
             // built on the device from the device CSR arrays (tiled_build.hip); HPRLP_TILING_CHECK=1 also runs the
             // host builder and compares every array
             const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr);
+            declined_sparse = !ok;  // rows >= min_rows here: what was missing is dense tiles
             if (pt.on)
                 std::cerr << "[timing]   tiled copy (device build): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, "
                           << tiled.n_steps << " steps, " << tiled.dense_entries << " entries in tiles + " << tiled.padding
@@ -295,6 +297,14 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             if (try_reorder(model)) {  // A now holds P A Q: transpose that
                 device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
                 pt.tick("locality ordering + device transpose of the permuted matrix");
+            } else if (pb_fallback_wanted(A)) {
+                // no column locality to be had (or the ordering is disabled): every random 8-byte gather of the stream kernel
+                // would cost a 128-byte line from the Infinity Cache / HBM.  Accept the tiled form with NO dense-tile
+                // requirement: whatever is not in dense tiles -- here almost everything -- goes through the propagation-
+                // blocking remainder (pre-pass in source order, streamed products in destination order): about 30 bytes per
+                // nonzero, all sequential.  Unstructured 2e8-nnz matrix: 3.85 -> 1.87 ms per half-step.
+                A.describe(m, n, As->rowPtr, nullptr, nullptr, 0.0);
+                pt.tick("tiled copy of A without a dense-tile requirement (propagation blocking for all entries)");
             }
             trp.resize(static_cast<size_t>(n) + 1);
             AT.rowptr.download(trp.data(), trp.size());
@@ -307,6 +317,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             }
             pt.tick("download A^T indices");
             AT.describe(n, m, trp.data(), need_tci ? tci.data() : nullptr, ht);
+            if (pb_fallback_wanted(AT)) AT.describe(n, m, trp.data(), nullptr, nullptr, 0.0);
         } else {
             std::vector<double> tv;
             csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
@@ -368,6 +379,16 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     pt.tick("vectors, work space, tiled copy of A");
     HIP_CHECK(hipDeviceSynchronize());
     setup_time = time_since(t0);
+}
+
+// Gather vector too long for the L2s (>= 4 M entries = 32 MB) and the tiled build declined for lack of dense tiles: the
+// stream kernel would pay a fabric line per gathered element (HPRLP_NO_PB_FALLBACK=1 keeps it anyway; one GPU only).
+bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
+    const char *no = std::getenv("HPRLP_NO_PB_FALLBACK");
+    if (no && no[0] == '1') return false;
+    const char *nt = std::getenv("HPRLP_NO_TILED");
+    if (nt && nt[0] == '1') return false;
+    return !comm && !M.view.tiled.valid && M.declined_sparse && M.view.cols >= (1 << 22) && M.view.nnz >= 4000000;
 }
 
 // Large matrix whose given order failed the tiling test: look for a locality ordering (reorder.cpp).  On entry A (device

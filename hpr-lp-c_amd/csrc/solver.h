@@ -48,7 +48,10 @@ struct DeviceMatrix {
     std::future<std::shared_ptr<TiledHost>> tiling;
     int planned_grid = 0;  // grid of the tiled kernel if the build succeeds (sizes the reduction partials)
     void upload(int rows, int cols, const int *rp, const int *ci, const double *v, std::shared_ptr<void> keep = nullptr);
-    void describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep);  // after the arrays are on the device
+    // after the arrays are on the device.  min_dense >= 0 overrides the share of the entries the tiled build wants in
+    // staged tiles (0: accept any pattern -- everything outside dense tiles goes through the propagation-blocking remainder)
+    void describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep, double min_dense_override = -1.0);
+    bool declined_sparse = false;  // the last tiled build was declined for lack of dense tiles (not for size)
     void finish_tiling(hipStream_t s);  // wait for the job, upload the copy, fill its values from the CSR values
     void refresh_tiled(hipStream_t s);  // re-gather the tiled values from the CSR values (after scaling)
 };
@@ -89,6 +92,7 @@ struct Solver {
     std::vector<int> perm_r, perm_c;
     double reorder_time = 0.0, reorder_before = 0.0, reorder_after = 0.0;
     bool try_reorder(const LP_info_cpu *model);
+    bool pb_fallback_wanted(const DeviceMatrix &M) const;  // unstructured large matrix: tiled form without dense-tile requirement
     // Hand-off of the remainder products between the two kernels of an iteration (kernels.h: FarPush).  far_A_ready: A's
     // remainder buffer holds the products of the current x_hat (written by the x-half's epilogue); far_AT_ready likewise
     // for y.  Every other launch on a tiled matrix refills its buffer for another vector: invalidate_far().

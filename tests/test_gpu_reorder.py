@@ -82,3 +82,53 @@ def test_reordered_solve_returns_the_callers_numbering(gpu, lp):
     rd = lp["c"] - A.T @ r.y - r.z
     assert np.linalg.norm(rd) <= 3e-4 * (1 + np.linalg.norm(lp["c"]))
     model.free()
+
+
+def test_unstructured_large_matrix_runs_propagation_blocking(gpu):
+    """No locality to be found (uniformly random pattern, 4.2 M columns: the gathered vector is far beyond the L2s): the
+    ordering is tried and rejected, and the tiled form is accepted WITHOUT a dense-tile requirement -- every entry goes
+    through the propagation-blocking remainder.  Same iterates as the stream kernel and as the oracle."""
+    rng = np.random.default_rng(21)
+    m = n = 4_300_000
+    per_row = 3
+    cols = rng.integers(0, n, size=(m, per_row))
+    cols.sort(axis=1)
+    cols[:, 1] = np.where(cols[:, 1] == cols[:, 0], (cols[:, 1] + 1) % n, cols[:, 1])
+    cols[:, 2] = np.where((cols[:, 2] == cols[:, 1]) | (cols[:, 2] == cols[:, 0]), (cols[:, 2] + 2) % n, cols[:, 2])
+    cols.sort(axis=1)
+    keep = np.ones((m, per_row), bool)
+    keep[:, 1:] &= cols[:, 1:] != cols[:, :-1]
+    rp = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int32)
+    ci = cols[keep].astype(np.int32)
+    v = rng.normal(size=len(ci))
+    A = sparse.csr_matrix((v, ci, rp), shape=(m, n))
+    x0 = rng.uniform(0, 1, size=n)
+    b = A @ x0
+    AL, AU = b - 1.0, b + 1.0
+    l, u, c = np.zeros(n), np.full(n, 2.0), rng.normal(size=n)
+    model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, c)
+
+    def run():
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+        info = s.info()
+        s.scale()
+        lam, it = s.power_iteration(max_iter=30)
+        s.init(0.7, 1.3 * lam)
+        s.iterate(12, True)
+        out = (info, lam, {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}, s.residuals(13, True))
+        s.close()
+        return out
+
+    info, lam, st, res = run()
+    assert info["tiled"] == 3 and not info["reordered"], info
+    os.environ["HPRLP_NO_PB_FALLBACK"] = "1"
+    try:
+        info0, lam0, st0, res0 = run()
+    finally:
+        os.environ.pop("HPRLP_NO_PB_FALLBACK", None)
+    assert info0["tiled"] == 0
+    assert abs(lam - lam0) <= 1e-11 * abs(lam0)
+    for k in st:
+        np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    assert abs(res["kkt"] - res0["kkt"]) <= 1e-9 * (1 + abs(res0["kkt"]))
+    model.free()

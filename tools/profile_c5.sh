@@ -43,14 +43,11 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 if "FETCH_SIZE" in far and "WRITE_SIZE" in far:
     far["bytes_per_launch"] = (2 * far["FETCH_SIZE"] + far["WRITE_SIZE"]) * 1024
     res["k_far_products"] = far
-# with the producer-side hand-off (kernels.h: FarPush) the normal half-steps run WITHOUT a pre-pass of their own: the few
-# k_far_products launches left belong to residual / power-iteration SpMVs.  Count launches to tell the two builds apart.
-calls = collections.Counter()
-for f in glob.glob(f"{out}/fetch/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == "FETCH_SIZE":
-            calls["far" if "k_far_products" in r["Kernel_Name"] else ("half" if ("XEpi<false>" in r["Kernel_Name"] or "YEpi<false>" in r["Kernel_Name"]) else "other")] += 1
-handoff = calls["half"] > 0 and calls["far"] < calls["half"] + calls["other"] * 0 + 0 and calls["far"] - calls["other"] < 0.5 * calls["half"]
+# with the producer-side hand-off (kernels.h: FarPush; default, HPRLP_NO_FAR_PUSH=1 disables) the normal half-steps run WITHOUT
+# a pre-pass of their own: the k_far_products launches left belong to the residual / power-iteration SpMVs
+import os
+handoff = os.environ.get("HPRLP_NO_FAR_PUSH", "0") != "1"
+calls = {}
 def half(tag):
     k = [v for n, v in res.items() if "k_tiled_fused" in n and tag in n and "bytes_per_launch" in v]
     return (k[0]["bytes_per_launch"] + (0.0 if handoff else far.get("bytes_per_launch", 0.0))) if k else None
