@@ -202,6 +202,36 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
         S.bfs_levels = level + 1;
         if (ch == 0) break;
     }
+    // Graphs of large diameter (grids, chains: a BFS ball grows polynomially, not by a factor per hop) are not covered after
+    // those levels: finish with a queue-based multi-source BFS from the labelled nodes, O(edges) in all, sequential and in
+    // index order (deterministic).  Nodes of components without a seed stay unlabelled (they keep their own relative index).
+    {
+        std::vector<int> queue;  // node ids: rows 0..m-1, columns m..m+n-1
+        for (int i = 0; i < m; ++i)
+            if (lab_r[i] >= 0) queue.push_back(i);
+        for (int j = 0; j < n; ++j)
+            if (lab_c[j] >= 0) queue.push_back(m + j);
+        if (static_cast<long>(queue.size()) < N) {
+            for (size_t h = 0; h < queue.size(); ++h) {
+                const int v = queue[h];
+                if (v < m) {
+                    const int lab = lab_r[v];
+                    for (int k = rp[v]; k < rp[v + 1]; ++k)
+                        if (lab_c[ci[k]] < 0) {
+                            lab_c[ci[k]] = lab;
+                            queue.push_back(m + ci[k]);
+                        }
+                } else {
+                    const int j = v - m, lab = lab_c[j];
+                    for (int k = trp[j]; k < trp[j + 1]; ++k)
+                        if (lab_r[tci[k]] < 0) {
+                            lab_r[tci[k]] = lab;
+                            queue.push_back(tci[k]);
+                        }
+                }
+            }
+        }
+    }
 
     // A seed row with a far entry grows a satellite blob around that entry's column (a few percent of the cluster, far
     // away); such a cluster links two distant places of the cluster graph and folds the spectral order.  Two rounds of
