@@ -79,6 +79,13 @@ __device__ __forceinline__ void block_store_per_problem(double (&acc)[NACC], con
 // ---- fused SpMM + half-step ---------------------------------------------------------------------
 // XHALF: M = A^T (n rows), V = Y.  reference update_x_z_{check,normal}_batched_kernel :122-178
 // else : M = A   (m rows), V = X_hat.  reference update_y_{check,normal}_batched_kernel :180-236
+// cache policy of the panel streams (measured on config 4, profiles/r02_pmc_summary.md)
+#ifndef HPRLP_BATCH_NT
+#define HPRLP_BATCH_NT 1  // 1: nontemporal loads of the panel streams (6390 -> 6800 batch-it/s on config 4); 2: also store X nontemporal (no difference)
+#endif
+constexpr bool kNtPanels = HPRLP_BATCH_NT != 0;
+constexpr bool kNtStoreX = HPRLP_BATCH_NT >= 2;
+
 struct HalfArgs {
     const double *V;                   // gathered panel
     double *P, *P_hat;                 // X / X_hat  or  Y / (unused)
@@ -100,8 +107,9 @@ __device__ __forceinline__ void half_update(const HalfArgs &a, size_t t, double 
         const double zt = xi + sig * (s - p_cost);
         const double xb = fmin(fmax(zt, p_lo), p_hi);
         const double xh = 2.0 * xb - xi;
-        a.P_hat[t] = xh;
-        a.P[t] = f2 * xh + f1 * p_last;
+        a.P_hat[t] = xh;  // gathered by the y-half that follows: default policy
+        if (kNtStoreX) __builtin_nontemporal_store(f2 * xh + f1 * p_last, a.P + t);  // next read: the next iteration's x-half
+        else a.P[t] = f2 * xh + f1 * p_last;
         if (CHECK) {
             const double zb = (xb - zt) / sig, dx = xb - xh;
             a.delta[t] = dx;
@@ -204,8 +212,14 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             const size_t t = static_cast<size_t>(min(rb + i, rows - 1)) * Bp + k;
-            p_i[i] = a.P[t], p_lo[i] = a.lo[t], p_hi[i] = a.hi[t], p_last[i] = a.last[t];
-            p_cost[i] = XHALF ? a.cost[t] : 0.0;
+            if (kNtPanels) {  // the panel streams are read once per half-step: keep them out of the gathered panel's way in the caches
+                p_i[i] = __builtin_nontemporal_load(a.P + t), p_lo[i] = __builtin_nontemporal_load(a.lo + t);
+                p_hi[i] = __builtin_nontemporal_load(a.hi + t), p_last[i] = __builtin_nontemporal_load(a.last + t);
+                p_cost[i] = XHALF ? __builtin_nontemporal_load(a.cost + t) : 0.0;
+            } else {
+                p_i[i] = a.P[t], p_lo[i] = a.lo[t], p_hi[i] = a.hi[t], p_last[i] = a.last[t];
+                p_cost[i] = XHALF ? a.cost[t] : 0.0;
+            }
             s[i] = 0.0;
         }
         const int pend = pb[RW];
