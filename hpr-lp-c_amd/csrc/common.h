@@ -35,6 +35,27 @@ inline double time_since(clock_type::time_point t0) {
     return std::chrono::duration<double>(clock_type::now() - t0).count();
 }
 
+// HPRLP_TIMING=1: where the allocator's time goes (hipMalloc / hipFree of multi-GB set-up temporaries are not free)
+struct AllocStats {
+    double malloc_s = 0, free_s = 0;
+    long mallocs = 0, frees = 0;
+    static AllocStats &get() {
+        static AllocStats s;
+        return s;
+    }
+};
+
+// Process-wide cache of large freed device blocks (host_model.cpp).  hipMalloc of a multi-GB set-up temporary right after the
+// previous solver's buffers were freed stalls for 0.5-0.9 s now and then on MI355X / ROCm 7.2 (measured with HPRLP_TIMING=1: one
+// hipMalloc call, a third of config 5's time-to-tolerance); blocks of 1 MiB and more therefore go back to this cache instead of
+// the driver and are handed out again to requests of the same size class (rounded up to 2 MiB).  Per device, mutex-protected,
+// capped at kDeviceCacheCapBytes; HPRLP_NO_ALLOC_CACHE=1 switches it off, hprlp_release_device_cache() returns everything.
+constexpr size_t kDeviceCacheMinBytes = size_t(1) << 20;
+constexpr size_t kDeviceCacheCapBytes = size_t(96) << 30;
+void *device_cache_get(size_t bytes, size_t *capacity);  // nullptr: nothing suitable cached
+bool device_cache_put(void *p, size_t capacity);        // false: not cached (caller frees)
+void device_cache_trim();
+
 // Device buffer with RAII; sized in elements.
 template <class T>
 struct DBuf {
@@ -44,25 +65,46 @@ struct DBuf {
     explicit DBuf(size_t count) { alloc(count); }
     DBuf(const DBuf &) = delete;
     DBuf &operator=(const DBuf &) = delete;
-    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n), cap_bytes(o.cap_bytes) { o.p = nullptr; o.n = 0; o.cap_bytes = 0; }
     DBuf &operator=(DBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; cap_bytes = o.cap_bytes; o.p = nullptr; o.n = 0; o.cap_bytes = 0; }
         return *this;
     }
     ~DBuf() { release(); }
+    size_t cap_bytes = 0;  // size of the underlying block (>= n * sizeof(T); blocks from the cache are rounded up)
     void alloc(size_t count) {
         release();
         n = count;
-        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T)));
+        size_t bytes = (count ? count : 1) * sizeof(T);
+        if (bytes >= kDeviceCacheMinBytes) {
+            bytes = (bytes + (size_t(2) << 20) - 1) / (size_t(2) << 20) * (size_t(2) << 20);
+            if (void *q = device_cache_get(bytes, &cap_bytes)) {
+                p = static_cast<T *>(q);
+                return;
+            }
+        }
+        const auto t0 = time_now();
+        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+        cap_bytes = bytes;
+        AllocStats::get().malloc_s += time_since(t0);
+        ++AllocStats::get().mallocs;
     }
     void alloc_zero(size_t count) {
         alloc(count);
         HIP_CHECK(hipMemset(p, 0, (count ? count : 1) * sizeof(T)));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (!(cap_bytes >= kDeviceCacheMinBytes && device_cache_put(p, cap_bytes))) {
+                const auto t0 = time_now();
+                (void)hipFree(p);
+                AllocStats::get().free_s += time_since(t0);
+                ++AllocStats::get().frees;
+            }
+        }
         p = nullptr;
         n = 0;
+        cap_bytes = 0;
     }
     void upload(const T *src, size_t count) {
         if (count) HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));

@@ -379,6 +379,11 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     pt.tick("vectors, work space, tiled copy of A");
     HIP_CHECK(hipDeviceSynchronize());
     setup_time = time_since(t0);
+    if (pt.on) {
+        const AllocStats &as = AllocStats::get();
+        std::cerr << "[timing] allocator so far (process): " << as.mallocs << " hipMalloc " << as.malloc_s << " s, " << as.frees << " hipFree "
+                  << as.free_s << " s" << std::endl;
+    }
 }
 
 // Gather vector too long for the L2s (>= 4 M entries = 32 MB) and the tiled build declined for lack of dense tiles: the

@@ -28,6 +28,10 @@ typedef struct hprlp_trace_row {
 
 const char *hprlp_last_error(void);
 const char *hprlp_backend(void); /* "hip-gfx950" */
+/* The library keeps freed device blocks of 1 MiB and more for its next solver (a hipMalloc of a multi-GB set-up temporary right
+ * behind a large hipFree stalls for up to a second on this platform); this returns them all to the driver.  HPRLP_NO_ALLOC_CACHE=1
+ * disables the cache. */
+void hprlp_release_device_cache(void);
 
 /* copy_lpinfo_to_device + allocate_memory (reference src/preprocess.cu:66-256): uploads A, builds A^T
  * and the wave row-block descriptors, allocates the work vectors.  Does not scale. */
