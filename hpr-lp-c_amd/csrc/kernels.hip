@@ -622,23 +622,45 @@ __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const 
     const int b = t.f_gptr[g], e = t.f_gptr[g + 1];
     if (b >= e) return;
     const int w = min(kFarGroup, ncols - c0);
-    for (int i = tid; i < w; i += kFarThreads) v[i] = vec[c0 + i];
-    __syncthreads();
+    // the first batch of entries does not depend on the staged slice: its loads go out before the slice's
+    constexpr int U = 4;
+    double a[U];
+    int pos[U];
+    uint16_t lc[U];
     int k = b + tid;
-    for (; k + 3 * kFarThreads < e; k += 4 * kFarThreads) {
-        double a[4];
-        int pos[4];
-        uint16_t lc[4];
+    auto load_batch = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = __builtin_nontemporal_load(t.f_val + k + u * kFarThreads);
-            pos[u] = __builtin_nontemporal_load(t.f_pos + k + u * kFarThreads);
-            lc[u] = __builtin_nontemporal_load(t.f_lcol + k + u * kFarThreads);
+        for (int u = 0; u < U; ++u) {
+            const int q = min(k0 + u * kFarThreads, e - 1);  // clamped: branch-free, surplus lanes are masked at the store
+            a[u] = __builtin_nontemporal_load(t.f_val + q);
+            pos[u] = __builtin_nontemporal_load(t.f_pos + q);
+            lc[u] = __builtin_nontemporal_load(t.f_lcol + q);
         }
+    };
+    load_batch(k);
+    {   // slice -> LDS: all loads in flight before the first store
+        constexpr int S = kFarGroup / kFarThreads;
+        double sv[S];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t.P[pos[u]] = a[u] * v[lc[u]];
+        for (int i = 0; i < S; ++i) sv[i] = vec[c0 + min(tid + i * kFarThreads, w - 1)];
+#pragma unroll
+        for (int i = 0; i < S; ++i) v[tid + i * kFarThreads] = sv[i];
     }
-    for (; k < e; k += kFarThreads) t.P[t.f_pos[k]] = t.f_val[k] * v[t.f_lcol[k]];
+    __syncthreads();
+    for (; k < e; k += U * kFarThreads) {
+        double pr[U];
+        int ps[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pr[u] = a[u] * v[lc[u]];
+            ps[u] = pos[u];
+        }
+        const int kn = k + U * kFarThreads;
+        if (kn < e) load_batch(kn);  // next batch in flight while this one is stored
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + u * kFarThreads < e) t.P[ps[u]] = pr[u];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
