@@ -1,4 +1,6 @@
-// reorder.cpp -- set-up time locality ordering of an LP matrix (host).
+// reorder.cpp -- set-up time locality ordering of an LP matrix: the method on the host (what hprlp_locality_ordering and the
+// CPU tests run, and the form the device path is checked against) and cluster_order, the one step the solver keeps on the
+// host; the solver runs steps 1, 2, 4, 5 on the device (reorder_dev.hip, Solver::try_reorder).
 //
 // Why: the column-tiled kernels (tiled.h) need column locality -- the rows of a super-block must read a narrow window
 // of the gathered vector.  An LP handed over in an arbitrary row/column order (or a structured one whose structure its
@@ -140,169 +142,11 @@ double tiling_dense_fraction(int m, int n, const int *rp, const int *ci, const i
     return static_cast<double>(d) / static_cast<double>(nnz);
 }
 
-void cluster_positions(int m, int n, const int *rp, const int *ci, const int *trp_, const int *tci_, std::vector<double> *pos_r,
-                       std::vector<double> *pos_c, ReorderStats *st) {
+// Steps 2b-3: from the directed cluster-to-cluster edge counts W[a] = {(b, count)} (sorted by b) to the position (rank in
+// (0, 1)) of every cluster: symmetrise, drop the weak links, order every component of what is left spectrally.
+std::vector<double> cluster_order(int K, const std::vector<std::vector<std::pair<int, float>>> &W, ReorderStats *st) {
     ReorderStats local;
     ReorderStats &S = st ? *st : local;
-    auto tphase = time_now();
-    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;
-    auto tick = [&](const char *what) {
-        if (timing) std::fprintf(stderr, "[timing]   reorder %-28s %.2f s\n", what, time_since(tphase));
-        tphase = time_now();
-    };
-    const long nnz = rp[m];
-    const int T = worker_count(nnz);
-    const int *trp = trp_, *tci = tci_;
-    // ---- 1. Voronoi clusters
-    const long N = static_cast<long>(m) + n;
-    // about 16k nodes per cluster: a BFS ball of that size is as wide as the matrix' natural window anyway, and the
-    // spectral ordering of the cluster graph (dense-ish: every cluster links to all that overlap it) stays cheap
-    long per_cluster = 16384;
-    if (const char *e = std::getenv("HPRLP_REORDER_CLUSTER")) per_cluster = std::max(64L, std::atol(e));
-    const int K = static_cast<int>(std::max<long>(2, std::min<long>(65536, std::min<long>(m, N / per_cluster + 1))));
-    S.clusters = K;
-    std::vector<int> lab_r(static_cast<size_t>(m), -1), lab_c(static_cast<size_t>(n), -1);
-    for (int k = 0; k < K; ++k) lab_r[static_cast<size_t>(static_cast<long>(k) * m / K)] = k;
-    for (int level = 0; level < 12; ++level) {
-        // columns pull from rows, then rows pull from the columns just labelled (one hop each)
-        std::vector<long> changed(static_cast<size_t>(T), 0);
-        parallel_chunks(n, T, [&](int t, long b, long e) {
-            long ch = 0;
-            for (long j = b; j < e; ++j) {
-                if (lab_c[j] >= 0) continue;
-                for (int k = trp[j]; k < trp[j + 1]; ++k) {
-                    const int l = lab_r[tci[k]];
-                    if (l >= 0) {
-                        lab_c[j] = l;
-                        ++ch;
-                        break;
-                    }
-                }
-            }
-            changed[t] = ch;
-        });
-        // (a row reads column labels only and writes its own: no races, the result does not depend on the thread count)
-        parallel_chunks(m, T, [&](int t, long b, long e) {
-            long ch = 0;
-            for (long i = b; i < e; ++i) {
-                if (lab_r[i] >= 0) continue;
-                for (int k = rp[i]; k < rp[i + 1]; ++k) {
-                    const int l = lab_c[ci[k]];
-                    if (l >= 0) {
-                        lab_r[i] = l;
-                        ++ch;
-                        break;
-                    }
-                }
-            }
-            changed[t] += ch;
-        });
-        long ch = 0;
-        for (long v : changed) ch += v;
-        S.bfs_levels = level + 1;
-        if (ch == 0) break;
-    }
-    // Graphs of large diameter (grids, chains: a BFS ball grows polynomially, not by a factor per hop) are not covered after
-    // those levels: finish with a queue-based multi-source BFS from the labelled nodes, O(edges) in all, sequential and in
-    // index order (deterministic).  Nodes of components without a seed stay unlabelled (they keep their own relative index).
-    {
-        std::vector<int> queue;  // node ids: rows 0..m-1, columns m..m+n-1
-        for (int i = 0; i < m; ++i)
-            if (lab_r[i] >= 0) queue.push_back(i);
-        for (int j = 0; j < n; ++j)
-            if (lab_c[j] >= 0) queue.push_back(m + j);
-        if (static_cast<long>(queue.size()) < N) {
-            for (size_t h = 0; h < queue.size(); ++h) {
-                const int v = queue[h];
-                if (v < m) {
-                    const int lab = lab_r[v];
-                    for (int k = rp[v]; k < rp[v + 1]; ++k)
-                        if (lab_c[ci[k]] < 0) {
-                            lab_c[ci[k]] = lab;
-                            queue.push_back(m + ci[k]);
-                        }
-                } else {
-                    const int j = v - m, lab = lab_c[j];
-                    for (int k = trp[j]; k < trp[j + 1]; ++k)
-                        if (lab_r[tci[k]] < 0) {
-                            lab_r[tci[k]] = lab;
-                            queue.push_back(tci[k]);
-                        }
-                }
-            }
-        }
-    }
-
-    // A seed row with a far entry grows a satellite blob around that entry's column (a few percent of the cluster, far
-    // away); such a cluster links two distant places of the cluster graph and folds the spectral order.  Two rounds of
-    // "take the label most of your neighbours have" dissolve the satellites into the clusters around them.
-    {
-        auto majority = [&](int cnt_nodes, const int *xp, const int *xi, const std::vector<int> &src, std::vector<int> &dst) {
-            parallel_chunks(cnt_nodes, T, [&](int, long b, long e) {
-                int buf[32];
-                for (long i = b; i < e; ++i) {
-                    const int k0 = xp[i], len = xp[i + 1] - k0;
-                    int take = 0;
-                    const int want = std::min(len, 32);
-                    for (int q = 0; q < want; ++q) {
-                        const int l = src[xi[k0 + static_cast<int>(static_cast<long>(q) * len / want)]];
-                        if (l >= 0) buf[take++] = l;
-                    }
-                    if (take == 0) continue;
-                    std::sort(buf, buf + take);
-                    int best = buf[0], best_n = 0, run = 0;
-                    for (int q = 0; q < take; ++q) {
-                        run = (q > 0 && buf[q] == buf[q - 1]) ? run + 1 : 1;
-                        if (run > best_n) {
-                            best_n = run;
-                            best = buf[q];
-                        }
-                    }
-                    dst[i] = best;
-                }
-            });
-        };
-        for (int round = 0; round < 2; ++round) {
-            std::vector<int> nc_lab(lab_c), nr_lab(lab_r);
-            majority(n, trp, tci, lab_r, nc_lab);
-            lab_c.swap(nc_lab);
-            majority(m, rp, ci, lab_c, nr_lab);
-            lab_r.swap(nr_lab);
-        }
-    }
-    tick("Voronoi clusters");
-    // ---- 2. cluster graph from the row side: W[a] = {(b, #edges between rows of a and columns of b)}
-    std::vector<int> cl_ptr(static_cast<size_t>(K) + 1, 0), cl_rows;
-    {
-        for (int i = 0; i < m; ++i)
-            if (lab_r[i] >= 0) ++cl_ptr[lab_r[i] + 1];
-        for (int k = 0; k < K; ++k) cl_ptr[k + 1] += cl_ptr[k];
-        cl_rows.resize(static_cast<size_t>(cl_ptr[K]));
-        std::vector<int> next(cl_ptr.begin(), cl_ptr.end() - 1);
-        for (int i = 0; i < m; ++i)
-            if (lab_r[i] >= 0) cl_rows[next[lab_r[i]]++] = i;
-    }
-    std::vector<std::vector<std::pair<int, float>>> W(static_cast<size_t>(K));
-    parallel_chunks(K, T, [&](int, long b, long e) {
-        std::vector<int> cnt(static_cast<size_t>(K), 0), touched;
-        for (long a = b; a < e; ++a) {
-            touched.clear();
-            for (int q = cl_ptr[a]; q < cl_ptr[a + 1]; ++q) {
-                const int i = cl_rows[q];
-                for (int k = rp[i]; k < rp[i + 1]; ++k) {
-                    const int l = lab_c[ci[k]];
-                    if (l < 0 || l == a) continue;
-                    if (cnt[l]++ == 0) touched.push_back(l);
-                }
-            }
-            std::sort(touched.begin(), touched.end());
-            W[a].reserve(touched.size());
-            for (int l : touched) {
-                W[a].emplace_back(l, static_cast<float>(cnt[l]));
-                cnt[l] = 0;
-            }
-        }
-    });
     // symmetric weights S = W + W^T, then the threshold (relative to the heaviest link of either end)
     std::vector<std::vector<std::pair<int, float>>> G(static_cast<size_t>(K));
     {
@@ -335,7 +179,6 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
         }
     }
 
-    tick("cluster graph");
     // ---- 3. order the clusters: components of the thresholded graph, spectral order inside each
     std::vector<double> cpos(static_cast<size_t>(K), 0.0);  // position (rank) of a cluster
     {
@@ -507,6 +350,174 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
         for (int q = 0; q < K; ++q) cpos[order[q]] = (static_cast<double>(q) + 0.5) / K;
     }
 
+    return cpos;
+}
+
+void cluster_positions(int m, int n, const int *rp, const int *ci, const int *trp_, const int *tci_, std::vector<double> *pos_r,
+                       std::vector<double> *pos_c, ReorderStats *st) {
+    ReorderStats local;
+    ReorderStats &S = st ? *st : local;
+    auto tphase = time_now();
+    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;
+    auto tick = [&](const char *what) {
+        if (timing) std::fprintf(stderr, "[timing]   reorder %-28s %.2f s\n", what, time_since(tphase));
+        tphase = time_now();
+    };
+    const long nnz = rp[m];
+    const int T = worker_count(nnz);
+    const int *trp = trp_, *tci = tci_;
+    // ---- 1. Voronoi clusters
+    const long N = static_cast<long>(m) + n;
+    // about 16k nodes per cluster: a BFS ball of that size is as wide as the matrix' natural window anyway, and the
+    // spectral ordering of the cluster graph (dense-ish: every cluster links to all that overlap it) stays cheap
+    long per_cluster = 16384;
+    if (const char *e = std::getenv("HPRLP_REORDER_CLUSTER")) per_cluster = std::max(64L, std::atol(e));
+    const int K = static_cast<int>(std::max<long>(2, std::min<long>(65536, std::min<long>(m, N / per_cluster + 1))));
+    S.clusters = K;
+    std::vector<int> lab_r(static_cast<size_t>(m), -1), lab_c(static_cast<size_t>(n), -1);
+    for (int k = 0; k < K; ++k) lab_r[static_cast<size_t>(static_cast<long>(k) * m / K)] = k;
+    for (int level = 0; level < 12; ++level) {
+        // columns pull from rows, then rows pull from the columns just labelled (one hop each)
+        std::vector<long> changed(static_cast<size_t>(T), 0);
+        parallel_chunks(n, T, [&](int t, long b, long e) {
+            long ch = 0;
+            for (long j = b; j < e; ++j) {
+                if (lab_c[j] >= 0) continue;
+                for (int k = trp[j]; k < trp[j + 1]; ++k) {
+                    const int l = lab_r[tci[k]];
+                    if (l >= 0) {
+                        lab_c[j] = l;
+                        ++ch;
+                        break;
+                    }
+                }
+            }
+            changed[t] = ch;
+        });
+        // (a row reads column labels only and writes its own: no races, the result does not depend on the thread count)
+        parallel_chunks(m, T, [&](int t, long b, long e) {
+            long ch = 0;
+            for (long i = b; i < e; ++i) {
+                if (lab_r[i] >= 0) continue;
+                for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                    const int l = lab_c[ci[k]];
+                    if (l >= 0) {
+                        lab_r[i] = l;
+                        ++ch;
+                        break;
+                    }
+                }
+            }
+            changed[t] += ch;
+        });
+        long ch = 0;
+        for (long v : changed) ch += v;
+        S.bfs_levels = level + 1;
+        if (ch == 0) break;
+    }
+    // Graphs of large diameter (grids, chains: a BFS ball grows polynomially, not by a factor per hop) are not covered after
+    // those levels: finish with a queue-based multi-source BFS from the labelled nodes, O(edges) in all, sequential and in
+    // index order (deterministic).  Nodes of components without a seed stay unlabelled (they keep their own relative index).
+    {
+        std::vector<int> queue;  // node ids: rows 0..m-1, columns m..m+n-1
+        for (int i = 0; i < m; ++i)
+            if (lab_r[i] >= 0) queue.push_back(i);
+        for (int j = 0; j < n; ++j)
+            if (lab_c[j] >= 0) queue.push_back(m + j);
+        if (static_cast<long>(queue.size()) < N) {
+            for (size_t h = 0; h < queue.size(); ++h) {
+                const int v = queue[h];
+                if (v < m) {
+                    const int lab = lab_r[v];
+                    for (int k = rp[v]; k < rp[v + 1]; ++k)
+                        if (lab_c[ci[k]] < 0) {
+                            lab_c[ci[k]] = lab;
+                            queue.push_back(m + ci[k]);
+                        }
+                } else {
+                    const int j = v - m, lab = lab_c[j];
+                    for (int k = trp[j]; k < trp[j + 1]; ++k)
+                        if (lab_r[tci[k]] < 0) {
+                            lab_r[tci[k]] = lab;
+                            queue.push_back(tci[k]);
+                        }
+                }
+            }
+        }
+    }
+
+    // A seed row with a far entry grows a satellite blob around that entry's column (a few percent of the cluster, far
+    // away); such a cluster links two distant places of the cluster graph and folds the spectral order.  Two rounds of
+    // "take the label most of your neighbours have" dissolve the satellites into the clusters around them.
+    {
+        auto majority = [&](int cnt_nodes, const int *xp, const int *xi, const std::vector<int> &src, std::vector<int> &dst) {
+            parallel_chunks(cnt_nodes, T, [&](int, long b, long e) {
+                int buf[32];
+                for (long i = b; i < e; ++i) {
+                    const int k0 = xp[i], len = xp[i + 1] - k0;
+                    int take = 0;
+                    const int want = std::min(len, 32);
+                    for (int q = 0; q < want; ++q) {
+                        const int l = src[xi[k0 + static_cast<int>(static_cast<long>(q) * len / want)]];
+                        if (l >= 0) buf[take++] = l;
+                    }
+                    if (take == 0) continue;
+                    std::sort(buf, buf + take);
+                    int best = buf[0], best_n = 0, run = 0;
+                    for (int q = 0; q < take; ++q) {
+                        run = (q > 0 && buf[q] == buf[q - 1]) ? run + 1 : 1;
+                        if (run > best_n) {
+                            best_n = run;
+                            best = buf[q];
+                        }
+                    }
+                    dst[i] = best;
+                }
+            });
+        };
+        for (int round = 0; round < 2; ++round) {
+            std::vector<int> nc_lab(lab_c), nr_lab(lab_r);
+            majority(n, trp, tci, lab_r, nc_lab);
+            lab_c.swap(nc_lab);
+            majority(m, rp, ci, lab_c, nr_lab);
+            lab_r.swap(nr_lab);
+        }
+    }
+    tick("Voronoi clusters");
+    // ---- 2. cluster graph from the row side: W[a] = {(b, #edges between rows of a and columns of b)}
+    std::vector<int> cl_ptr(static_cast<size_t>(K) + 1, 0), cl_rows;
+    {
+        for (int i = 0; i < m; ++i)
+            if (lab_r[i] >= 0) ++cl_ptr[lab_r[i] + 1];
+        for (int k = 0; k < K; ++k) cl_ptr[k + 1] += cl_ptr[k];
+        cl_rows.resize(static_cast<size_t>(cl_ptr[K]));
+        std::vector<int> next(cl_ptr.begin(), cl_ptr.end() - 1);
+        for (int i = 0; i < m; ++i)
+            if (lab_r[i] >= 0) cl_rows[next[lab_r[i]]++] = i;
+    }
+    std::vector<std::vector<std::pair<int, float>>> W(static_cast<size_t>(K));
+    parallel_chunks(K, T, [&](int, long b, long e) {
+        std::vector<int> cnt(static_cast<size_t>(K), 0), touched;
+        for (long a = b; a < e; ++a) {
+            touched.clear();
+            for (int q = cl_ptr[a]; q < cl_ptr[a + 1]; ++q) {
+                const int i = cl_rows[q];
+                for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                    const int l = lab_c[ci[k]];
+                    if (l < 0 || l == a) continue;
+                    if (cnt[l]++ == 0) touched.push_back(l);
+                }
+            }
+            std::sort(touched.begin(), touched.end());
+            W[a].reserve(touched.size());
+            for (int l : touched) {
+                W[a].emplace_back(l, static_cast<float>(cnt[l]));
+                cnt[l] = 0;
+            }
+        }
+    });
+    tick("cluster graph");
+    const std::vector<double> cpos = cluster_order(K, W, &S);
     tick("spectral order of the clusters");
     // ---- 4. fine positions
     std::vector<double> pr_(static_cast<size_t>(m)), pc_(static_cast<size_t>(n));

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <utility>
 #include <vector>
 
 namespace hprlp {
@@ -29,6 +30,17 @@ bool locality_ordering(int m, int n, const int *rp, const int *ci, std::vector<i
 // node's cluster in (0, 1) (nodes no cluster reached keep their own relative index).  trp / tci: pattern of A^T.
 void cluster_positions(int m, int n, const int *rp, const int *ci, const int *trp, const int *tci, std::vector<double> *pos_r,
                        std::vector<double> *pos_c, ReorderStats *stats);
+
+// Steps 2b-3 alone: directed cluster-to-cluster edge counts W[a] = {(b, count)}, sorted by b -> rank of every cluster in (0, 1).
+std::vector<double> cluster_order(int K, const std::vector<std::vector<std::pair<int, float>>> &W, ReorderStats *stats);
+
+// cluster_positions with the graph work on the device (level-synchronous Voronoi BFS, majority relabelling, edge counts by
+// radix sort + run lengths); only the K x K cluster graph comes back for cluster_order.  pos_r / pos_c: device arrays.
+void device_cluster_positions(int m, int n, long nnz, const int *rp, const int *ci, const int *trp, const int *tci, double *pos_r,
+                              double *pos_c, ReorderStats *stats, hipStream_t s);
+// the tiling test (tiling_dense_fraction) for device patterns; null permutations = the given order
+double device_tiling_dense_fraction(int m, int n, long nnz, const int *rp, const int *ci, const int *row_new2old,
+                                    const int *col_new2old, hipStream_t s);
 
 // Device parts (reorder_dev.hip; all pointers device memory): the median sweeps + rank normalisation + argsorts, and P A Q.
 void device_refine_order(int m, int n, const int *rp, const int *ci, const int *trp, const int *tci, double *pos_r, double *pos_c,

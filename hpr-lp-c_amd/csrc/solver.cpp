@@ -411,34 +411,49 @@ bool Solver::try_reorder(const LP_info_cpu *model) {
     const sparseMatrix *As = model->A;
     const long nnz = As->numElements;
     ReorderStats st;
-    st.fraction_before = tiling_dense_fraction(m, n, As->rowPtr, As->colIndex, nullptr, nullptr);
+    // everything but the spectral ordering of the (small) cluster graph runs on the device, on the patterns of A and A^T
+    // that are resident already; HPRLP_REORDER_HOST=1 keeps the clustering on the host (reorder.cpp, the reference form)
+    const char *hostc = std::getenv("HPRLP_REORDER_HOST");
+    const bool host_clusters = hostc && hostc[0] == '1';
+    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;
+    auto tphase = time_now();
+    auto tick = [&](const char *what) {
+        if (timing) std::cerr << "[timing]   reorder " << what << " " << time_since(tphase) << " s" << std::endl;
+        tphase = time_now();
+    };
+    st.fraction_before = device_tiling_dense_fraction(m, n, nnz, A.rowptr.p, A.col.p, nullptr, nullptr, stream);
     reorder_before = st.fraction_before;
+    tick("tiling test (given order)");
     if (st.fraction_before >= 0.5) return false;  // the tiled build declined for another reason
-    // pattern of A^T back to the host for the clustering
-    std::vector<int> trp(static_cast<size_t>(n) + 1), tci(static_cast<size_t>(nnz));
-    AT.rowptr.download(trp.data(), trp.size());
-    AT.col.download(tci.data(), tci.size());
-    std::vector<double> pr, pc;
-    cluster_positions(m, n, As->rowPtr, As->colIndex, trp.data(), tci.data(), &pr, &pc, &st);
-    std::vector<int>().swap(tci);
     DBuf<double> dpr(static_cast<size_t>(m)), dpc(static_cast<size_t>(n));
-    dpr.upload(pr.data(), pr.size());
-    dpc.upload(pc.data(), pc.size());
+    if (host_clusters) {
+        std::vector<int> trp(static_cast<size_t>(n) + 1), tci(static_cast<size_t>(nnz));
+        AT.rowptr.download(trp.data(), trp.size());
+        AT.col.download(tci.data(), tci.size());
+        std::vector<double> pr, pc;
+        cluster_positions(m, n, As->rowPtr, As->colIndex, trp.data(), tci.data(), &pr, &pc, &st);
+        dpr.upload(pr.data(), pr.size());
+        dpc.upload(pc.data(), pc.size());
+    } else {
+        device_cluster_positions(m, n, nnz, A.rowptr.p, A.col.p, AT.rowptr.p, AT.col.p, dpr.p, dpc.p, &st, stream);
+    }
+    tick("clusters and their order");
     DBuf<int> d_r(static_cast<size_t>(m)), d_c(static_cast<size_t>(n));
     device_refine_order(m, n, A.rowptr.p, A.col.p, AT.rowptr.p, AT.col.p, dpr.p, dpc.p, kReorderSweeps, d_r.p, d_c.p, stream);
-    std::vector<int> hr(static_cast<size_t>(m)), hc(static_cast<size_t>(n)), c_old2new(static_cast<size_t>(n));
-    d_r.download(hr.data(), hr.size());
-    d_c.download(hc.data(), hc.size());
-    for (int j = 0; j < n; ++j) c_old2new[hc[j]] = j;
-    st.fraction_after = tiling_dense_fraction(m, n, As->rowPtr, As->colIndex, hr.data(), c_old2new.data());
+    tick("median sweeps");
+    st.fraction_after = device_tiling_dense_fraction(m, n, nnz, A.rowptr.p, A.col.p, d_r.p, d_c.p, stream);
     reorder_after = st.fraction_after;
+    tick("tiling test (permuted)");
     if (verbose || std::getenv("HPRLP_TIMING"))
         std::cerr << "[reorder] tiled share of the entries " << st.fraction_before << " -> " << st.fraction_after << " (" << st.clusters
-                  << " clusters, " << st.components << " components, " << time_since(t0) << " s)" << std::endl;
+                  << " clusters, " << st.components << " components, " << st.bfs_levels << " BFS levels, " << time_since(t0) << " s)" << std::endl;
     if (st.fraction_after < 0.5) {
         reorder_time = time_since(t0);
         return false;
     }
+    std::vector<int> hr(static_cast<size_t>(m)), hc(static_cast<size_t>(n));
+    d_r.download(hr.data(), hr.size());
+    d_c.download(hc.data(), hc.size());
     // P A Q on the device, swapped into A
     DBuf<int> nrp(static_cast<size_t>(m) + 1), nci(static_cast<size_t>(nnz));
     DBuf<double> nval(static_cast<size_t>(nnz));

@@ -132,3 +132,35 @@ def test_unstructured_large_matrix_runs_propagation_blocking(gpu):
         np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
     assert abs(res["kkt"] - res0["kkt"]) <= 1e-9 * (1 + abs(res0["kkt"]))
     model.free()
+
+
+def test_permuted_grid_is_reordered_on_the_device(gpu):
+    """A five-point grid (large diameter: BFS balls grow polynomially, the Voronoi clustering needs ~100 levels) in random
+    numbering: the device clustering + ordering must make it tileable, and the iterates must match the oracle."""
+    g = 1300
+    m = n = g * g
+    idx = np.arange(n).reshape(g, g)
+    rows = [idx.ravel()] * 5
+    nb = [idx, np.roll(idx, 1, 0), np.roll(idx, -1, 0), np.roll(idx, 1, 1), np.roll(idx, -1, 1)]
+    rng = np.random.default_rng(5)
+    A = sparse.coo_matrix((rng.uniform(0.5, 1.5, size=5 * n) * rng.choice([-1.0, 1.0], size=5 * n),
+                           (np.concatenate(rows), np.concatenate([x.ravel() for x in nb]))), shape=(m, n)).tocsr()
+    pr, pc = rng.permutation(m), rng.permutation(n)
+    inv_pc = np.empty(n, np.int64); inv_pc[pc] = np.arange(n)
+    B = A[pr]
+    B = sparse.csr_matrix((B.data, inv_pc[B.indices], B.indptr), shape=(m, n))
+    B.sort_indices()
+    x0 = rng.uniform(0, 1, size=n)
+    b = B @ x0
+    AL, AU, l, u, c = b - 1.0, b + 1.0, np.zeros(n), np.full(n, 2.0), rng.normal(size=n)
+    rp, ci, v = B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.copy()
+    model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, c)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+    info = s.info()
+    assert info["reordered"] and info["tiled"] == 3, info
+    ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, c, O.Params.default(use_CR_scaling=0))
+    s.scale()
+    st = run_steps(s, ref, 0.6, 1.4, [(7, True), (4, False)])
+    for name in NAMES_N + NAMES_M:
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-12, err_msg=name)
+    s.close(); model.free()
