@@ -84,6 +84,10 @@ __device__ __forceinline__ void block_store_per_problem(double (&acc)[NACC], con
 #define HPRLP_BATCH_NT 1  // 1: nontemporal loads of the panel streams (6390 -> 6800 batch-it/s on config 4); 2: also store X nontemporal (no difference)
 #endif
 constexpr bool kNtPanels = HPRLP_BATCH_NT != 0;
+// developer experiments (build/variants): where does the batched x-half spend its time
+#ifndef HPRLP_DBG_MODE  // bit 0: no panel loads, 1: no stores, 2: no gathers, 3: no SpMM loop at all (kb_half64, normal variant)
+#define HPRLP_DBG_MODE 0
+#endif
 constexpr bool kNtStoreX = HPRLP_BATCH_NT >= 2;
 
 struct HalfArgs {
@@ -107,6 +111,7 @@ __device__ __forceinline__ void half_update(const HalfArgs &a, size_t t, double 
         const double zt = xi + sig * (s - p_cost);
         const double xb = fmin(fmax(zt, p_lo), p_hi);
         const double xh = 2.0 * xb - xi;
+        if ((HPRLP_DBG_MODE & 2) && !CHECK && xh != 1.2345e300) return;
         a.P_hat[t] = xh;  // gathered by the y-half that follows: default policy
         if (kNtStoreX) __builtin_nontemporal_store(f2 * xh + f1 * p_last, a.P + t);  // next read: the next iteration's x-half
         else a.P[t] = f2 * xh + f1 * p_last;
@@ -212,7 +217,9 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             const size_t t = static_cast<size_t>(min(rb + i, rows - 1)) * Bp + k;
-            if (kNtPanels) {  // the panel streams are read once per half-step: keep them out of the gathered panel's way in the caches
+            if ((HPRLP_DBG_MODE & 1) && !CHECK) {
+                p_i[i] = 0.5, p_lo[i] = 0.0, p_hi[i] = 1.0, p_last[i] = 0.25, p_cost[i] = 0.125;
+            } else if (kNtPanels) {  // the panel streams are read once per half-step: keep them out of the gathered panel's way in the caches
                 p_i[i] = __builtin_nontemporal_load(a.P + t), p_lo[i] = __builtin_nontemporal_load(a.lo + t);
                 p_hi[i] = __builtin_nontemporal_load(a.hi + t), p_last[i] = __builtin_nontemporal_load(a.last + t);
                 p_cost[i] = XHALF ? __builtin_nontemporal_load(a.cost + t) : 0.0;
@@ -222,14 +229,14 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
             }
             s[i] = 0.0;
         }
-        const int pend = pb[RW];
+        const int pend = ((HPRLP_DBG_MODE & 8) && !CHECK) ? pb[0] : pb[RW];
         for (int p = pb[0]; p < pend; p += G) {
             double gv[G], av[G];
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 const int q = min(p + u, pend - 1);
                 av[u] = val[q];
-                gv[u] = V[static_cast<size_t>(col[q]) * Bp];
+                gv[u] = ((HPRLP_DBG_MODE & 4) && !CHECK) ? static_cast<double>(col[q]) : V[static_cast<size_t>(col[q]) * Bp];
             }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
