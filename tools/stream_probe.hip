@@ -44,6 +44,48 @@ __global__ void __launch_bounds__(256) k_mix(Ptrs p, size_t n2, double *sink) {
     if (W == 0 && acc == 12345.678) *sink = acc;
 }
 
+// the persistent-workgroup pattern of the tiled kernels: every workgroup streams its OWN contiguous range of each array
+// (512 lanes x 16 B = 8 KB per array per trip), so the chip reads gridDim.x * (R + W) scattered streams at once
+template <int R, int W>
+__global__ void __launch_bounds__(512) k_private(Ptrs p, size_t n2, double *sink) {
+    const size_t per = (n2 + gridDim.x - 1) / gridDim.x;
+    const size_t b = blockIdx.x * per, e = b + per < n2 ? b + per : n2;
+    double acc = 0.0;
+    for (size_t i = b + threadIdx.x; i < e; i += 512) {
+        dbl2 v[R > 0 ? R : 1];
+#pragma unroll
+        for (int a = 0; a < R; ++a) v[a] = __builtin_nontemporal_load(p.r[a] + i);
+        dbl2 s = {0.0, 1.0};
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+            s.x += v[a].x;
+            s.y += v[a].y;
+        }
+        if (W == 0) acc += s.x + s.y;
+#pragma unroll
+        for (int a = 0; a < W; ++a) __builtin_nontemporal_store(s, p.w[a] + i);
+    }
+    if (W == 0 && acc == 12345.678) *sink = acc;
+}
+
+template <int R, int W>
+void run_private(const char *name, Ptrs p, size_t n2, double *sink, int grid) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_private<R, W>), dim3(grid), dim3(512), 0, 0, p, n2, sink);
+    const int reps = 20;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_private<R, W>), dim3(grid), dim3(512), 0, 0, p, n2, sink);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = static_cast<double>(n2) * 16.0 * (R + W);
+    std::printf("%-10s private ranges, %4d workgroups of 512  %8.1f us  %7.0f GB/s\n", name, grid, ms / reps * 1e3,
+                bytes / (ms / reps * 1e-3) / 1e9);
+}
+
 template <int R, int W>
 void run(const char *name, Ptrs p, size_t n2, double *sink, int grid) {
     hipEvent_t e0, e1;
@@ -84,6 +126,12 @@ int main(int argc, char **argv) {
         run<5, 2>("5r2w", p, n2, sink, grid);
         run<4, 1>("4r1w", p, n2, sink, grid);
         run<0, 2>("2w", p, n2, sink, grid);
+    }
+    for (int grid : {512, 1024}) {
+        run_private<1, 0>("1r", p, n2, sink, grid);
+        run_private<2, 0>("2r", p, n2, sink, grid);
+        run_private<4, 0>("4r", p, n2, sink, grid);
+        run_private<5, 2>("5r2w", p, n2, sink, grid);
     }
     return 0;
 }
