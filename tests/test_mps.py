@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, hprlp
+from conftest import ROOT, hprlp, lpgen
 
 DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 INF = np.inf
@@ -98,3 +98,108 @@ def test_cli_driver_solves_on_gpu(gpu):
     r = subprocess.run([exe, "-i", os.path.join(DATA, "lp_small.mps"), "--tol", "1e-8"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "status = OPTIMAL" in r.stdout and "primal_obj = -26.4" in r.stdout
+
+
+def write_mps(path, lp, two_per_card=True, use_ranges=True):
+    """A plain MPS writer for the round-trip tests (test code: the product only reads).  Rows: E when AL == AU, L / G for
+    one-sided rows, two-sided rows as L + RANGES (or G + RANGES for every other one); bounds through UP / LO / MI / FX / FR."""
+    from scipy import sparse
+    m, n = lp["m"], lp["n"]
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n)).tocsc()
+    AL, AU, l, u, c = lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"]
+    fin_l, fin_u = np.isfinite(AL), np.isfinite(AU)
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "wt") as f:
+        f.write("NAME          ROUNDTRIP\nROWS\n N  COST\n")
+        kind = []
+        for i in range(m):
+            if fin_l[i] and fin_u[i]:
+                k = "E" if AL[i] == AU[i] else ("L" if i % 2 == 0 else "G")
+            elif fin_u[i]:
+                k = "L"
+            elif fin_l[i]:
+                k = "G"
+            else:
+                k = "N"  # a free row: written as a rim N row, dropped by the reader
+            kind.append(k)
+            f.write(f" {k}  R{i}\n")
+        f.write("COLUMNS\n")
+        for j in range(n):
+            ent = []
+            if c[j] != 0.0:
+                ent.append(("COST", c[j]))
+            for p in range(A.indptr[j], A.indptr[j + 1]):
+                ent.append((f"R{A.indices[p]}", A.data[p]))
+            step = 2 if two_per_card else 1
+            for q in range(0, len(ent), step):
+                f.write(f"    C{j}  " + "  ".join(f"{r}  {repr(float(v))}" for r, v in ent[q:q + step]) + "\n")
+        f.write("RHS\n")
+        for i in range(m):
+            rhs = AU[i] if kind[i] in "EL" else (AL[i] if kind[i] == "G" else 0.0)
+            if kind[i] != "N" and rhs != 0.0:
+                f.write(f"    RHS  R{i}  {repr(float(rhs))}\n")
+        if use_ranges:
+            f.write("RANGES\n")
+            for i in range(m):
+                if kind[i] in "LG" and fin_l[i] and fin_u[i]:
+                    f.write(f"    RNG  R{i}  {repr(float(AU[i] - AL[i]))}\n")
+        f.write("BOUNDS\n")
+        for j in range(n):
+            lo, hi = l[j], u[j]
+            if lo == hi:
+                f.write(f" FX BND  C{j}  {repr(float(lo))}\n")
+                continue
+            if lo == -INF and hi == INF:
+                f.write(f" FR BND  C{j}\n")
+                continue
+            if lo == -INF:
+                f.write(f" MI BND  C{j}\n")
+            elif lo != 0.0:
+                f.write(f" LO BND  C{j}  {repr(float(lo))}\n")
+            if hi != INF:
+                f.write(f" UP BND  C{j}  {repr(float(hi))}\n")
+        f.write("ENDATA\n")
+    return kind
+
+
+@pytest.mark.parametrize("which,gz", [("c2", False), ("c3", True)])
+def test_round_trip_at_benchmark_size(tmp_path, which, gz):
+    """BASELINE configs 2 and 3 (Netlib 25fv47 / pds-20 scale stand-ins) written as MPS text and read back through
+    create_model_from_mps: every array of the model must come back exactly (values are written with repr, i.e. round-trip
+    exact decimal strings; two-sided rows go through RANGES, whose AU - AL arithmetic is allowed one rounding)."""
+    lp = lpgen.c2_25fv47_like() if which == "c2" else lpgen.c3_pds20_like()
+    lp = dict(lp)
+    rng = np.random.default_rng(7)
+    n, m = lp["n"], lp["m"]
+    # richer bounds than the generator's: some free, some lower-unbounded, some fixed variables; some two-sided rows
+    l, u = lp["l"].copy(), lp["u"].copy()
+    pick = rng.random(n)
+    l[pick < 0.02] = -INF
+    u[(pick >= 0.02) & (pick < 0.03)] = l[(pick >= 0.02) & (pick < 0.03)]
+    free = (pick >= 0.03) & (pick < 0.04)
+    l[free], u[free] = -INF, INF
+    neg_up = (pick >= 0.04) & (pick < 0.045) & np.isfinite(u) & (l == 0)
+    lp["l"], lp["u"] = l, u
+    AL, AU = lp["AL"].copy(), lp["AU"].copy()
+    two = np.isfinite(AU) & ~np.isfinite(AL) & (rng.random(m) < 0.2)
+    AL[two] = AU[two] - rng.uniform(0.5, 2.0, size=int(two.sum()))
+    lp["AL"], lp["AU"] = AL, AU
+    del neg_up
+    path = tmp_path / (f"{which}.mps.gz" if gz else f"{which}.mps")
+    kind = write_mps(path, lp, two_per_card=(which == "c2"))
+    mod = hprlp.Model.from_mps(path)
+    keep = np.array([k != "N" for k in kind])
+    assert (mod.m, mod.n) == (int(keep.sum()), n)
+    from scipy import sparse
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))[keep]
+    A.sort_indices()
+    rp, ci, v = mod.csr()
+    assert np.array_equal(rp, A.indptr) and np.array_equal(ci, A.indices) and np.array_equal(v, A.data)
+    vec = mod.vectors()
+    assert np.array_equal(vec["c"], lp["c"]) and np.array_equal(vec["l"], lp["l"]) and np.array_equal(vec["u"], lp["u"])
+    ALk, AUk, kk = lp["AL"][keep], lp["AU"][keep], np.array(kind)[keep]
+    ranged = np.isfinite(ALk) & np.isfinite(AUk) & (kk != "E")
+    for got, want in ((vec["AL"], ALk), (vec["AU"], AUk)):
+        assert np.array_equal(got[~ranged], want[~ranged])
+        np.testing.assert_allclose(got[ranged], want[ranged], rtol=4e-16, atol=1e-15)
+    mod.free()
