@@ -271,6 +271,18 @@ def side_configs():
     return out
 
 
+def xhalf_kernel_label(tiled):
+    """Name of what avg_launch_ms covers on one GPU (rocprofv3 kernel names in profiles/)."""
+    if not tiled & 2:
+        return "k_spmv_fused<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern)"
+    if os.environ.get("HPRLP_NO_FAR_PUSH", "0") == "1":
+        return ("k_far_products + k_tiled_fused<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern; avg_launch_ms = remainder "
+                "pre-pass + fused kernel, the two launches of the half-step)")
+    return ("k_tiled_fused<XEpi<false>, REP, PUSH=true> (x-half: SpMV(A^T,y) + prox + Halpern in ONE launch; the products of its "
+            "far-column remainder were written by the preceding y-half's epilogue and its own epilogue writes the y-half's "
+            "(hand-off, DESIGN.md section 4); shard-shaped matrices: k_tiled_part + k_tiled_finish)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,8 +421,7 @@ def main():
                            "rank0_entries_received_per_iteration": (dinfo["m_received"] if dinfo["m_sparse"] else m - m // P)
                                                                    + (dinfo["n_received"] if dinfo["n_sparse"] else n - n // P)},
                        "bytes_per_iteration_algorithmic": bytes_per_iteration(m, n, nnz)},
-            "roofline": {"bound": "hbm", "kernel": (("k_far_products + k_tiled_fused" if tiled & 2 else "k_spmv_fused") + "<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern"
-                                                     + ("; avg_launch_ms = remainder pre-pass + fused kernel, the two launches of the half-step)" if tiled & 2 else ")"))
+            "roofline": {"bound": "hbm", "kernel": xhalf_kernel_label(tiled)
                          if P == 1 else "x-half window of one rank: local-column SpMV beside the exchange of y, then the remote-column fused kernel "
                                         "(k_spmv_fused<WithBase<XEpi<false>>>); avg_launch_ms is that window, exchange wait included",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
