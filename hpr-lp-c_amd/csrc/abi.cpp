@@ -168,7 +168,8 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
     std::cout << "Presolve reduced problem: (" << model->m << ", " << model->n << ") -> (" << pre.reduced()->m << ", "
               << pre.reduced()->n << ")  [fixed cols " << st.fixed_cols << ", empty cols " << st.empty_cols
               << ", dual-fixed cols " << st.dual_fixed_cols << ", slack cols " << st.slack_cols << ", parallel rows " << st.parallel_rows << ", parallel cols " << st.parallel_cols << ", forcing rows " << st.forcing_rows << ", singleton rows " << st.singleton_rows << ", empty rows " << st.empty_rows << ", redundant rows "
-              << st.redundant_rows << "]" << std::endl;
+              << st.redundant_rows << ", doubleton rows " << st.doubleton_rows << ", tightened bounds " << st.tightened_bounds << "; " << st.rounds
+              << " rounds]" << std::endl;
     // The stopping test is relative to 1 + |b| and 1 + |c| of the model it runs on, and slack substitution moves cost
     // between columns (|c| of the reduced model can be several times the original's): the same absolute residuals would
     // then pass on the reduced model and fail the original-model check below.  Hand the reduced solve the tolerance
@@ -247,7 +248,7 @@ extern "C" int hprlp_presolve_stats(const hprlp_presolve *h, int out[16]) {
     out[0] = h->p.reduced()->m; out[1] = h->p.reduced()->n; out[2] = s.fixed_cols; out[3] = s.empty_cols;
     out[4] = s.singleton_rows; out[5] = s.empty_rows; out[6] = s.redundant_rows; out[7] = s.passes;
     out[8] = s.dual_fixed_cols; out[9] = s.slack_cols; out[10] = s.parallel_rows; out[11] = s.parallel_cols;
-    out[12] = s.forcing_rows; out[13] = out[14] = out[15] = 0;
+    out[12] = s.forcing_rows; out[13] = s.doubleton_rows; out[14] = s.tightened_bounds; out[15] = s.rounds;
     return 0;
 }
 extern "C" int hprlp_presolve_postsolve(const hprlp_presolve *h, const double *xr, const double *yr, const double *zr,

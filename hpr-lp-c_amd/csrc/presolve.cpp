@@ -32,7 +32,7 @@ inline unsigned long long pattern_hash(int idx) {
 
 }  // namespace
 
-Presolve::~Presolve() {
+ReduceStage::~ReduceStage() {
     if (reduced_) free_model(reduced_);
 }
 
@@ -41,7 +41,7 @@ Presolve::~Presolve() {
 // singleton and redundant rows).  Less than 0.1 % of the rows + columns: not worth a reduced copy of the model.
 constexpr long kScanFirstNnz = 10000000;
 
-bool Presolve::worth_it(const LP_info_cpu *model) const {
+bool ReduceStage::worth_it(const LP_info_cpu *model) const {
     const int m = model->m, n = model->n;
     const int *rp = model->A->rowPtr, *ci = model->A->colIndex;
     const double *av = model->A->value, *l = model->l, *u = model->u, *AL = model->AL, *AU = model->AU;
@@ -88,7 +88,7 @@ bool Presolve::worth_it(const LP_info_cpu *model) const {
     return static_cast<double>(hit) >= 1e-3 * (static_cast<double>(m) + static_cast<double>(n));
 }
 
-bool Presolve::run(const LP_info_cpu *model) {
+bool ReduceStage::run(const LP_info_cpu *model) {
     const auto t0 = std::chrono::steady_clock::now();
     if (!model || !model->A || model->m <= 0 || model->n <= 0) return false;
     org_ = model;
@@ -523,7 +523,7 @@ bool Presolve::run(const LP_info_cpu *model) {
     return reduced_ != nullptr;
 }
 
-void Presolve::postsolve(const double *xr, const double *yr, const double *zr, double *x, double *y, double *z) const {
+void ReduceStage::postsolve(const double *xr, const double *yr, const double *zr, double *x, double *y, double *z) const {
     std::fill(x, x + n_, 0.0);
     std::fill(y, y + m_, 0.0);
     std::fill(z, z + n_, 0.0);

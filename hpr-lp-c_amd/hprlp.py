@@ -269,7 +269,7 @@ class Presolved:
         self.reduced = Model(lib().hprlp_presolve_reduced(self.h))
         out = (C.c_int * 16)()
         lib().hprlp_presolve_stats(self.h, out)
-        keys = ("m", "n", "fixed_cols", "empty_cols", "singleton_rows", "empty_rows", "redundant_rows", "passes", "dual_fixed_cols", "slack_cols", "parallel_rows", "parallel_cols", "forcing_rows")
+        keys = ("m", "n", "fixed_cols", "empty_cols", "singleton_rows", "empty_rows", "redundant_rows", "passes", "dual_fixed_cols", "slack_cols", "parallel_rows", "parallel_cols", "forcing_rows", "doubleton_rows", "tightened_bounds", "rounds")
         self.stats = dict(zip(keys, [int(v) for v in out]))
 
     def postsolve(self, xr, yr, zr):

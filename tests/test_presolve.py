@@ -371,6 +371,114 @@ def test_randomised_sweep_of_all_reductions():
     assert all(v > 0 for v in seen.values()), seen
 
 
+def doubleton_lp(seed, m0=50, n0=80, pairs=10, free_share=0.0):
+    """A planted LP plus `pairs` equality rows a x_j + b x_k = a xs_j + b xs_k over columns that also sit in other rows
+    (some chained: the kept column of one pair is a member of the next); with free_share > 0 some columns lose their
+    finite bounds, so that rows imply them."""
+    rng = np.random.default_rng(seed)
+    base = lpgen.planted_lp(m0, n0, 6 * m0, seed)
+    A = sparse.csr_matrix((base["values"], base["colind"], base["rowptr"]), shape=(m0, n0)).tolil()
+    AL, AU = list(base["AL"]), list(base["AU"])
+    l, u, c = base["l"].copy(), base["u"].copy(), base["c"].copy()
+    xs = base["x_star"]
+    # columns strictly inside their box at the planted optimum first (a pair of columns on their bounds is a forcing row)
+    inside = np.flatnonzero((xs > l + 1e-3) & (xs < u - 1e-3))
+    others = np.setdiff1d(np.arange(n0), inside)
+    cols = np.concatenate([rng.permutation(inside), rng.permutation(others)])[:pairs + 1]
+    rows = [A]
+    for q in range(pairs):
+        j, k = int(cols[q]), int(cols[q + 1])  # chained: k of this pair is j of the next
+        a, b = rng.choice([1.0, -2.0, 0.5, 3.0]), rng.choice([1.0, -1.0, 4.0, -0.25])
+        r = sparse.lil_matrix((1, n0))
+        r[0, j], r[0, k] = a, b
+        rows.append(r)
+        rhs = a * xs[j] + b * xs[k]
+        AL.append(rhs); AU.append(rhs)
+    if free_share > 0:
+        pick = rng.random(n0) < free_share
+        u[pick & (xs < u)] = INF          # planted value is not on that bound: the optimum stays an optimum
+        l[pick & (xs > l) & (rng.random(n0) < 0.5)] = -INF
+    A2 = sparse.vstack(rows).tocsr()
+    A2.sort_indices()
+    return dict(m=A2.shape[0], n=n0, rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), values=A2.data.copy(),
+                AL=np.array(AL), AU=np.array(AU), l=l, u=u, c=c)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34, 35, 36])
+def test_doubleton_equations(seed):
+    """Doubleton equality rows are substituted out (the matrix entries change: PSLP DtonsEq): the reduced model keeps the
+    optimum, and the postsolved triple -- x_j from the row, the row's multiplier from the reduced costs -- satisfies the
+    KKT conditions of the original model."""
+    lp = doubleton_lp(seed)
+    f0, x0, y0, z0 = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    model = make_model(lp)
+    pre = hprlp.Presolved(model)
+    # (a pair whose column another reduction fixed first is gone as a singleton row instead)
+    assert pre.stats["doubleton_rows"] >= 8, pre.stats
+    assert pre.reduced.m <= lp["m"] - 8 and pre.reduced.n <= lp["n"] - 8
+    rm, rn, rp, ci, v, AL, AU, l, u, c = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp, ci, v, AL, AU, l, u, c)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-8 * (1 + abs(f0))
+    x, y, z = pre.postsolve(xr, yr, zr)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-8, (k, pre.stats)
+    assert abs(k["primal_obj"] - f0) <= 1e-8 * (1 + abs(f0))
+    pre.free(); model.free()
+
+
+def test_doubleton_bound_transfer_moves_the_multiplier():
+    """min x0 + x1  s.t.  x0 - 2 x1 = 0 (doubleton),  x0 + x1 + x2 >= 1,  0 <= x0 <= 0.3,  0 <= x1 <= 10,  0 <= x2 <= 10, cost
+    of x2 = 5.  x0 = 2 x1 and x0 <= 0.3 cap x1 at 0.15: optimum x = (0.3, 0.15, 0.55).  Whichever column is substituted, the
+    bound that stops the pair is x0's: after postsolve x0 carries the reduced cost and x1 none."""
+    rp = np.array([0, 2, 5], np.int32); ci = np.array([0, 1, 0, 1, 2], np.int32); v = np.array([1.0, -2.0, 1.0, 1.0, 1.0])
+    AL, AU = np.array([0.0, 1.0]), np.array([0.0, INF])
+    l, u, c = np.zeros(3), np.array([0.3, 10.0, 10.0]), np.array([1.0, 1.0, 5.0])
+    f0, x0, y0, z0 = highs(2, 3, rp, ci, v, AL, AU, l, u, c)
+    np.testing.assert_allclose(x0, [0.3, 0.15, 0.55], atol=1e-12)
+    model = hprlp.Model.from_csr(2, 3, rp, ci, v, AL, AU, l, u, c)
+    pre = hprlp.Presolved(model)
+    assert pre.stats["doubleton_rows"] == 1
+    rm, rn, rp2, ci2, v2, rAL, rAU, rl, ru, rc = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp2, ci2, v2, rAL, rAU, rl, ru, rc)
+    x, y, z = pre.postsolve(xr, yr, zr)
+    np.testing.assert_allclose(x, x0, atol=1e-12)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-10, k
+    assert z[1] == 0.0 and z[0] < 0.0   # x0 sits on its upper bound, x1 is strictly inside its box
+    np.testing.assert_allclose(z, c - sparse.csr_matrix((v, ci, rp), shape=(2, 3)).T @ y, atol=1e-12)
+    pre.free(); model.free()
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43, 44])
+def test_bound_propagation_feeds_the_reductions(seed):
+    """Columns without finite bounds get the bounds their rows imply (PSLP Primal_propagation, infinite bounds only); the box is
+    kept only when the next round removes something with it.  Optimum and original KKT as everywhere."""
+    lp = doubleton_lp(seed, pairs=4, free_share=0.5)
+    try:
+        f0, x0, y0, z0 = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    except AssertionError:
+        pytest.skip("unbounded after freeing columns")
+    model = make_model(lp)
+    pre = hprlp.Presolved(model)
+    rm, rn, rp, ci, v, AL, AU, l, u, c = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp, ci, v, AL, AU, l, u, c)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-7 * (1 + abs(f0))
+    x, y, z = pre.postsolve(xr, yr, zr)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-7, (k, pre.stats)
+    pre.free(); model.free()
+
+
+def test_bound_propagation_alone_is_not_a_reduction():
+    """x0 + 2 x1 <= 10, 3 x0 + x1 <= 12, x >= 0 without upper bounds: the rows imply them, nothing can be removed with them,
+    and the caller keeps its own model (Presolve::run: the bound stage is dropped)."""
+    rp = np.array([0, 2, 4], np.int32); ci = np.array([0, 1, 0, 1], np.int32); v = np.array([1.0, 2.0, 3.0, 1.0])
+    model = hprlp.Model.from_csr(2, 2, rp, ci, v, [-INF, -INF], [10.0, 12.0], [0.0, 0.0], [INF, INF], [-3.0, -5.0])
+    with pytest.raises(RuntimeError):
+        hprlp.Presolved(model)
+    model.free()
+
+
 def test_free_singleton_column_with_a_cost():
     """min 0.5 f + x1 + 2 x2  s.t.  f + x1 + x2 >= 2 (row 0),  1 <= x1 + 3 x2 <= 4 (row 1),  0 <= x1, x2 <= 5,  f free.
     f appears in row 0 only and is free, so z_f = 0 forces y_0 = 0.5 > 0: row 0 is active at 2 in every optimum and f is
@@ -512,4 +620,23 @@ def test_gpu_solve_of_decorated_lps_with_presolve(gpu, seed):
     k = hprlp.original_kkt(model, r.x, r.y, r.z)
     assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-5, k
     assert len(r.x) == lp["n"] and len(r.y) == lp["m"]
+    model.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,free_share", [(31, 0.0), (33, 0.0), (42, 0.5), (44, 0.5)])
+def test_gpu_solve_with_doubletons_and_implied_bounds(gpu, seed, free_share):
+    """solve() through the whole chain (reductions, doubleton substitution, bound propagation) on the GPU: an approximate
+    solution of the reduced model, postsolved, has the exact optimum and passes the original-model KKT evaluation."""
+    lp = doubleton_lp(seed, m0=200, n0=320, pairs=30, free_share=free_share)
+    try:
+        f0, *_ = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    except AssertionError:
+        pytest.skip("unbounded after freeing columns")
+    model = make_model(lp)
+    r = model.solve(hprlp.Parameters(stop_tol=1e-7, use_presolve=True, max_iter=400000))
+    assert r.status == "OPTIMAL"
+    assert abs(r.primal_obj - f0) <= 1e-5 * (1 + abs(f0))
+    k = hprlp.original_kkt(model, r.x, r.y, r.z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-5, k
     model.free()
