@@ -388,12 +388,18 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
 
 // Gather vector too long for the L2s (>= 4 M entries = 32 MB) and the tiled build declined for lack of dense tiles: the
 // stream kernel would pay a fabric line per gathered element (HPRLP_NO_PB_FALLBACK=1 keeps it anyway; one GPU only).
+// gathered vector from which the all-remainder tiled form beats the stream kernel on a pattern without locality (measured,
+// tools/unstructured_ab.py, uniformly random 10 per row: 1M columns 0.154 vs 0.125 ms per half-step, 2M 0.218 vs 0.318, 3M 0.316
+// vs 0.508, 4.2M 0.46 vs 0.75, 6M 0.59 vs 1.13)
+constexpr long kPbMinCols = 1500000;
+
 bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
     const char *no = std::getenv("HPRLP_NO_PB_FALLBACK");
     if (no && no[0] == '1') return false;
     const char *nt = std::getenv("HPRLP_NO_TILED");
     if (nt && nt[0] == '1') return false;
-    return !comm && !M.view.tiled.valid && M.declined_sparse && M.view.cols >= (1 << 22) && M.view.nnz >= 4000000;
+    static const long min_cols = std::getenv("HPRLP_PB_MIN_COLS") ? std::atol(std::getenv("HPRLP_PB_MIN_COLS")) : kPbMinCols;
+    return !comm && !M.view.tiled.valid && M.declined_sparse && M.view.cols >= min_cols && M.view.nnz >= 4000000;
 }
 
 // Large matrix whose given order failed the tiling test: look for a locality ordering (reorder.cpp).  On entry A (device
