@@ -17,7 +17,7 @@ namespace hprlp {
 namespace {
 
 constexpr double kFeasTol = 1e-9;        // as in presolve.cpp: a crossing of bounds beyond this (relative) is left to the solver
-constexpr double kMaxPivotRatio = 1e3;   // |a_k / a_j| of a doubleton must lie in [1/ratio, ratio] (PSLP: MAX_RATIO_PIVOT)
+constexpr double kMaxPivotRatio = 10.0;  // |a_k / a_j| of a doubleton: the factor a substitution multiplies with (PSLP allows 1e3)
 constexpr int kMaxSubstColumn = 256;     // longest column that is substituted (fill-in and postsolve storage stay small)
 constexpr double kCancel = 1e-12;        // a merged coefficient this small relative to its parts counts as cancelled
 constexpr double kBoundMargin = 1e-6;    // an implied bound is loosened by this (relative to 1 + |bound|): it stays redundant
@@ -97,13 +97,17 @@ bool DoubletonStage::run(const LP_info_cpu *model) {
         if (!row_alive[i] || R[i].size() != 2 || !(fin(AL[i]) && AL[i] == AU[i])) continue;
         const Entry e0 = R[i][0], e1 = R[i][1];
         if (!col_alive[e0.first] || !col_alive[e1.first]) continue;
-        // substitute the shorter column (less fill-in), the kept one takes its entries
-        const bool subst0 = col_cnt[e0.first] <= col_cnt[e1.first];
+        // Substitute the shorter column (less fill-in) unless its coefficient is the small one of the two: x_j = (b - a_k x_k) / a_j
+        // multiplies everything it touches by a_k / a_j, and chains of doubletons multiply those factors (three links at 500
+        // each left a reduced model that was infeasible at 1e-7) -- so |a_k / a_j| stays below kMaxPivotRatio, by taking the
+        // other column if need be.
+        bool subst0 = col_cnt[e0.first] <= col_cnt[e1.first];
+        auto ratio_of = [&](bool s0) { return s0 ? std::abs(e1.second / e0.second) : std::abs(e0.second / e1.second); };
+        auto len_of = [&](bool s0) { return col_cnt[s0 ? e0.first : e1.first]; };
+        if (!(ratio_of(subst0) <= kMaxPivotRatio) || len_of(subst0) > kMaxSubstColumn) subst0 = !subst0;
+        if (!(ratio_of(subst0) <= kMaxPivotRatio) || len_of(subst0) > kMaxSubstColumn) continue;
         const int j = subst0 ? e0.first : e1.first, k = subst0 ? e1.first : e0.first;
         const double aj = subst0 ? e0.second : e1.second, ak = subst0 ? e1.second : e0.second;
-        const double ratio = std::abs(ak / aj);
-        if (!(ratio <= kMaxPivotRatio && ratio >= 1.0 / kMaxPivotRatio)) continue;
-        if (col_cnt[j] > kMaxSubstColumn) continue;
         const double b = AL[i];
         // bounds of x_j as bounds of x_k:  a_k x_k = b - a_j x_j  in  [b - max(a_j l_j, a_j u_j), b - min(...)]
         const double t1 = aj * l[j], t2 = aj * u[j];
@@ -354,6 +358,26 @@ bool Presolve::run(const LP_info_cpu *model) {
     const char *off_env = std::getenv("HPRLP_PRESOLVE_OFF");
     const std::string off = off_env ? off_env : "";
     const bool use_dton = off.find("doubleton") == std::string::npos, use_bounds = off.find("bounds") == std::string::npos;
+    // HPRLP_PRESOLVE_ONLY=doubleton|bounds: that stage alone on the model as given (unit tests of the stages)
+    if (const char *only = std::getenv("HPRLP_PRESOLVE_ONLY")) {
+        const std::string which = only;
+        if (which == "doubleton") {
+            auto st = std::make_unique<DoubletonStage>();
+            if (!st->run(model)) return false;
+            stats_.doubleton_rows = st->eliminated();
+            reduced_ = st->reduced();
+            chain_.push_back(std::move(st));
+            return true;
+        }
+        if (which == "bounds") {
+            auto st = std::make_unique<BoundStage>();
+            if (!st->run(model)) return false;
+            stats_.tightened_bounds = st->tightened();
+            reduced_ = st->reduced();
+            chain_.push_back(std::move(st));
+            return true;
+        }
+    }
     const LP_info_cpu *cur = model;
     auto add = [&](const PresolveStats &s) {
         stats_.fixed_cols += s.fixed_cols; stats_.empty_cols += s.empty_cols; stats_.empty_rows += s.empty_rows;
@@ -365,7 +389,8 @@ bool Presolve::run(const LP_info_cpu *model) {
     // it (PSLP likewise drops the implied bounds that stayed redundant at the end, Primal_propagation.c:786).
     bool bounds_done = false, pending = false;
     const LP_info_cpu *before_bounds = nullptr;
-    for (int round = 0; round < kMaxRounds && !solved_; ++round) {
+    const int max_links = std::getenv("HPRLP_PRESOLVE_MAX_LINKS") ? std::atoi(std::getenv("HPRLP_PRESOLVE_MAX_LINKS")) : 1 << 20;  // (debugging)
+    for (int round = 0; round < kMaxRounds && !solved_ && static_cast<int>(chain_.size()) < max_links; ++round) {
         bool progress = false;
         ++stats_.rounds;
         {
@@ -383,7 +408,7 @@ bool Presolve::run(const LP_info_cpu *model) {
                 break;
             }
         }
-        if (use_dton) {
+        if (use_dton && static_cast<int>(chain_.size()) < max_links) {
             auto st = std::make_unique<DoubletonStage>();
             if (st->run(cur)) {
                 stats_.doubleton_rows += st->eliminated();

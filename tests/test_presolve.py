@@ -27,7 +27,11 @@ def highs(m, n, rp, ci, v, AL, AU, l, u, c):
     A_eq = A[eq] if eq.any() else None
     b_eq = AL[eq] if eq.any() else None
     bounds = [(None if not np.isfinite(a) else a, None if not np.isfinite(b) else b) for a, b in zip(l, u)]
-    r = linprog(c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=bounds, method="highs")
+    # (HiGHS' own presolve off and tight tolerances: with the defaults it calls a few of the reduced models of the sweeps
+    # infeasible or "unknown" that it solves to optimality without its presolve, and its 1e-7 feasibility tolerance shows
+    # up as 1e-5 differences in the optimum of degenerate LPs)
+    r = linprog(c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=bounds, method="highs",
+                options=dict(presolve=False, primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10))
     assert r.status == 0, r.message
     y = np.zeros(m)
     if A_ub is not None:
@@ -477,6 +481,46 @@ def test_bound_propagation_alone_is_not_a_reduction():
     with pytest.raises(RuntimeError):
         hprlp.Presolved(model)
     model.free()
+
+
+def test_randomised_sweep_of_the_chain():
+    """90 LPs of three families (decorated, structured with freed columns, doubleton chains with freed columns) through the
+    whole chain -- reductions, doubleton substitution, bound propagation, several rounds: optimum kept and original-model KKT
+    of the postsolved exact solution at 1e-8."""
+    def gen(seed):
+        kind = seed % 3
+        if kind == 0:
+            return decorated_lp(seed)
+        if kind == 1:
+            lp = structured_lp(seed, m0=40 + seed % 50, n0=60 + seed % 70)
+            pick = np.random.default_rng(seed).random(lp["n"]) < 0.3
+            lp["u"] = np.where(pick & (lp["l"] < lp["u"]), np.inf, lp["u"])
+            return lp
+        return doubleton_lp(seed, m0=30 + seed % 40, n0=50 + seed % 60, pairs=3 + seed % 9, free_share=[0.0, 0.3, 0.6][(seed // 3) % 3])
+    ran = dt = tb = 0
+    for seed in range(200, 290):
+        lp = gen(seed)
+        try:
+            f0, *_ = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        except AssertionError:
+            continue
+        model = make_model(lp)
+        try:
+            pre = hprlp.Presolved(model)
+        except RuntimeError:
+            model.free()
+            continue
+        ran += 1
+        dt += pre.stats["doubleton_rows"]
+        tb += pre.stats["tightened_bounds"]
+        rm, rn, rp, ci, v, AL, AU, l, u, c = reduced_arrays(pre)
+        fr, xr, yr, zr = highs(rm, rn, rp, ci, v, AL, AU, l, u, c)
+        assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-8 * (1 + abs(f0)), (seed, pre.stats)
+        x, y, z = pre.postsolve(xr, yr, zr)
+        k = hprlp.original_kkt(model, x, y, z)
+        assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-8, (seed, k, pre.stats)
+        pre.free(); model.free()
+    assert ran >= 60 and dt >= 100 and tb >= 300, (ran, dt, tb)
 
 
 def test_free_singleton_column_with_a_cost():
