@@ -229,6 +229,10 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 // ED / TD: how many steps ahead the entry loads (HBM) and the tile loads (L2) are issued.  Full chip (two workgroups on
 // every CU): <2, 1> -- deeper gains nothing there, the fabric is busy (profiles/r02_pmc_summary.md).  Few workgroups
 // (the split form): a step cannot be shorter than the HBM latency / ED, so <3, 2>.
+#ifndef HPRLP_DBG_HALF_TILES
+#define HPRLP_DBG_HALF_TILES 0
+#endif
+
 template <int ED, int TD, bool REP, bool STAMP = false>
 __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, int first, int count, const double *__restrict__ vec,
                                             int ncols, double *acc, double *ytile, int tid, unsigned long long *stamp = nullptr) {
@@ -266,11 +270,36 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
         E.i1 = w.y;
         E.i2 = w.z;
     };
+    // tile loads and LDS stores in pairs (one 16-byte access per lane instead of two 8-byte ones: the vector-memory issue
+    // of a step is what stalls when two workgroups share a CU, profiles/r02_pmc_summary.md).  Lane pair index p covers
+    // columns col0 + 2 p, col0 + 2 p + 1; behind the end of the vector the last valid pair is read (never referenced), and
+    // the lane that holds the last column of an odd-length vector takes it from the pair's second half.
+    typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
     auto issue_tile = [&](double (&tl)[TPT], int k) {
         int col0, eb, ee_;
         getstep(k, col0, eb, ee_);
+        static_assert(TPT % 2 == 0, "tile loads come in pairs");
 #pragma unroll
-        for (int j = 0; j < TPT; ++j) tl[j] = vec[min(col0 + tid + j * NT, ncols - 1)];
+        for (int j = 0; j < TPT / 2; ++j) {
+            const int p = col0 + 2 * (tid + j * NT);
+            const int q = min(p, ncols - 2);
+            d2u_t v = *reinterpret_cast<const d2u_t *>(vec + q);
+            if (q != p) v.x = v.y;
+            tl[2 * j] = v.x;
+            tl[2 * j + 1] = v.y;
+#if HPRLP_DBG_HALF_TILES
+            if (k & 1) break;  // timing experiment only: half of the tile traffic (results are wrong)
+#endif
+        }
+    };
+    auto store_tile = [&](const double (&tl)[TPT]) {
+#pragma unroll
+        for (int j = 0; j < TPT / 2; ++j) {
+            d2_t v;
+            v.x = tl[2 * j];
+            v.y = tl[2 * j + 1];
+            reinterpret_cast<d2_t *>(ytile)[tid + j * NT] = v;
+        }
     };
     auto process = [&](const Ent &E, int k) {
         int col0, eb, ee_;
@@ -315,8 +344,7 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
         lds_barrier();  // every lane is done with the previous step (tile and accumulators)
         if (STAMP) tq[1] = __builtin_amdgcn_s_memtime();
         if (STAMP) {
-#pragma unroll
-            for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+            store_tile(tl);
             tq[2] = __builtin_amdgcn_s_memtime();  // tile data arrived and written
             issue_tile(tl, k + TD);
             tq[3] = __builtin_amdgcn_s_memtime();
@@ -339,14 +367,12 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
         if (REP) {
             const bool keep = same_tile(k);  // uniform
             if (!keep) {
-#pragma unroll
-                for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+                store_tile(tl);
             }
             if (!same_tile(k + TD)) issue_tile(tl, k + TD);
             if (!keep) lds_barrier();  // tile visible
         } else {
-#pragma unroll
-            for (int j = 0; j < TPT; ++j) ytile[tid + j * NT] = tl[j];
+            store_tile(tl);
             issue_tile(tl, k + TD);
             lds_barrier();  // tile visible
         }
@@ -466,7 +492,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
     constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols;
     constexpr int NACC = Epi::NACC;
     __shared__ double acc[R];
-    __shared__ double ytile[T];
+    __shared__ __attribute__((aligned(16))) double ytile[T];
     const TiledDev &t = A.tiled;
     const int tid = threadIdx.x;
     const int per = t.per, slots = gridDim.x / 8;  // persistent: slot, slot + slots, ... of this XCD's range
@@ -539,7 +565,7 @@ template <bool REP, bool STAMP = false>
 __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_part(CsrDev A, const double *__restrict__ vec) {
     constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols;
     __shared__ double acc[R];
-    __shared__ double ytile[T];
+    __shared__ __attribute__((aligned(16))) double ytile[T];
     const TiledDev &t = A.tiled;
     const int tid = threadIdx.x;
     // XCD-aware: a contiguous range of pieces per XCD (neighbouring pieces read the same vector tiles)
