@@ -239,8 +239,16 @@ bool ReduceStage::run(const LP_info_cpu *model) {
             const bool force_max = fin(AL[i]) && !up_inf && std::abs(up_act - AL[i]) <= rel(AL[i]);
             if (use_forcing && (force_min || force_max)) {
                 std::vector<int> live;
+                double amin = INFINITY, amax = 0.0;
                 for (int k = rp[i]; k < rp[i + 1]; ++k)
-                    if (col_alive[ci[k]] && av[k] != 0.0) live.push_back(ci[k]);
+                    if (col_alive[ci[k]] && av[k] != 0.0) {
+                        live.push_back(ci[k]);
+                        amin = std::min(amin, std::abs(av[k]));
+                        amax = std::max(amax, std::abs(av[k]));
+                    }
+                // the test above holds to a tolerance: a column whose whole range moves the activity by less than that
+                // tolerance is not pinned by the row at all -- rows with such entries are left to the solver
+                if (amin < 1e-6 * amax) continue;
                 std::sort(live.begin(), live.end());
                 if (std::adjacent_find(live.begin(), live.end()) != live.end()) continue;  // repeated column index: leave it
                 const int cnt = static_cast<int>(live.size());

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 #include <string>
@@ -20,6 +21,7 @@ constexpr double kFeasTol = 1e-9;        // as in presolve.cpp: a crossing of bo
 constexpr double kMaxPivotRatio = 10.0;  // |a_k / a_j| of a doubleton: the factor a substitution multiplies with (PSLP allows 1e3)
 constexpr int kMaxSubstColumn = 256;     // longest column that is substituted (fill-in and postsolve storage stay small)
 constexpr double kCancel = 1e-12;        // a merged coefficient this small relative to its parts counts as cancelled
+constexpr double kGray = 1e-6;           // ... and one between kCancel and this makes the substitution too ill-conditioned to do
 constexpr double kBoundMargin = 1e-6;    // an implied bound is loosened by this (relative to 1 + |bound|): it stays redundant
 constexpr double kHugeBound = 1e8;       // implied bounds beyond this are not worth having
 constexpr int kBoundSweeps = 3;
@@ -92,7 +94,8 @@ bool DoubletonStage::run(const LP_info_cpu *model) {
     std::vector<char> row_alive(static_cast<size_t>(m), 1), col_alive(static_cast<size_t>(n), 1);
     double offset = 0.0;
 
-    for (size_t h = 0; h < queue.size(); ++h) {
+    const int max_elim = std::getenv("HPRLP_DTON_MAX") ? std::atoi(std::getenv("HPRLP_DTON_MAX")) : 1 << 30;  // (debugging)
+    for (size_t h = 0; h < queue.size() && static_cast<int>(recs_.size()) < max_elim; ++h) {
         const int i = queue[h];
         if (!row_alive[i] || R[i].size() != 2 || !(fin(AL[i]) && AL[i] == AU[i])) continue;
         const Entry e0 = R[i][0], e1 = R[i][1];
@@ -116,6 +119,30 @@ bool DoubletonStage::run(const LP_info_cpu *model) {
         const double l_new = std::max(l[k], k_lo), u_new = std::min(u[k], k_up);
         if (l_new > u_new && l_new - u_new > rel(l_new)) return false;  // the two boxes contradict the row: the solver reports it
         Rec rec{i, j, k, aj, ak, b, l[k], u[k], l_new, std::max(u_new, l_new), cost[j], static_cast<int>(ents_.size()), 0};
+        if (std::getenv("HPRLP_DTON_TRACE"))
+            std::fprintf(stderr, "[dton %zu] row %d: %.17g x%d + %.17g x%d = %.17g; x%d in [%g, %g] (len %d), x%d in [%g, %g] (len %d) -> [%.17g, %.17g]\n",
+                         recs_.size() + 1, i, aj, j, ak, k, b, j, l[j], u[j], col_cnt[j], k, l[k], u[k], col_cnt[k], rec.lk_new, rec.uk_new);
+        // A merged coefficient that nearly cancels (|a_rk - (a_rj / a_j) a_k| tiny against its parts, but not rounding noise)
+        // would stay in the model as an entry of size 1e-10 whose column other reductions then take at face value (a forcing
+        // row pinned such a column to a bound 11 away from its value): leave this doubleton to the solver.
+        {
+            bool gray = false;
+            for (int r : C[j]) {
+                if (r == i || !row_alive[r]) continue;
+                const auto &row = R[r];
+                const int pj = find_col(row, j);
+                if (pj < 0) continue;
+                const int pk = find_col(row, k);
+                if (pk < 0) continue;
+                const double old = row[pk].second, delta = -(row[pj].second / aj) * ak, now = old + delta;
+                const double scale = std::max(std::abs(old), std::abs(delta));
+                if (std::abs(now) > kCancel * scale && std::abs(now) < kGray * scale) {
+                    gray = true;
+                    break;
+                }
+            }
+            if (gray) continue;
+        }
         // every other row that holds x_j:  a_rj x_j = (a_rj / a_j) (b - a_k x_k)
         for (int r : C[j]) {
             if (r == i || !row_alive[r]) continue;

@@ -31,7 +31,7 @@ def highs(m, n, rp, ci, v, AL, AU, l, u, c):
     # infeasible or "unknown" that it solves to optimality without its presolve, and its 1e-7 feasibility tolerance shows
     # up as 1e-5 differences in the optimum of degenerate LPs)
     r = linprog(c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=bounds, method="highs",
-                options=dict(presolve=False, primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10))
+                options=dict(presolve=False, primal_feasibility_tolerance=1e-9, dual_feasibility_tolerance=1e-9))
     assert r.status == 0, r.message
     y = np.zeros(m)
     if A_ub is not None:
@@ -427,6 +427,25 @@ def test_doubleton_equations(seed):
     k = hprlp.original_kkt(model, x, y, z)
     assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-8, (k, pre.stats)
     assert abs(k["primal_obj"] - f0) <= 1e-8 * (1 + abs(f0))
+    pre.free(); model.free()
+
+
+@pytest.mark.parametrize("seed,free_share", [(45, 0.5), (44, 0.5), (7, 0.3)])
+def test_doubleton_chain_at_gpu_test_size(seed, free_share):
+    """Regression: at 230 x 320 with 30 chained pairs a substitution left a merged coefficient of 1.8e-10 in an equality row; the
+    forcing-row test (a tolerance test) then pinned that column to a bound 11 away from its value and the reduced model lost
+    the optimum by 1e4.  Such near-cancelling substitutions are refused now, and forcing rows with entries below 1e-6 of their
+    largest one are left alone."""
+    lp = doubleton_lp(seed, m0=200, n0=320, pairs=30, free_share=free_share)
+    f0, *_ = highs(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    model = make_model(lp)
+    pre = hprlp.Presolved(model)
+    rm, rn, rp, ci, v, AL, AU, l, u, c = reduced_arrays(pre)
+    fr, xr, yr, zr = highs(rm, rn, rp, ci, v, AL, AU, l, u, c)
+    assert abs(fr + pre.reduced.obj_constant - f0) <= 1e-7 * (1 + abs(f0)), pre.stats
+    x, y, z = pre.postsolve(xr, yr, zr)
+    k = hprlp.original_kkt(model, x, y, z)
+    assert max(k["primal_feas"], k["dual_feas"], k["gap"]) <= 1e-7, (k, pre.stats)
     pre.free(); model.free()
 
 
