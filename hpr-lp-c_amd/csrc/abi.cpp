@@ -218,6 +218,13 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
             std::cout << "Warning: postsolve original KKT check failed (the primal solution and objective are reliable)\n"
                       << "  Primal Residual: " << k.primal_feas << "  Dual Residual: " << k.dual_feas
                       << "  Relative Gap: " << k.gap << "  (tolerance " << p->stop_tol << ")" << std::endl;
+            // Safety net: a reduced model that is solved to tolerance but misses the original model by orders of magnitude
+            // means a reduction went wrong on this input -- solve the model as given rather than hand back a wrong answer.
+            if (err > 100.0 * p->stop_tol && err > 1e-3) {
+                std::cout << "Postsolved solution is far from the original model's KKT conditions; solving the original model" << std::endl;
+                std::free(r.x); std::free(r.y); std::free(r.z);
+                return HPRLP_main_solve(model, p);
+            }
         }
     } else {
         std::cout << "Skipping postsolve original KKT check since the reduced solution is not optimal" << std::endl;
