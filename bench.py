@@ -47,6 +47,9 @@ WORKLOADS = {
     "c5_shard_like": (1_250_000, 1_250_000, 20, 100_000),  # rows and band of one of 8 shards of c5 (kernel-shape experiments)
     "c5_small": (1_000_000, 1_000_000, 20, 10_000),
     "c5_tiny": (100_000, 100_000, 20, 1_000),
+    # exactly 2 / 3 rounds of super-blocks over the 512 resident workgroups (config 5 has 1221 = 2.38 rounds): tail-balance experiments
+    "c5_2rounds": (8_388_608, 8_388_608, 20, 100_000),
+    "c5_3rounds": (12_582_912, 12_582_912, 20, 100_000),
     # config 5 handed over in a RANDOM row / column order: what the set-up time locality ordering (csrc/reorder.cpp) is for
     "c5_permuted": (10_000_000, 10_000_000, 20, 100_000),
     "c5_small_permuted": (2_000_000, 2_000_000, 20, 20_000),

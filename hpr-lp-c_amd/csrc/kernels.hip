@@ -501,6 +501,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
 #pragma unroll
     for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
     epi.begin();
+    int wg_round = 0;  // HPRLP_WG_TIMES diagnostic
+    if (t.wgtimes && tid == 0) t.wgtimes[blockIdx.x * 8] = wall_clock64();
     for (int q = slot; q < per; q += slots) {
         const int sb = (blockIdx.x % 8) * per + q;
         if (sb >= t.nsb) break;
@@ -544,7 +546,9 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
             }
             for (; k < e; k += NT) f.P[f.pos[k]] = f.val[k] * acc[f.lcol[k]];
         }
+        if (t.wgtimes && tid == 0 && ++wg_round <= 6) t.wgtimes[blockIdx.x * 8 + wg_round] = wall_clock64();
     }
+    if (t.wgtimes && tid == 0) t.wgtimes[blockIdx.x * 8 + 7] = wall_clock64();
     if constexpr (NACC > 0) {
         // the tile buffer is the scratch of the block reduction: a separate array would push the workgroup past
         // 80 KiB of LDS and leave ONE workgroup per CU (measured: 0.92 instead of 0.73 ms per launch)

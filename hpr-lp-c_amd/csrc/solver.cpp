@@ -227,6 +227,8 @@ void DeviceMatrix::refresh_tiled(hipStream_t s) {
 Solver::~Solver() {
     A.tiled.dump_stamps();
     AT.tiled.dump_stamps();
+    A.tiled.dump_wgtimes();
+    AT.tiled.dump_wgtimes();
     for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
     if (ev_ready) (void)hipEventDestroy(ev_ready);
     if (ev_done_x) (void)hipEventDestroy(ev_done_x);

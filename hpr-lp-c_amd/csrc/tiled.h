@@ -66,6 +66,7 @@ struct TiledDev {
     const int *slot_ptr = nullptr;     // nsb + 1: segments (= slots of `parts`) of a super-block, in summation order
     double *parts = nullptr;           // (number of segments) * kTileRows partial row sums
     unsigned long long *stamps = nullptr;  // HPRLP_TILE_STAMPS=1 (diagnostic): 16 shader-clock sums per piece
+    unsigned long long *wgtimes = nullptr;  // HPRLP_WG_TIMES=1 (diagnostic): 8 wall-clock stamps per workgroup of the fused kernel
     const int *sb_ptr = nullptr;   // nsb+1: steps of a super-block
     const int *sb_mid = nullptr;   // nsb: first remainder step
     const TileStep *steps = nullptr;
@@ -136,6 +137,8 @@ struct DeviceTiled {
     DBuf<int> piece_ptr, slot_ptr;
     DBuf<unsigned long long> stamps;
     void dump_stamps() const;  // diagnostic: phase times of the piece form on stderr
+    DBuf<unsigned long long> wgtimes;
+    void dump_wgtimes() const;  // diagnostic: start / per-super-block / end times of the fused kernel's workgroups (last launch)
     DBuf<int4> segs;
     // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,
     // too scattered, or too large for 32-bit entry offsets) and nothing is valid.

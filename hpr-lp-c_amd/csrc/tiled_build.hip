@@ -360,6 +360,10 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
             view.stamps = stamps.p;
         }
     }
+    if (const char *e = std::getenv("HPRLP_WG_TIMES"); e && e[0] == '1' && view.grid > 0) {
+        wgtimes.alloc_zero(static_cast<size_t>(view.grid) * 8);
+        view.wgtimes = wgtimes.p;
+    }
     rot_period = 0;
     if (nsb <= 0 || n_steps <= 0) return;
     {
@@ -678,6 +682,50 @@ void DeviceTiled::build_far(int cols, hipStream_t s) {
     view.f_val = f_val.p;
     view.f_pos = f_pos.p;
     view.f_lcol = f_lcol.p;
+}
+
+void DeviceTiled::dump_wgtimes() const {
+    if (!wgtimes.p || view.grid <= 0) return;
+    std::vector<unsigned long long> h(static_cast<size_t>(view.grid) * 8);
+    wgtimes.download(h.data(), h.size());
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < view.grid; ++w) {
+        if (h[w * 8] == 0) continue;
+        t0 = std::min(t0, h[w * 8]);
+        t1 = std::max(t1, h[w * 8 + 7]);
+    }
+    if (t1 == 0) return;
+    // wall clock: 100 MHz
+    std::fprintf(stderr, "[wg times] %d workgroups, kernel span %.1f us (first start to last end)\n", view.grid, (t1 - t0) / 100.0);
+    for (int x = 0; x < 8; ++x) {
+        double s_min = 1e30, s_max = 0, e_min = 1e30, e_max = 0, e_sum = 0;
+        int cnt = 0, rounds_max = 0;
+        for (int w = x; w < view.grid; w += 8) {
+            if (h[w * 8] == 0) continue;
+            const double st = (h[w * 8] - t0) / 100.0, en = (h[w * 8 + 7] - t0) / 100.0;
+            s_min = std::min(s_min, st); s_max = std::max(s_max, st);
+            e_min = std::min(e_min, en); e_max = std::max(e_max, en);
+            e_sum += en;
+            ++cnt;
+            int r = 0;
+            for (int q = 1; q <= 6; ++q) r += h[w * 8 + q] != 0;
+            rounds_max = std::max(rounds_max, r);
+        }
+        if (cnt) std::fprintf(stderr, "[wg times]   XCD %d: %d workgroups, start %.1f..%.1f us, end %.1f..%.1f us (mean %.1f), up to %d super-blocks each\n", x, cnt,
+                              s_min, s_max, e_min, e_max, e_sum / cnt, rounds_max);
+    }
+    // distribution of per-super-block durations by round
+    for (int q = 1; q <= 4; ++q) {
+        double mn = 1e30, mx = 0, sum = 0;
+        int cnt = 0;
+        for (int w = 0; w < view.grid; ++w) {
+            if (h[w * 8 + q] == 0) continue;
+            const double d = (h[w * 8 + q] - h[w * 8 + q - 1]) / 100.0;
+            mn = std::min(mn, d); mx = std::max(mx, d); sum += d;
+            ++cnt;
+        }
+        if (cnt) std::fprintf(stderr, "[wg times]   super-block %d of a workgroup: %d workgroups, %.1f..%.1f us (mean %.1f)\n", q, cnt, mn, mx, sum / cnt);
+    }
 }
 
 void DeviceTiled::dump_stamps() const {
