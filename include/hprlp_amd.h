@@ -149,7 +149,8 @@ typedef struct hprlp_presolve hprlp_presolve;
 hprlp_presolve *hprlp_presolve_run(const LP_info_cpu *model);
 const LP_info_cpu *hprlp_presolve_reduced(const hprlp_presolve *p); /* owned by p */
 /* out = {reduced m, reduced n, fixed cols, empty cols, singleton rows, empty rows, redundant rows, passes,
- *        dual-fixed cols, slack cols, parallel rows, parallel cols, forcing rows, 0, 0, 0 (reserved)} */
+ *        dual-fixed cols, slack cols, parallel rows, parallel cols, forcing rows, doubleton rows, tightened bounds,
+ *        rounds of the chain} */
 int hprlp_presolve_stats(const hprlp_presolve *p, int out[16]);
 /* (xr, yr, zr) of the reduced model -> (x, y, z) in the original dimensions */
 int hprlp_presolve_postsolve(const hprlp_presolve *p, const double *xr, const double *yr, const double *zr, double *x,
