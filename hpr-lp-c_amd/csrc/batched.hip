@@ -99,6 +99,7 @@ struct HalfArgs {
     BatchCtl ctl;
     double lambda_max;
     double *partials;
+    const int *order;                  // kb_half64: row group handled at position g of the launch (null: g itself)
 };
 
 // the half-step update of one (row, problem) element given the SpMM row sum s
@@ -209,7 +210,12 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
         else if (act) a.ctl.kx[k] = kk + 1;
     }
     const double *__restrict__ V = a.V + k;
-    for (int rb = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * RW); rb < rows; rb += gridDim.x * 4 * RW) {
+    // Row groups in launch order: the few groups with long rows first (BatchWS::order_*).  A 200-entry row is 26 dependent
+    // trips to memory for its wave (about 50 us): dispatched wherever it falls in the row order it ends up as the launch's
+    // tail (config 4: 53 such rows of A^T, x-half 101 -> 71 us without them); dispatched first it runs beside everything else.
+    const int ngroups = (rows + RW - 1) / RW;
+    for (int gi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); gi < ngroups; gi += gridDim.x * 4) {
+        const int rb = (a.order ? a.order[gi] : gi) * RW;
         int pb[RW + 1];
 #pragma unroll
         for (int i = 0; i <= RW; ++i) pb[i] = rowptr[min(rb + i, rows)];
@@ -416,6 +422,7 @@ struct BatchWS {
     DBuf<double> X, Xh, Xb, DX, Zb, lastX, Y, Yb, DY, Yobj, lastY;
     DBuf<double> sigma, SC, partials;
     DBuf<int> active, kx, ky, rflag;
+    DBuf<int> order_x, order_y;  // launch order of the 4-row groups of A^T / A in kb_half64 (groups with long rows first)
     HBuf<double> SC_h;
     BatchCtl ctl{};
     double lambda_max = 1.0;
@@ -451,8 +458,8 @@ void finalize(BatchWS &w, int nblocks, std::initializer_list<int> slots) {
 
 void launch_half_pair(BatchWS &w, bool check) {
     const CsrDev &A = w.shared->A.view, &AT = w.shared->AT.view;
-    HalfArgs xa{w.Y.p, w.X.p, w.Xh.p, w.L.p, w.U.p, w.C.p, w.lastX.p, w.Xb.p, w.Zb.p, w.DX.p, w.ctl, w.lambda_max, w.partials.p};
-    HalfArgs ya{w.Xh.p, w.Y.p, nullptr, w.AL.p, w.AU.p, nullptr, w.lastY.p, w.Yb.p, w.Yobj.p, w.DY.p, w.ctl, w.lambda_max, w.partials.p};
+    HalfArgs xa{w.Y.p, w.X.p, w.Xh.p, w.L.p, w.U.p, w.C.p, w.lastX.p, w.Xb.p, w.Zb.p, w.DX.p, w.ctl, w.lambda_max, w.partials.p, w.order_x.p};
+    HalfArgs ya{w.Xh.p, w.Y.p, nullptr, w.AL.p, w.AU.p, nullptr, w.lastY.p, w.Yb.p, w.Yobj.p, w.DY.p, w.ctl, w.lambda_max, w.partials.p, w.order_y.p};
     const dim3 gxd(w.gx, w.kchunks), gyd(w.gy, w.kchunks), blk(256);
     const bool wide = w.Bp >= 64;  // a wave = one row: kb_half64
     if (check) {
@@ -652,6 +659,29 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
         w.kchunks = (w.Bp + 63) / 64;
         w.gx = grid_for(n, geo);
         w.gy = grid_for(m, geo);
+        if (w.Bp >= 64) {
+            // groups of kRowsPerWave rows with more than kLongGroup nonzeros go first, longest first; the rest keep their order
+            auto build_order = [](const DBuf<int> &rowptr_dev, int rows, DBuf<int> &out) {
+                constexpr int kLongGroup = 32;
+                std::vector<int> rp(static_cast<size_t>(rows) + 1);
+                rowptr_dev.download(rp.data(), rp.size());
+                const int ng = (rows + kRowsPerWave - 1) / kRowsPerWave;
+                std::vector<int> longg, order;
+                order.reserve(static_cast<size_t>(ng));
+                auto len = [&](int g) { return rp[std::min(rows, (g + 1) * kRowsPerWave)] - rp[g * kRowsPerWave]; };
+                for (int g = 0; g < ng; ++g)
+                    if (len(g) > kLongGroup) longg.push_back(g);
+                if (longg.empty()) return;  // identity: no table
+                std::stable_sort(longg.begin(), longg.end(), [&](int x, int y) { return len(x) > len(y); });
+                order = longg;
+                for (int g = 0; g < ng; ++g)
+                    if (len(g) <= kLongGroup) order.push_back(g);
+                out.alloc(order.size());
+                out.upload(order.data(), order.size());
+            };
+            build_order(shared.AT.rowptr, n, w.order_x);
+            build_order(shared.A.rowptr, m, w.order_y);
+        }
         const size_t nB = static_cast<size_t>(n) * w.Bp, mB = static_cast<size_t>(m) * w.Bp;
         {
             std::vector<double> panel;

@@ -11,7 +11,7 @@ import bench  # noqa: E402
 
 H, G = bench.H, bench.G
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 600
-lp = G.c3_pds20_like()
+lp = G.c3_pds20_like() if os.environ.get("C4_NO_DENSE") != "1" else G.planted_lp(33874, 105728, 230200, 3, values="network", dense_col_frac=0.0)  # C4_NO_DENSE=1: the same shape without the 53 columns of ~205 entries
 model = H.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
 B = 64
 rng = np.random.default_rng(4)
