@@ -162,9 +162,24 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         const int min_rows = mr ? std::atoi(mr) : 32 * kTileRows;
         const double min_dense = min_dense_override >= 0.0 ? min_dense_override : (md ? std::atof(md) : 0.5);
         declined_sparse = false;
+        // Two more conditions on the shape (measured late in round 2, tools/longrow_ab.py):
+        //  * the gathered vector must be big enough for staging it to pay: a 300k x 100k matrix passes the dense-tile test but
+        //    its 0.8 MB vector lives in every L2 anyway -- stream kernel 11.5 us, tiled 30.7 us per launch.  Tiled from 2^20
+        //    columns on (8 MB: beyond an XCD's 4 MiB L2).  An explicit HPRLP_TILED_MIN_ROWS (tests) lifts the default.
+        //  * no long rows: a row's entries beyond four per tile go to the remainder list, where ONE lane adds a row's
+        //    consecutive products (two dependent LDS reads each): five rows of 3000 entries took that launch from 31 to 203
+        //    us.  Such matrices keep the stream kernel, which spreads a long row over a wave or several.
+        const char *mc = std::getenv("HPRLP_TILED_MIN_COLS");
+        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (1 << 20));
+        int longest = 0;
+        if (rp)
+            for (int i = 0; i < rows; ++i) longest = std::max(longest, rp[i + 1] - rp[i]);
+        declined_shape = cols < min_cols || longest > kTileMaxRow;
         const char *ht = std::getenv("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
-        if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
+        if (declined_shape) {
+            if (pt.on) std::cerr << "[timing]   tiled copy not attempted: " << cols << " columns, longest row " << longest << std::endl;
+        } else if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
             // built on the device from the device CSR arrays (tiled_build.hip); HPRLP_TILING_CHECK=1 also runs the
             // host builder and compares every array
             const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr);
@@ -414,7 +429,7 @@ bool Solver::try_reorder(const LP_info_cpu *model) {
     if (nt && nt[0] == '1') return false;
     const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
     const int min_rows = mr ? std::atoi(mr) : 32 * kTileRows;
-    if (comm || A.view.tiled.valid || m < min_rows || n < min_rows) return false;
+    if (comm || A.view.tiled.valid || A.declined_shape || m < min_rows || n < min_rows) return false;
     const auto t0 = time_now();
     const sparseMatrix *As = model->A;
     const long nnz = As->numElements;

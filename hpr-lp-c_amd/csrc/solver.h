@@ -52,6 +52,7 @@ struct DeviceMatrix {
     // staged tiles (0: accept any pattern -- everything outside dense tiles goes through the propagation-blocking remainder)
     void describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep, double min_dense_override = -1.0);
     bool declined_sparse = false;  // the last tiled build was declined for lack of dense tiles (not for size)
+    bool declined_shape = false;   // ... not attempted: too few columns for staging to pay, or rows too long for the remainder list
     void finish_tiling(hipStream_t s);  // wait for the job, upload the copy, fill its values from the CSR values
     void refresh_tiled(hipStream_t s);  // re-gather the tiled values from the CSR values (after scaling)
 };

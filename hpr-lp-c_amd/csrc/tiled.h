@@ -33,6 +33,7 @@ constexpr int kTileChunk = 4;      // entries per lane per step
 constexpr int kTileStepCap = kTileThreads * kTileChunk;                       // entries per tile step
 constexpr int kTileRemK = (kTileCols * 8 - 8) / (12 * kTileThreads);          // remainder entries per lane per step (8 B product + 4 B code of LDS each)
 constexpr int kTileRemCap = kTileThreads * kTileRemK;                         // (scratch aliases the tile buffer)
+constexpr int kTileMaxRow = 512;  // matrices with a longer row are not tiled (its entries beyond four per tile are added by one lane, serially)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
 static_assert(kTileRemK >= 1, "tile buffer too small for the remainder scratch");
 constexpr int kTileRowBits = 13;  // local row in an entry code
