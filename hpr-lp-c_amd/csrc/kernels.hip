@@ -484,6 +484,54 @@ __device__ __forceinline__ void tiled_remainder(const TiledDev &t, int smid, int
         if (tid == 0) rq[0] = 0xffffu;
         if (s + 1 < s1) issue(nxt);
         lds_barrier();
+        if (st.col0 != 0) {
+            // A row with a long run in this step (marked by the builder; uniform): two levels.  Level 1: every entry at a
+            // row change or at a multiple of kTileRemRun adds the products up to the next such entry and leaves the partial
+            // sum in its own product slot (nobody else reads that slot); level 2: the entry at the row change adds the
+            // partials.  (One lane adding a 1000-entry run -- two dependent LDS reads per product -- was 55 us; a tree of
+            // fan-in 4 with a barrier per level measured slower than these two levels.)
+#pragma unroll
+            for (int k = 0; k < kTileRemK; ++k) {
+                const int el = tid + k * NT;
+                if (el < cnt) {
+                    const uint32_t w = rq[el + 1];
+                    const uint32_t rw = w & 0xffffu;
+                    if ((rq[el] & 0xffffu) != rw || (el % kTileRemRun) == 0) {
+                        double part = 0.0;
+                        uint32_t q = w;
+                        int j = el;
+                        do {
+                            part += prod[q >> 16];
+                            ++j;
+                            q = rq[j + 1];
+                        } while (j < cnt && (j % kTileRemRun) != 0 && (q & 0xffffu) == rw);
+                        prod[w >> 16] = part;
+                    }
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < kTileRemK; ++k) {
+                const int el = tid + k * NT;
+                if (el < cnt) {
+                    const uint32_t w = rq[el + 1];
+                    const uint32_t rw = w & 0xffffu;
+                    if ((rq[el] & 0xffffu) != rw) {
+                        double sacc = acc[rw];
+                        int j = el;
+                        uint32_t q = w;
+                        do {
+                            sacc += prod[q >> 16];
+                            j = (j / kTileRemRun + 1) * kTileRemRun;
+                            q = rq[min(j, cnt - 1) + 1];
+                        } while (j < cnt && (q & 0xffffu) == rw);
+                        acc[rw] = sacc;
+                    }
+                }
+            }
+            st = nxt;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < kTileRemK; ++k) {
             const int el = tid + k * NT;

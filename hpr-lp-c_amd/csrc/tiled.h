@@ -33,7 +33,9 @@ constexpr int kTileChunk = 4;      // entries per lane per step
 constexpr int kTileStepCap = kTileThreads * kTileChunk;                       // entries per tile step
 constexpr int kTileRemK = (kTileCols * 8 - 8) / (12 * kTileThreads);          // remainder entries per lane per step (8 B product + 4 B code of LDS each)
 constexpr int kTileRemCap = kTileThreads * kTileRemK;                         // (scratch aliases the tile buffer)
-constexpr int kTileMaxRow = 512;  // matrices with a longer row are not tiled (its entries beyond four per tile are added by one lane, serially)
+constexpr int kTileRemRun = 16;    // remainder steps in which a row holds more consecutive entries than this are added in two levels (8 / 16 / 32 measured)
+constexpr int kTileMaxRow = 1024;  // matrices with a longer row are not tiled: a long row's remainder entries all go through ONE workgroup
+                                   // (2M x 2M, five rows of L entries, per launch: L = 1000 192 us, 3000 265-327 us, 8000 433-470 us; stream kernel 262 us)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
 static_assert(kTileRemK >= 1, "tile buffer too small for the remainder scratch");
 constexpr int kTileRowBits = 13;  // local row in an entry code

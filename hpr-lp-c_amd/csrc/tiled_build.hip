@@ -546,15 +546,21 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
 namespace {
 
 __global__ void __launch_bounds__(kThreads) k_far_step_of(int nsb, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
-                                                         const TileStep *__restrict__ steps, int *__restrict__ step_of, int *__restrict__ sb_of) {
-    // one workgroup per super-block: every remainder entry learns its step and its super-block
+                                                         TileStep *__restrict__ steps, const uint16_t *__restrict__ rrow,
+                                                         int *__restrict__ step_of, int *__restrict__ sb_of, bool mark) {
+    // one workgroup per super-block: every remainder entry learns its step and its super-block; a step in which some row
+    // holds more than kTileRemRun consecutive entries is marked (col0 = 1, unused by remainder steps otherwise): the
+    // kernel adds such a step's rows in two levels (kernels.hip, tiled_remainder)
     const int sb = blockIdx.x;
     if (sb >= nsb) return;
     for (int s = sb_mid[sb]; s < sb_ptr[sb + 1]; ++s) {
         const TileStep st = steps[s];
+        if (threadIdx.x == 0) steps[s].col0 = 0;
+        __syncthreads();
         for (int e = st.e_begin + threadIdx.x; e < st.e_end; e += kThreads) {
             step_of[e] = s;
             sb_of[e] = sb;
+            if (mark && e + kTileRemRun < st.e_end && rrow[e] == rrow[e + kTileRemRun]) steps[s].col0 = 1;  // (entries are in row order)
         }
     }
 }
@@ -647,7 +653,25 @@ void DeviceTiled::build_far(int cols, hipStream_t s) {
     const int n = static_cast<int>(n_rem), nsb = view.nsb;
     const int ngroups = (cols + kFarGroup - 1) / kFarGroup;
     DBuf<int> step_of(static_cast<size_t>(n)), sb_of(static_cast<size_t>(n));
-    hipLaunchKernelGGL(k_far_step_of, dim3(nsb), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, step_of.p, sb_of.p);
+    const char *no2 = std::getenv("HPRLP_NO_REM2");  // diagnostic: long runs of the remainder added by one lane, as before
+    hipLaunchKernelGGL(k_far_step_of, dim3(nsb), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, rrow.p, step_of.p, sb_of.p, !(no2 && no2[0] == '1'));
+    if (std::getenv("HPRLP_TIMING")) {
+        std::vector<TileStep> hs(static_cast<size_t>(n_steps));
+        std::vector<int> hp(static_cast<size_t>(nsb) + 1), hm(static_cast<size_t>(nsb));
+        HIP_CHECK(hipStreamSynchronize(s));
+        steps.download(hs.data(), hs.size());
+        sb_ptr.download(hp.data(), hp.size());
+        sb_mid.download(hm.data(), hm.size());
+        long rem_steps = 0, marked = 0, most = 0;
+        for (int sb = 0; sb < nsb; ++sb) {
+            most = std::max<long>(most, hp[sb + 1] - hm[sb]);
+            for (int q = hm[sb]; q < hp[sb + 1]; ++q) {
+                ++rem_steps;
+                marked += hs[q].col0 != 0;
+            }
+        }
+        std::fprintf(stderr, "[timing]   remainder: %ld steps (most in one super-block: %ld), %ld with a long run of one row\n", rem_steps, most, marked);
+    }
     DBuf<unsigned long long> kin(static_cast<size_t>(n)), kout(static_cast<size_t>(n));
     DBuf<int> vin(static_cast<size_t>(n)), e_of_p(static_cast<size_t>(n));
     // P order
