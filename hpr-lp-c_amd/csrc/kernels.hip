@@ -101,8 +101,9 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
         const int *__restrict__ col = A.col + k0;
         const double *__restrict__ val = A.val + k0;
 
-        if (nr <= 1 && nz > kLongRow) {
-            // ---- vector mode: one long row per wave (nr == 0: one chunk of a split row, see below)
+        if (nr == 0 || (nr == 1 && nz > kLongRow)) {
+            // ---- vector mode: one long row per wave (nr == 0: one chunk of a split row, see below -- of any length: the last
+            // chunk of a row of 4097 entries holds one)
             double s[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) s[v] = 0.0;
@@ -991,11 +992,73 @@ struct Publishes<Epi, std::void_t<decltype(Epi::kPublishes)>> : std::true_type {
 
 // far_ready: M's remainder buffer already holds the products of e.gv[0] (pushed by the producing half-step): no pre-pass.
 // Returns true if the launch pushed (fused tiled kernel with a hand-off requested in e.push).
+// Second kernel of a half-step whose matrix was split by columns (multi-GPU overlap): `base[r]` is the row sum over
+// the local-column part, computed while the exchange was in flight; this launch adds the remote-column part and runs
+// the epilogue.  Summation order per row: local entries (CSR order), then remote entries (CSR order).
+template <class Epi>
+struct WithBase : Epi {
+    const double *base;
+    struct Row {
+        typename Epi::Row w;
+        double b;
+    };
+    __device__ __forceinline__ Row load_row(int r) const { return Row{Epi::load_row(r), base[r]}; }
+    __device__ __forceinline__ auto apply(int r, const Row &w, const double (&s)[1], double (&acc)[Epi::NACC > 0 ? Epi::NACC : 1]) const {
+        const double t[1] = {w.b + s[0]};
+        return Epi::apply(r, w.w, t, acc);
+    }
+};
+
+// the long rows of a tiled matrix (tiled.h: TiledDev::side_*): their row sums, formed by the stream kernel over the CSR
+// arrays, land in base[row]
+struct SideEpi {
+    static constexpr int NV = 1;
+    static constexpr int NACC = 0;
+    const double *gv[1];
+    const int *rows;
+    double *base;
+    struct Row {};
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Row load_row(int) const { return Row{}; }
+    __device__ __forceinline__ void apply(int r, const Row &, const double (&s)[1], double (&)[1]) const { base[rows[r]] = s[0]; }
+};
+
+template <class Epi>
+static bool launch_tiled(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready);
+
 template <class Epi>
 static bool launch_fused(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready = false) {
     if (M.nblk <= 0) return false;
     if constexpr (Epi::NV == 1) {
         if (M.tiled.valid) {
+            if (M.tiled.side_nblk > 0) {
+                // long rows aside: their sums first (a few waves, stream kernel), then the tiled launch adds them
+                CsrDev S = M;
+                S.tiled.valid = false;
+                S.blk = M.tiled.side_blk;
+                S.nblk = M.tiled.side_nblk;
+                S.longrows = M.tiled.side_long;
+                S.nlong = M.tiled.side_nlong;
+                S.long_partial = M.tiled.side_partial;
+                SideEpi se{{e.gv[0]}, M.tiled.side_rows, M.tiled.base};
+                hipLaunchKernelGGL(k_spmv_fused<SideEpi>, dim3(S.csr_grid()), dim3(kThreads), 0, s, S, se);
+                if (S.nlong > 0) hipLaunchKernelGGL(k_long_finish<SideEpi>, dim3(S.finish_grid()), dim3(kThreads), 0, s, S, se, S.csr_grid());
+                WithBase<Epi> wb{e, M.tiled.base};
+                return launch_tiled(M, wb, s, far_ready);
+            }
+            return launch_tiled(M, e, s, far_ready);
+        }
+    }
+    hipLaunchKernelGGL(k_spmv_fused<Epi>, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, e);
+    if (M.nlong > 0)
+        hipLaunchKernelGGL(k_long_finish<Epi>, dim3(M.finish_grid()), dim3(kThreads), 0, s, M, e, M.csr_grid());
+    return false;
+}
+
+template <class Epi>
+static bool launch_tiled(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready) {
+    {
+        {
             if (M.tiled.n_groups > 0 && !far_ready)
                 hipLaunchKernelGGL(k_far_products, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
             if (M.tiled.n_pieces > 0) {
@@ -1017,10 +1080,6 @@ static bool launch_fused(const CsrDev &M, const Epi &e, hipStream_t s, bool far_
             return false;
         }
     }
-    hipLaunchKernelGGL(k_spmv_fused<Epi>, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, e);
-    if (M.nlong > 0)
-        hipLaunchKernelGGL(k_long_finish<Epi>, dim3(M.finish_grid()), dim3(kThreads), 0, s, M, e, M.csr_grid());
-    return false;
 }
 
 FarPush far_push_of(const CsrDev &consumer) {
@@ -1053,22 +1112,6 @@ bool launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t 
     return launch_fused(A, e, s, a.far_ready);
 }
 
-// Second kernel of a half-step whose matrix was split by columns (multi-GPU overlap): `base[r]` is the row sum over
-// the local-column part, computed while the exchange was in flight; this launch adds the remote-column part and runs
-// the epilogue.  Summation order per row: local entries (CSR order), then remote entries (CSR order).
-template <class Epi>
-struct WithBase : Epi {
-    const double *base;
-    struct Row {
-        typename Epi::Row w;
-        double b;
-    };
-    __device__ __forceinline__ Row load_row(int r) const { return Row{Epi::load_row(r), base[r]}; }
-    __device__ __forceinline__ auto apply(int r, const Row &w, const double (&s)[1], double (&acc)[Epi::NACC > 0 ? Epi::NACC : 1]) const {
-        const double t[1] = {w.b + s[0]};
-        return Epi::apply(r, w.w, t, acc);
-    }
-};
 
 void launch_x_half_base(const CsrDev &AT_remote, const XHalfArgs &a, const double *base, hipStream_t s) {
     WithBase<XEpi<false>> e{{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, FarPush{}}, base};

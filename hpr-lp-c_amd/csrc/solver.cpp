@@ -121,9 +121,9 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
     std::vector<int4> b = build_row_blocks(rows, rp, &lr);
     int nslots = 0;
     for (const int4 &d : b) {
-        const bool vec = (d.y <= 1 && d.w > kLongRow);
+        const bool vec = d.y == 0 || (d.y == 1 && d.w > kLongRow);
         if (d.y == 0) {
-            if (!vec || d.w > kSplitRow || d.x != nslots++) throw std::runtime_error("bad split-row block");
+            if (d.w < 1 || d.w > kSplitRow || d.x != nslots++) throw std::runtime_error("bad split-row block");
         } else if (!vec && (d.w > kStreamW || d.y > kStreamRows || d.y < 1)) {
             throw std::runtime_error("bad row block");
         }
@@ -177,6 +177,45 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         declined_shape = cols < min_cols || longest > kTileMaxRow;
         const char *ht = std::getenv("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
+        // A FEW long rows (dense LP columns / rows) do not have to cost the matrix the tiled kernel: they are left out of the
+        // tiled copy and summed by the stream kernel's vector / split-row mode into a base vector that every tiled launch
+        // adds (tiled.h: TiledDev::side_*).  At most 0.1 % of the rows (and 64) and a fifth of the nonzeros.
+        const char *nside = std::getenv("HPRLP_NO_LONG_SIDE");
+        if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && rp && !host_tiling && !(nside && nside[0] == '1')) {
+            std::vector<int> long_rows;
+            long long_nnz = 0;
+            for (int i = 0; i < rows; ++i)
+                if (rp[i + 1] - rp[i] > kTileMaxRow) {
+                    long_rows.push_back(i);
+                    long_nnz += rp[i + 1] - rp[i];
+                }
+            if (static_cast<long>(long_rows.size()) <= std::max<long>(64, rows / 1000) && long_nnz * 5 <= nnz) {
+                std::vector<int> rp_c(static_cast<size_t>(rows) + 1, 0);
+                for (int i = 0; i < rows; ++i) {
+                    const int len = rp[i + 1] - rp[i];
+                    rp_c[i + 1] = rp_c[i] + (len > kTileMaxRow ? 0 : len);
+                }
+                const long nnz_c = rp_c[rows];
+                DBuf<int> d_rp_c(rp_c.size()), col_c(static_cast<size_t>(std::max<long>(nnz_c, 1))), map_c(static_cast<size_t>(std::max<long>(nnz_c, 1)));
+                d_rp_c.upload(rp_c.data(), rp_c.size());
+                compact_without_rows(nnz, rows, rowptr.p, d_rp_c.p, col.p, col_c.p, map_c.p, nullptr);
+                const bool ok = tiled.build_on_device(rows, cols, nnz_c, d_rp_c.p, col_c.p, min_rows, min_dense, nullptr);
+                if (pt.on)
+                    std::cerr << "[timing]   tiled copy without " << long_rows.size() << " long rows (" << long_nnz << " entries, longest " << longest
+                              << "): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, " << tiled.n_steps << " steps" << std::endl;
+                if (ok) {
+                    tiled.build_far(cols, nullptr);
+                    tiled.compose_perms(map_c.p, nullptr);
+                    tiled.set_side(rows, rp, long_rows);
+                    view.tiled = tiled.view;
+                    launch_tiled_refresh(tiled, val.p, nullptr);
+                    HIP_CHECK(hipDeviceSynchronize());
+                    declined_shape = false;
+                }
+                pt.tick("  build tiled copy (device, long rows aside)");
+                if (ok) return;
+            }
+        }
         if (declined_shape) {
             if (pt.on) std::cerr << "[timing]   tiled copy not attempted: " << cols << " columns, longest row " << longest << std::endl;
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {

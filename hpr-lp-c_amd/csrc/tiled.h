@@ -68,6 +68,17 @@ struct TiledDev {
     const int4 *segs = nullptr;        // {super-block, first step (relative), steps, 1 if the super-block's last segment}
     const int *slot_ptr = nullptr;     // nsb + 1: segments (= slots of `parts`) of a super-block, in summation order
     double *parts = nullptr;           // (number of segments) * kTileRows partial row sums
+    // Long rows kept OUT of the tiled copy (rows over kTileMaxRow entries: DeviceMatrix::describe): their sums are formed by
+    // the stream kernel's vector / split-row mode over the CSR arrays (block list side_blk: descriptor {slot, 1, first
+    // nonzero, count} or the chunks of a split row) into base[row], and every tiled launch adds base through the WithBase
+    // epilogue (kernels.hip, launch_fused).  side_nblk == 0: no such rows.
+    const int4 *side_blk = nullptr;
+    int side_nblk = 0;
+    const int4 *side_long = nullptr;  // split rows of the side list: {slot, first chunk slot, one past the last, 0}
+    int side_nlong = 0;
+    double *side_partial = nullptr;
+    const int *side_rows = nullptr;   // slot -> row
+    double *base = nullptr;           // rows doubles, zero except for the long rows
     unsigned long long *stamps = nullptr;  // HPRLP_TILE_STAMPS=1 (diagnostic): 16 shader-clock sums per piece
     unsigned long long *wgtimes = nullptr;  // HPRLP_WG_TIMES=1 (diagnostic): 8 wall-clock stamps per workgroup of the fused kernel
     const int *sb_ptr = nullptr;   // nsb+1: steps of a super-block
@@ -113,6 +124,9 @@ struct TiledHost {
 bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
                  double min_dense_fraction);
 
+// col_c / map_c (device, compact nnz entries): the CSR pattern without the rows whose compact length is zero (tiled_build.hip)
+void compact_without_rows(long nnz, int rows, const int *rp_dev, const int *rp_c_dev, const int *col_dev, int *col_c, int *map_c, hipStream_t s);
+
 struct DeviceTiled {
     DBuf<int> sb_ptr, sb_mid, tperm, rperm, rcol;
     DBuf<TileStep> steps;
@@ -141,6 +155,13 @@ struct DeviceTiled {
     DBuf<unsigned long long> stamps;
     void dump_stamps() const;  // diagnostic: phase times of the piece form on stderr
     DBuf<unsigned long long> wgtimes;
+    // long rows aside (TiledDev::side_*): built by set_side from the host row pointers
+    DBuf<int4> side_blk, side_long;
+    DBuf<int> side_rows;
+    DBuf<double> side_partial, base;
+    void set_side(int rows, const int *rowptr_host, const std::vector<int> &long_rows);
+    // the copy was built from a CSR without the long rows: translate its value indices back (map: compact -> original position)
+    void compose_perms(const int *map_dev, hipStream_t s);
     void dump_wgtimes() const;  // diagnostic: start / per-super-block / end times of the fused kernel's workgroups (last launch)
     DBuf<int4> segs;
     // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,

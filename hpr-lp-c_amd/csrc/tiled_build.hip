@@ -708,6 +708,80 @@ void DeviceTiled::build_far(int cols, hipStream_t s) {
     view.f_lcol = f_lcol.p;
 }
 
+namespace {
+
+// compact CSR without the rows of zero compact length: one thread per ORIGINAL entry
+__global__ void __launch_bounds__(kThreads) k_compact_cols(long nnz, int rows, const int *__restrict__ rp, const int *__restrict__ rp_c,
+                                                          const int *__restrict__ col, int *__restrict__ col_c, int *__restrict__ map_c) {
+    const long k = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (k >= nnz) return;
+    int lo = 0, hi = rows;  // rp[lo] <= k < rp[hi]
+    while (hi - lo > 1) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (rp[mid] <= k) lo = mid;
+        else hi = mid;
+    }
+    if (rp_c[lo + 1] == rp_c[lo]) return;  // a row left out (or empty)
+    const int q = rp_c[lo] + static_cast<int>(k - rp[lo]);
+    col_c[q] = col[k];
+    map_c[q] = static_cast<int>(k);
+}
+
+__global__ void __launch_bounds__(kThreads) k_compose_perm(long n, int *__restrict__ perm, const int *__restrict__ map) {
+    const long i = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < n && perm[i] >= 0) perm[i] = map[perm[i]];
+}
+
+}  // namespace
+
+void compact_without_rows(long nnz, int rows, const int *rp_dev, const int *rp_c_dev, const int *col_dev, int *col_c, int *map_c, hipStream_t s) {
+    if (nnz > 0) hipLaunchKernelGGL(k_compact_cols, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, rows, rp_dev, rp_c_dev, col_dev, col_c, map_c);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void DeviceTiled::compose_perms(const int *map_dev, hipStream_t s) {
+    if (n_tile > 0) hipLaunchKernelGGL(k_compose_perm, dim3(grid_for(n_tile)), dim3(kThreads), 0, s, n_tile, tperm.p, map_dev);
+    if (n_rem > 0 && f_perm.p) hipLaunchKernelGGL(k_compose_perm, dim3(grid_for(n_rem)), dim3(kThreads), 0, s, n_rem, f_perm.p, map_dev);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void DeviceTiled::set_side(int rows, const int *rp, const std::vector<int> &long_rows) {
+    // block list of the stream kernel over the long rows only: {slot, 1, first nonzero, count} (vector mode), rows over
+    // kSplitRow as chunks {chunk slot, 0, first, count} + an entry {slot, first chunk slot, one past the last, 0}
+    std::vector<int4> blk, lng;
+    int chunk_slots = 0;
+    for (size_t q = 0; q < long_rows.size(); ++q) {
+        const int i = long_rows[q], len = rp[i + 1] - rp[i];
+        if (len > kSplitRow) {
+            const int first = chunk_slots;
+            for (int k = rp[i]; k < rp[i + 1]; k += kSplitRow) blk.push_back(make_int4(chunk_slots++, 0, k, std::min(kSplitRow, rp[i + 1] - k)));
+            lng.push_back(make_int4(static_cast<int>(q), first, chunk_slots, 0));
+        } else {
+            blk.push_back(make_int4(static_cast<int>(q), 1, rp[i], len));
+        }
+    }
+    side_blk.alloc(blk.size());
+    side_blk.upload(blk.data(), blk.size());
+    side_rows.alloc(long_rows.size());
+    side_rows.upload(long_rows.data(), long_rows.size());
+    base.alloc_zero(static_cast<size_t>(rows));
+    view.side_blk = side_blk.p;
+    view.side_nblk = static_cast<int>(blk.size());
+    view.side_rows = side_rows.p;
+    view.base = base.p;
+    view.side_long = nullptr;
+    view.side_nlong = 0;
+    view.side_partial = nullptr;
+    if (!lng.empty()) {
+        side_long.alloc(lng.size());
+        side_long.upload(lng.data(), lng.size());
+        side_partial.alloc_zero(static_cast<size_t>(chunk_slots) * 2);
+        view.side_long = side_long.p;
+        view.side_nlong = static_cast<int>(lng.size());
+        view.side_partial = side_partial.p;
+    }
+}
+
 void DeviceTiled::dump_wgtimes() const {
     if (!wgtimes.p || view.grid <= 0) return;
     std::vector<unsigned long long> h(static_cast<size_t>(view.grid) * 8);

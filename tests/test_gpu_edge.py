@@ -164,8 +164,11 @@ def test_dense_rows_and_columns_are_split(gpu):
     A[17, cols] = rng.uniform(0.5, 1.5, size=9000)
     rows = np.sort(rng.choice(m, size=5000, replace=False))
     A[rows, 33] = rng.uniform(0.5, 1.5, size=5000).reshape(-1, 1)
+    # a row whose last chunk holds a single entry (4097 = 4096 + 1: round 2 found such a row refused with "bad split-row block")
+    A[40, :] = 0
+    A[40, np.sort(rng.choice(n, size=4097, replace=False))] = rng.uniform(0.5, 1.5, size=4097)
     A = sparse.csr_matrix(A); A.sort_indices()
-    assert np.diff(A.indptr).max() >= 9000 and np.diff(sparse.csc_matrix(A).indptr).max() >= 5000
+    assert np.diff(A.indptr).max() >= 9000 and np.diff(sparse.csc_matrix(A).indptr).max() >= 5000 and np.diff(A.indptr)[40] == 4097
     x0 = rng.uniform(0, 1, n)
     b = A @ x0
     AL = np.full(m, -INF); AU = b + 0.1

@@ -140,42 +140,53 @@ def test_piece_form_matches_oracle(gpu, force_tiled, pieces):
         os.environ.pop("HPRLP_TILE_PIECES", None)
 
 
-def test_tiled_long_rows_are_added_in_two_levels(gpu, force_tiled):
-    """A few rows and columns with thousands of entries in a tiled matrix: all but four entries per tile of such a row go to the
-    remainder list, where a step that holds a long run of one row is added in two levels (tiled.h: kTileRemRun).  Parity with
-    the oracle as for every tiled matrix; rows over kTileMaxRow = 1024 entries keep the matrix off the tiled path."""
+def test_tiled_matrix_with_long_rows(gpu, force_tiled):
+    """Rows and columns with hundreds to thousands of entries in a tiled matrix.  Up to kTileMaxRow = 1024 entries a row stays in
+    the tiled copy: all but four entries per tile go to the remainder list, where a step that holds a long run of one row is
+    added in two levels (tiled.h: kTileRemRun).  Longer rows (a few of them) are left out of the tiled copy and summed by the
+    stream kernel's vector / split-row mode into the base vector every tiled launch adds (TiledDev::side_*; 9000 entries: split
+    into chunks).  Parity with the oracle as for every tiled matrix; with too many long rows the matrix keeps the stream kernel."""
     from scipy import sparse
     m, n = 26000, 34000
     lp = bh.banded_lp(m, n, 10, 500)
-    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    A0 = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
     rng = np.random.default_rng(9)
-    add_r, add_c, add_v = [], [], []
-    for i, L in zip(rng.choice(m, 4, replace=False), (300, 500, 700, 950)):     # long rows of A
-        c = rng.choice(n, L, replace=False)
-        add_r.append(np.full(L, i)); add_c.append(c); add_v.append(rng.normal(size=L) * 0.05)
-    for j, L in zip(rng.choice(n, 3, replace=False), (250, 600, 900)):            # long rows of A^T
-        r = rng.choice(m, L, replace=False)
-        add_r.append(r); add_c.append(np.full(L, j)); add_v.append(rng.normal(size=L) * 0.05)
-    A = (A + sparse.csr_matrix((np.concatenate(add_v), (np.concatenate(add_r), np.concatenate(add_c))), shape=(m, n))).tocsr()
-    A.sort_indices()
+
+    def with_long(rows_of_A, rows_of_AT):
+        add_r, add_c, add_v = [], [], []
+        for i, L in zip(rng.choice(m, len(rows_of_A), replace=False), rows_of_A):
+            c = rng.choice(n, L, replace=False)
+            add_r.append(np.full(L, i)); add_c.append(c); add_v.append(rng.normal(size=L) * 0.05)
+        for j, L in zip(rng.choice(n, len(rows_of_AT), replace=False), rows_of_AT):
+            r = rng.choice(m, L, replace=False)
+            add_r.append(r); add_c.append(np.full(L, j)); add_v.append(rng.normal(size=L) * 0.05)
+        A = (A0 + sparse.csr_matrix((np.concatenate(add_v), (np.concatenate(add_r), np.concatenate(add_c))), shape=(m, n))).tocsr()
+        A.sort_indices()
+        return A
+
+    for rows_of_A, rows_of_AT in (((300, 500, 700, 950), (250, 600, 900)),             # inside the tiled copy (two-level remainder)
+                                  ((700, 1500, 3100, 9000), (900, 2500, 5000, 4097))):  # aside: vector mode and split rows
+        A = with_long(rows_of_A, rows_of_AT)
+        x0 = np.abs(rng.normal(size=n))
+        b = A @ x0
+        rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+        AL, AU, l, u, c = b - 1.0, b + 1.0, np.zeros(n), np.full(n, 10.0), rng.normal(size=n)
+        model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, c)
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+        assert s.info()["tiled"] == 3
+        ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, c, O.Params.default(use_CR_scaling=0))
+        s.scale()
+        adopt_gpu_data(s, ref)
+        st = run_steps(s, ref, 0.6, 1.4, [(9, True), (4, True), (6, False)])
+        for name in NAMES_N + NAMES_M:
+            np.testing.assert_allclose(s.get(name), st[name], rtol=1e-10, atol=1e-12, err_msg=name)
+        s.close(); model.free()
+    # more long rows than the side list takes (64, or 0.1 % of the rows): not tiled
+    A2 = with_long(tuple([1100] * 70), ())
     x0 = np.abs(rng.normal(size=n))
-    b = A @ x0
-    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
-    AL, AU, l, u, c = b - 1.0, b + 1.0, np.zeros(n), np.full(n, 10.0), rng.normal(size=n)
-    model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, c)
-    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
-    assert s.info()["tiled"] == 3
-    ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, c, O.Params.default(use_CR_scaling=0))
-    s.scale()
-    adopt_gpu_data(s, ref)
-    st = run_steps(s, ref, 0.6, 1.4, [(9, True), (4, True), (6, False)])
-    for name in NAMES_N + NAMES_M:
-        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-10, atol=1e-12, err_msg=name)
-    s.close(); model.free()
-    # one row beyond kTileMaxRow: not tiled
-    A2 = (A + sparse.csr_matrix((np.full(9000, 0.01), (np.full(9000, 5), rng.choice(n, 9000, replace=False))), shape=(m, n))).tocsr()
-    A2.sort_indices()
-    model2 = hprlp.Model.from_csr(m, n, A2.indptr.astype(np.int32), A2.indices.astype(np.int32), A2.data, AL, AU, l, u, c)
+    b = A2 @ x0
+    model2 = hprlp.Model.from_csr(m, n, A2.indptr.astype(np.int32), A2.indices.astype(np.int32), A2.data, b - 1.0, b + 1.0, np.zeros(n), np.full(n, 10.0),
+                                  rng.normal(size=n))
     s2 = hprlp.Solver(model2, hprlp.Parameters(use_presolve=False))
-    assert s2.info()["tiled"] & 1 == 0   # A holds the 9000-entry row
+    assert s2.info()["tiled"] & 1 == 0
     s2.close(); model2.free()
