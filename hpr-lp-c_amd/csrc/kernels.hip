@@ -108,6 +108,26 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) s[v] = 0.0;
             int j = lane;
+            // eight independent load chains first (a 4096-entry row: 2 trips of 8 instead of 4 of 4 per lane pair), same
+            // accumulation sequence per lane as the four-wide loop below
+            for (; j + 7 * kWave < nz; j += 8 * kWave) {
+                double a[8];
+                int c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    a[u] = __builtin_nontemporal_load(val + j + u * kWave);
+                    c[u] = __builtin_nontemporal_load(col + j + u * kWave);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const double *__restrict__ g = epi.gv[v];
+                    double gg[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) gg[u] = g[c[u]];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s[v] += term<Epi>(a[u], gg[u]);
+                }
+            }
             for (; j + 3 * kWave < nz; j += 4 * kWave) {
                 double a0 = __builtin_nontemporal_load(val + j), a1 = __builtin_nontemporal_load(val + j + kWave),
                        a2 = __builtin_nontemporal_load(val + j + 2 * kWave), a3 = __builtin_nontemporal_load(val + j + 3 * kWave);
