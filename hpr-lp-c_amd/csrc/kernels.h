@@ -13,7 +13,10 @@ constexpr int kWavesPerBlock = 4; // 256-thread workgroups, one row block per wa
 constexpr int kThreads = kWave * kWavesPerBlock;
 constexpr int kStreamW = 512;     // max nonzeros staged through LDS by one wave (4 KiB per vector)
 constexpr int kStreamRows = 64;   // max rows per stream block: one lane per row
-constexpr int kLongRow = 256;     // rows longer than this get a whole wave (vector mode)
+constexpr int kLongRow = 64;      // rows longer than this get a whole wave (vector mode: lanes stride the row, then a wave sum).  256 until late in
+                                  // round 2: one lane adding a 205-entry row in CSR order is a chain of 205 dependent additions -- 1.5 us of the
+                                  // config-3 x-half launch (10.9 -> 9.4 us per iteration).  Rows up to 64 entries keep the plain CSR-order sum
+                                  // (bit-identical to the oracle and to the single-workgroup kernel); longer ones agree to rounding.
 constexpr int kSplitRow = 4096;   // rows longer than this are cut into chunks of this many nonzeros
 constexpr int kNumScalars = 24;   // device scalar slots (see enum Slot)
 

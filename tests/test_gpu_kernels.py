@@ -119,7 +119,7 @@ def run_steps(s, ref, sigma, lam, schedule):
 def test_iterations_bit_exact_on_short_rows(gpu):
     lp = lpgen.planted_lp(300, 500, 3000, 24, dense_col_frac=0.0)
     model, s, ref = make(lp, use_CR_scaling=False)
-    assert np.diff(ref.Arp).max() <= 256 and np.diff(ref.ATrp).max() <= 256
+    assert np.diff(ref.Arp).max() <= 64 and np.diff(ref.ATrp).max() <= 64  # kLongRow: longer rows are summed by a whole wave
     s.scale()
     adopt_gpu_data(s, ref)
     st = run_steps(s, ref, 0.7, 1.3, [(37, True), (0, True), (9, True), (70, False)])

@@ -50,24 +50,39 @@ def iterate_states(model, prm, plan, no_small):
                                    (821, 1571, 10700), (1900, 2040, 11500)])
 def test_small_kernel_equals_regular_kernels_bit_for_bit(gpu, shape):
     m, n, nnz = shape
-    lp = lpgen.planted_lp(m, n, nnz, 5, dense_col_frac=0.01)
+    lp = lpgen.planted_lp(m, n, nnz, 5, dense_col_frac=0.01 if m != 300 else 0.0)  # (300, 500, 2500): no dense columns, rows <= 64
     model = make(lp)
     prm = hprlp.Parameters(use_presolve=False)
     plan = [(1, False), (7, True), (64, False), (149, True), (3, False)]
     small, res_s = iterate_states(model, prm, plan, no_small=False)
     regular, res_r = iterate_states(model, prm, plan, no_small=True)
+    # The single-workgroup kernel adds every row in CSR order; the regular kernels do so for rows of up to 64 entries
+    # (kernels.h: kLongRow) and hand longer rows to a whole wave (strided partial sums + a wave sum).  Shapes without such
+    # rows must agree bit for bit, the others to rounding.
+    from scipy import sparse
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    longest = max(np.diff(A.indptr).max(), np.diff(A.tocsc().indptr).max())
     for a, b in zip(small, regular):
         assert a["k"] == b["k"]
         for k in VECS:
-            assert np.array_equal(a[k], b[k]), k
+            if longest <= 64:
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                np.testing.assert_allclose(a[k], b[k], rtol=1e-11, atol=1e-13, err_msg=k)
     for k in res_r:
-        assert res_s[k] == res_r[k], k
+        if longest <= 64:
+            assert res_s[k] == res_r[k], k
+        else:
+            assert abs(res_s[k] - res_r[k]) <= 1e-9 * (1 + abs(res_r[k])), k
     model.free()
 
 
-def test_small_kernel_matches_oracle(gpu):
+@pytest.mark.parametrize("dense", [0.0, 0.01])
+def test_small_kernel_matches_oracle(gpu, dense):
+    """Normal steps by the single-workgroup kernel, check steps by the regular kernels, against the oracle: bit for bit when no
+    row has more than 64 entries (kLongRow: the regular kernels add longer rows wave-wide), to rounding otherwise."""
     m, n = 400, 650
-    lp = lpgen.planted_lp(m, n, 4000, 8, dense_col_frac=0.01)
+    lp = lpgen.planted_lp(m, n, 4000, 8, dense_col_frac=dense)
     model = make(lp)
     s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
     assert s.info()["tiled"] & 4
@@ -76,8 +91,13 @@ def test_small_kernel_matches_oracle(gpu):
     s.scale()
     adopt_gpu_data(s, ref)
     st = run_steps(s, ref, 0.7, 1.3, [(23, True), (5, True), (40, False)])
+    longest = max(np.diff(ref.Arp).max(), np.diff(ref.ATrp).max())
+    assert (longest <= 64) == (dense == 0.0)
     for name in NAMES_N + NAMES_M:
-        assert np.array_equal(s.get(name), st[name]), name
+        if longest <= 64:
+            assert np.array_equal(s.get(name), st[name]), name
+        else:
+            np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
     s.close(); model.free()
 
 
