@@ -34,7 +34,10 @@ for L in [int(a) for a in sys.argv[1:]] or [0, 200, 1000, 3000, 10000]:
     model = H.Model.from_csr(m, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, b - 1, b + 1, np.zeros(n), np.full(n, 10.0),
                              rng.normal(size=n))
     s = H.Solver(model, H.Parameters(use_presolve=False))
+    import time as _t
+    _t0 = _t.time()
     s.scale()
+    print("   entries: scale() %.4f s" % (_t.time() - _t0), file=sys.stderr)
     s.init(0.7, 1.3)
     big = m > 1_000_000
     t = s.time_iterations(20 if big else 200, 200 if big else 5000, 0)
