@@ -65,7 +65,7 @@ int main() {
         {   // the host form of the locality ordering on this pattern (declines or orders: either way every loop runs)
             std::vector<int> pr, pc;
             ReorderStats st;
-            const bool ord = locality_ordering(m, n, rp.data(), ci.data(), &pr, &pc, &st, 0.5);
+            const bool ord = locality_ordering(m, n, rp.data(), ci.data(), &pr, &pc, &st, 2.0);  // (2.0: no order is good enough, so nothing is skipped)
             printf("rep %d: locality ordering %s (tiled share %.3f -> %.3f, %d clusters)\n", rep, ord ? "accepted" : "declined", st.fraction_before,
                    st.fraction_after, st.clusters);
         }
