@@ -164,6 +164,54 @@ def test_sharded_solver_with_tiled_kernels_on_the_shards(gpu):
                 os.environ[k] = v
 
 
+def test_sharded_solver_with_tiled_shards_and_long_rows(gpu):
+    """Tiled shards of a matrix with a few rows and columns of thousands of entries: on a shard the long rows are kept aside (base
+    vector) AND the remote-column kernel adds the local-column part through the same kind of epilogue -- the two nest.  Same
+    iterates as the single-GPU solver."""
+    import os
+    import bench_helpers as bh
+    from scipy import sparse
+    old = {k: os.environ.get(k) for k in ("HPRLP_TILED_MIN_ROWS", "HPRLP_TILED_MIN_DENSE")}
+    os.environ["HPRLP_TILED_MIN_ROWS"] = "1"
+    os.environ["HPRLP_TILED_MIN_DENSE"] = "0.0"
+    try:
+        m = n = 24000
+        lp = bh.banded_lp(m, n, 10, 300)
+        A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+        rng = np.random.default_rng(4)
+        rr, cc, vv = [], [], []
+        for i, L in zip(rng.choice(m, 3, replace=False), (1500, 3000, 5000)):
+            c = rng.choice(n, L, replace=False); rr.append(np.full(L, i)); cc.append(c); vv.append(rng.normal(size=L) * 0.02)
+        for j, L in zip(rng.choice(n, 3, replace=False), (1200, 2500, 4500)):
+            r = rng.choice(m, L, replace=False); rr.append(r); cc.append(np.full(L, j)); vv.append(rng.normal(size=L) * 0.02)
+        A = (A + sparse.csr_matrix((np.concatenate(vv), (np.concatenate(rr), np.concatenate(cc))), shape=(m, n))).tocsr()
+        A.sort_indices()
+        x0 = np.abs(rng.normal(size=n))
+        b = A @ x0
+        c = rng.normal(size=n)
+        model = hprlp.Model.from_csr(m, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, b - 1.0, b + 1.0, np.zeros(n), np.full(n, 10.0), c)
+        prm = hprlp.Parameters(stop_tol=1e-4, use_presolve=False, max_iter=20000)
+        ref = single(model, prm, 23)
+        ranks = run_ranks(model, prm, 2, 23)
+        for o in ranks:
+            row_off, m_loc, col_off, n_loc = o["off"]
+            assert o["it"] == ref["it"] and abs(o["lam"] - ref["lam"]) <= 1e-11 * ref["lam"]
+            for k in ("x", "x_bar", "z_bar"):
+                np.testing.assert_allclose(o["state"][k][:n_loc], ref["state"][k][col_off:col_off + n_loc], rtol=1e-9, atol=1e-11, err_msg=k)
+            for k in ("y", "y_bar"):
+                np.testing.assert_allclose(o["state"][k][:m_loc], ref["state"][k][row_off:row_off + m_loc], rtol=1e-9, atol=1e-11, err_msg=k)
+            for k in ref["res"]:
+                assert abs(o["res"][k] - ref["res"][k]) <= 1e-8 * (1 + abs(ref["res"][k])), k
+            assert o["run"].status == ref["run"].status
+        model.free()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_failed_exchange_self_test_falls_back_to_the_all_gather(gpu):
     """Set-up self-test of the exchange (Solver::verify_exchange): a neighbour exchange reported as failed is replaced
     by the all-gather on every rank and the solve goes on to the single-GPU answer."""
