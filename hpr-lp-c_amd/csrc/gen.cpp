@@ -3,6 +3,7 @@
 // Every row is a pure function of (seed, row), so any rank can produce any row range on its own.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <thread>
 #include <vector>
@@ -36,6 +37,8 @@ struct RowRng {
 void gen_rows(int m, int n, int per_row, int band, uint64_t seed, int row0, int r_begin, int r_end, int *col,
               double *val) {
     const int width = std::min(2 * band + 1, n);
+    // 5 % of a row's entries fall anywhere (BASELINE config 5); HPRLP_GEN_FAR overrides the share for kernel experiments
+    static const double far_share = std::getenv("HPRLP_GEN_FAR") ? std::atof(std::getenv("HPRLP_GEN_FAR")) : 0.05;
     std::vector<int> c(static_cast<size_t>(per_row));
     for (int r = r_begin; r < r_end; ++r) {
         const int grow = row0 + r;
@@ -45,7 +48,7 @@ void gen_rows(int m, int n, int per_row, int band, uint64_t seed, int row0, int 
         if (base < 0) base = 0;
         if (base > n - width) base = n - width;
         for (int k = 0; k < per_row; ++k) {
-            const bool far = rng.uniform() < 0.05;
+            const bool far = rng.uniform() < far_share;
             c[k] = far ? static_cast<int>(rng.below(static_cast<uint64_t>(n)))
                        : static_cast<int>(base + static_cast<long>(rng.below(static_cast<uint64_t>(width))));
         }
