@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 #include <string>
@@ -120,6 +121,16 @@ bool ReduceStage::run(const LP_info_cpu *model) {
             }
     double offset = 0.0;
     bool give_up = false;
+    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;  // section times of this stage on stderr
+    double t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](int k) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        t_sec[k] += std::chrono::duration<double>(now - t_mark).count();
+        t_mark = now;
+    };
+    lap(0);  // transpose + working copies
     // HPRLP_PRESOLVE_OFF=slack,dualfix,parallel,forcing switches reductions off (diagnostics)
     const char *off_env = std::getenv("HPRLP_PRESOLVE_OFF");
     const std::string off = off_env ? off_env : "";
@@ -167,6 +178,7 @@ bool ReduceStage::run(const LP_info_cpu *model) {
                 changed = true;
             }
         }
+        lap(1);  // fixed columns
         // ---- rows
         for (int i = 0; i < m && !give_up; ++i) {
             if (!row_alive[i]) continue;
@@ -264,6 +276,7 @@ bool ReduceStage::run(const LP_info_cpu *model) {
                 changed = true;
             }
         }
+        lap(2);  // rows: empty / singleton / redundant / forcing
         // ---- parallel rows (PSLP: Parallel_rows): row i2 = lambda * row i1 over the live columns.  Row i2 goes, row i1
         // keeps the intersection of its own sides and row i2's sides divided by lambda.  (The two parallel scans hash
         // every live row and column: they run in the first pass and then in every fourth one.)
@@ -383,6 +396,7 @@ bool ReduceStage::run(const LP_info_cpu *model) {
                 }
             }
         }
+        lap(3);  // parallel rows and columns
         // ---- slack columns (PSLP: StonCols): column j appears only in row i,
         //   AL <= a x_j + sum_k a_ik x_k <= AU,  l_j <= x_j <= u_j,
         // and either the row is an equality (any cost) or c_j = 0.  x_j is eliminated: the row becomes
@@ -453,6 +467,7 @@ bool ReduceStage::run(const LP_info_cpu *model) {
             ++stats_.slack_cols;
             changed = true;
         }
+        lap(4);  // slack columns
         // ---- dual fixing (PSLP: Simple_dual_fix): a column whose cost and whose rows all push it the same way sits at
         // that bound in some optimal solution.  Down: c_j >= 0 and lowering x_j can violate no row (positive entries
         // only in rows without a lower side, negative entries only in rows without an upper side); up: mirrored.
@@ -473,6 +488,7 @@ bool ReduceStage::run(const LP_info_cpu *model) {
                 changed = true;
             }
         }
+        lap(5);  // dual fixing
         // ---- columns that no row uses any more
         for (int j = 0; j < n && !give_up; ++j) {
             if (!col_alive[j] || col_cnt[j] != 0) continue;
@@ -486,6 +502,7 @@ bool ReduceStage::run(const LP_info_cpu *model) {
             changed = true;
         }
     }
+    lap(6);  // empty columns (last pass)
     if (give_up) return false;
 
     // ---- assemble the reduced model
@@ -528,6 +545,10 @@ bool ReduceStage::run(const LP_info_cpu *model) {
     reduced_ = model_from_csr(rm, rn, static_cast<long>(rci.size()), rrp.data(), rci.data(), rv.data(), rAL.data(),
                               rAU.data(), rl.data(), ru.data(), rc.data(), model->obj_constant + offset);
     stats_.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    lap(7);  // assembling the reduced model
+    if (timing)
+        std::fprintf(stderr, "[timing] presolve reductions (%d passes): set-up %.4f, fixed cols %.4f, rows %.4f, parallel %.4f, slack %.4f, dual fix %.4f, empty cols %.4f, assemble %.4f s\n",
+                     stats_.passes, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_sec[5], t_sec[6], t_sec[7]);
     return reduced_ != nullptr;
 }
 
