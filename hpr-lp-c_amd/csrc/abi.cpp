@@ -223,7 +223,17 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
             if (err > 100.0 * p->stop_tol && err > 1e-3) {
                 std::cout << "Postsolved solution is far from the original model's KKT conditions; solving the original model" << std::endl;
                 std::free(r.x); std::free(r.y); std::free(r.z);
-                return HPRLP_main_solve(model, p);
+                // the caller's time limit covers presolve + the reduced solve + this one; so do the reported times and counts
+                const double spent = pre.stats().seconds + r.time;
+                const int it_first = r.iter;
+                HPRLP_parameters p2 = *p;
+                p2.time_limit = std::max(p->time_limit - spent, 0.0);
+                HPRLP_results r2 = HPRLP_main_solve(model, &p2);
+                r2.time += spent; r2.time4 += spent; r2.time6 += spent; r2.time8 += spent;
+                r2.iter += it_first; r2.iter4 += it_first; r2.iter6 += it_first; r2.iter8 += it_first;
+                std::cout << "Fallback solve: reported time and iterations include presolve and the reduced solve (" << spent
+                          << " s, " << it_first << " iterations)" << std::endl;
+                return r2;
             }
         }
     } else {

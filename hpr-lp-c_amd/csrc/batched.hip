@@ -626,6 +626,7 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
         mp.use_bc_scaling = false;
         Solver shared;
         shared.verbose = false;
+        shared.allow_reorder = false;  // the panels and the returned X / Y / Z are in the caller's numbering
         shared.setup(&mat, &mp);
         shared.scale();
         std::vector<double> rn(m), cn(n);

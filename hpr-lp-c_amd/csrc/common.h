@@ -48,13 +48,16 @@ struct AllocStats {
 // Process-wide cache of large freed device blocks (host_model.cpp).  hipMalloc of a multi-GB set-up temporary right after the
 // previous solver's buffers were freed stalls for 0.5-0.9 s now and then on MI355X / ROCm 7.2 (measured with HPRLP_TIMING=1: one
 // hipMalloc call, a third of config 5's time-to-tolerance); blocks of 1 MiB and more therefore go back to this cache instead of
-// the driver and are handed out again to requests of the same size class (rounded up to 2 MiB).  Per device, mutex-protected,
-// capped at kDeviceCacheCapBytes; HPRLP_NO_ALLOC_CACHE=1 switches it off, hprlp_release_device_cache() returns everything.
+// the driver and are handed out again to requests of the same size class (rounded up to 2 MiB).  Keyed by the device that OWNS
+// the block (not the freeing thread's current device), mutex-protected, capped PER DEVICE at min(kDeviceCacheCapBytes, a third of
+// the device's memory); a hipMalloc that runs out of memory trims the cache and retries once (device_malloc_or_trim);
+// HPRLP_NO_ALLOC_CACHE=1 switches it off, hprlp_release_device_cache() returns everything.
 constexpr size_t kDeviceCacheMinBytes = size_t(1) << 20;
 constexpr size_t kDeviceCacheCapBytes = size_t(96) << 30;
 void *device_cache_get(size_t bytes, size_t *capacity);  // nullptr: nothing suitable cached
 bool device_cache_put(void *p, size_t capacity);        // false: not cached (caller frees)
 void device_cache_trim();
+void *device_malloc_or_trim(size_t bytes);              // hipMalloc; on out-of-memory: trim the cache, retry once, then throw
 
 // Device buffer with RAII; sized in elements.
 template <class T>
@@ -84,7 +87,7 @@ struct DBuf {
             }
         }
         const auto t0 = time_now();
-        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+        p = static_cast<T *>(device_malloc_or_trim(bytes));
         cap_bytes = bytes;
         AllocStats::get().malloc_s += time_since(t0);
         ++AllocStats::get().mallocs;

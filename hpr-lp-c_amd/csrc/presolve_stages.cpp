@@ -358,8 +358,10 @@ void BoundStage::postsolve(const double *xr, const double *yr, const double *zr,
     std::copy(xr, xr + n_, x);
     std::copy(yr, yr + m_, y);
     std::copy(zr, zr + n_, z);
-    const int *rp = org_->A->rowPtr, *ci = org_->A->colIndex;
-    const double *av = org_->A->value;
+    // the stage's own copy has the input's rows, entries and indices (only bounds differ): no pointer into the caller's
+    // model is followed after run()
+    const int *rp = reduced_->A->rowPtr, *ci = reduced_->A->colIndex;
+    const double *av = reduced_->A->value;
     // a reduced cost leaning on a bound that only this stage gave the column belongs to the row that implied the bound
     for (size_t s = recs_.size(); s-- > 0;) {
         const Rec &r = recs_[s];

@@ -462,6 +462,7 @@ bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
 // CSR of the model) and the arrays of AT (device transpose, not yet described) are in place.  On success A's device
 // arrays hold P A Q, A is re-described (row blocks, tiled copy) and perm_r / perm_c are set.
 bool Solver::try_reorder(const LP_info_cpu *model) {
+    if (!allow_reorder) return false;
     const char *no = std::getenv("HPRLP_NO_REORDER");
     if (no && no[0] == '1') return false;
     const char *nt = std::getenv("HPRLP_NO_TILED");

@@ -92,6 +92,9 @@ struct Solver {
     // (get / set_vector, collect_solution) speaks the caller's numbering.
     std::vector<int> perm_r, perm_c;
     double reorder_time = 0.0, reorder_before = 0.0, reorder_after = 0.0;
+    // Callers that read A / AT / row_norm / col_norm directly in the caller's numbering (solve_batched) switch the
+    // ordering off before setup(): they would otherwise pair permuted scale vectors with unpermuted panels.
+    bool allow_reorder = true;
     bool try_reorder(const LP_info_cpu *model);
     bool pb_fallback_wanted(const DeviceMatrix &M) const;  // unstructured large matrix: tiled form without dense-tile requirement
     // Hand-off of the remainder products between the two kernels of an iteration (kernels.h: FarPush).  far_A_ready: A's

@@ -32,6 +32,9 @@ const char *hprlp_backend(void); /* "hip-gfx950" */
  * behind a large hipFree stalls for up to a second on this platform); this returns them all to the driver.  HPRLP_NO_ALLOC_CACHE=1
  * disables the cache. */
 void hprlp_release_device_cache(void);
+/* Bookkeeping self-test of that cache without a GPU (blocks are filed under the device that owns them, the cap is per
+ * device): 0 = passed, else the number of the failed check. */
+int hprlp_alloc_cache_selftest(void);
 
 /* copy_lpinfo_to_device + allocate_memory (reference src/preprocess.cu:66-256): uploads A, builds A^T
  * and the wave row-block descriptors, allocates the work vectors.  Does not scale. */
@@ -144,7 +147,9 @@ hprlp_solver *hprlp_solver_create_local_from_shard(const hprlp_shard *shard, con
 
 /* ---- presolve / postsolve as separate host-side steps (what solve() does around the iteration when
  * use_presolve is set; replaces the reference's forked PSLP worker, src/pslp_integration.cpp:628-787).
- * hprlp_presolve_run returns NULL when the model is left unchanged or looks infeasible/unbounded. */
+ * hprlp_presolve_run returns NULL when the model is left unchanged or looks infeasible/unbounded.
+ * LIFETIME: the handle keeps a pointer to `model` (postsolve reads the original rows and costs); the model must stay
+ * alive and unchanged until hprlp_presolve_free(). */
 typedef struct hprlp_presolve hprlp_presolve;
 hprlp_presolve *hprlp_presolve_run(const LP_info_cpu *model);
 const LP_info_cpu *hprlp_presolve_reduced(const hprlp_presolve *p); /* owned by p */

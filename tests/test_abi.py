@@ -191,3 +191,11 @@ def test_reference_examples_compile_and_link_unchanged(src, tmp_path):
     # the symbols it binds are ours
     nm = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
     assert re.search(r"\b(solve|create_model_from_arrays|create_model_from_mps|solve_batched)\b", nm)
+
+
+def test_device_block_cache_is_keyed_by_the_owning_device():
+    """csrc/alloc.cpp: freed device blocks are filed under the device that owns them (not the freeing thread's current
+    device) and only handed to requests of that device; the cap is per device.  Pure bookkeeping, runs without a GPU."""
+    L = hprlp.lib()
+    L.hprlp_alloc_cache_selftest.restype = C.c_int
+    assert L.hprlp_alloc_cache_selftest() == 0

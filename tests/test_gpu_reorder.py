@@ -164,3 +164,39 @@ def test_permuted_grid_is_reordered_on_the_device(gpu):
     for name in NAMES_N + NAMES_M:
         np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-12, err_msg=name)
     s.close(); model.free()
+
+
+def test_solve_batched_on_a_matrix_the_single_solver_would_reorder(gpu, lp):
+    """solve_batched builds its shared matrix with Solver::setup(); that must NOT apply the locality ordering (the panels,
+    the scale vectors it downloads and the returned X / Y / Z are all in the caller's numbering).  Two members on the
+    permuted 1.6 M x 1.6 M LP, checked by the KKT conditions recomputed here on the LP as given and against single solves
+    (which do reorder).  With the ordering applied silently the members would be solved against a different LP."""
+    m, n = lp["m"], lp["n"]
+    B, tol = 2, 1e-4
+    rng = np.random.default_rng(3)
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    Cm = np.stack([lp["c"], lp["c"] + 0.05 * rng.uniform(0.0, 1.0, size=n)], axis=1)
+    AL = np.repeat(lp["AL"][:, None], B, axis=1)
+    AU = np.repeat(lp["AU"][:, None], B, axis=1)
+    L = np.repeat(lp["l"][:, None], B, axis=1)
+    U = np.where(np.isfinite(lp["u"]), lp["u"], 50.0)
+    U = np.repeat(U[:, None], B, axis=1)
+    prm = hprlp.Parameters(stop_tol=tol, max_iter=30000, use_presolve=False)
+    r = hprlp.solve_batched(model, Cm, AL, AU, L, U, None, prm)
+    assert r["status"] == ["OPTIMAL"] * B, r["status"]
+    A = sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(m, n))
+    for k in range(B):
+        x, y, z = r["x"][:, k], r["y"][:, k], r["z"][:, k]
+        Ax = A @ x
+        viol = np.maximum(np.maximum(np.where(np.isfinite(AL[:, k]), AL[:, k] - Ax, 0), np.where(np.isfinite(AU[:, k]), Ax - AU[:, k], 0)), 0)
+        b = np.maximum(np.where(np.isfinite(AL[:, k]), np.abs(AL[:, k]), 0), np.where(np.isfinite(AU[:, k]), np.abs(AU[:, k]), 0))
+        assert np.linalg.norm(viol) <= 3 * tol * (1 + np.linalg.norm(b)), k
+        rd = Cm[:, k] - A.T @ y - z
+        assert np.linalg.norm(rd) <= 3 * tol * (1 + np.linalg.norm(Cm[:, k])), k
+        assert abs(r["primal_obj"][k] - float(Cm[:, k] @ x)) <= 1e-8 * (1 + abs(r["primal_obj"][k]))
+    assert abs(r["primal_obj"][0] - lp["obj_star"]) <= 1e-3 * (1 + abs(lp["obj_star"]))
+    mk = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], AL[:, 1], AU[:, 1], L[:, 1], U[:, 1], Cm[:, 1])
+    s1 = mk.solve(prm)  # single-LP path: reorders
+    assert s1.status == "OPTIMAL"
+    assert abs(s1.primal_obj - r["primal_obj"][1]) <= 10 * tol * (1 + abs(s1.primal_obj))
+    mk.free(); model.free()
