@@ -286,6 +286,71 @@ def xhalf_kernel_label(tiled):
             "(hand-off, DESIGN.md section 4); shard-shaped matrices: k_tiled_part + k_tiled_finish)")
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, one
+    fresh child process per GPU, BEFORE this process has made any HIP call -- the parent loads neither torch nor
+    lib/libhprlp.so, never touches a GPU and never execs; it relays rank 0's JSON line and the children's exit codes.
+    A run that cannot give N ranks exits non-zero instead of printing a line for fewer GPUs."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HPRLP_BENCH_LAUNCHER="self-spawned")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), start_new_session=False))
+    log(f"[bench] --gpus {n} without a launcher: started ranks as child processes {[p.pid for p in procs]} (127.0.0.1:{port})")
+    # a rank that dies takes the others with it (they would wait for it at the next gloo collective until its time-out)
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    alive = set(range(n))
+    while alive and failed is None:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        time.sleep(2.0)  # let the others print their own error
+        for r in sorted(alive):
+            if procs[r].poll() is None:
+                procs[r].terminate()  # exactly the PIDs started above
+        for r in sorted(alive):
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        reader.join(timeout=5)
+        log(f"[bench] rank {failed[0]} exited with code {failed[1]}: no result line (ranks {[p.returncode for p in procs]})")
+        return failed[1] if failed[1] > 0 else 1
+    reader.join()
+    line = None
+    for ln in (out0[0] if out0 else b"").decode().splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        log("[bench] rank 0 printed no JSON line")
+        return 1
+    got = json.loads(line).get("n_gpus")
+    if got != n:
+        log(f"[bench] rank 0 reported n_gpus={got}, wanted {n}: refusing to pass the line on")
+        return 1
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +361,10 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the config-2/3 side measurements")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-tolerance solve of the workload")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     # The library prints its banner / "problem information" lines to the C-level stdout like the
     # reference does; stdout of this script must carry exactly one JSON line, so route fd 1 to
     # stderr for the duration of the run and keep the real stdout for the result.
@@ -308,18 +377,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("HPRLP_BENCH_ONE_DEVICE"):  # rehearsal of the multi-rank path on a one-GPU box (if RCCL allows it)
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:  # never print a line whose n_gpus is not what --gpus asked for
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}), or leave WORLD_SIZE unset and bench.py starts the ranks itself")
 
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # gloo carries only the bootstrap (RCCL unique id), barriers and the max-over-ranks of the
+        # gloo carries only the bootstrap (RCCL unique ids), barriers and the max-over-ranks of the
         # timing; the data path is RCCL inside lib/libhprlp.so.
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
+        ndev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if local_rank >= ndev:
+            log(f"[bench] rank {rank}: needs GPU {local_rank}, this box has {ndev} -- the RCCL communicator cannot be built")
 
     m, n, per_row, band = WORKLOADS[args.workload]
     t0 = time.time()
@@ -338,13 +410,36 @@ def main():
             log(f"[bench] rank 0 assembled its shard of {args.workload} ({m}x{n}, nnz={nnz} over {world} ranks; {nnz_loc} here) "
                 f"in {time.time() - t0:.1f}s, peak host RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.2f} GB")
         t0 = time.time()
-        uid = np.zeros(128, np.uint8)
-        if rank == 0 and H.lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 128) != 0:
-            raise RuntimeError(H.last_error())
+        # two unique ids: the exchange stream gets its own communicator (no communicator is driven from two streams)
+        uid = np.zeros(256 + 1, np.uint8)
+        if rank == 0:
+            log(f"[bench] rank 0: creating the RCCL unique ids for {world} ranks")
+            if H.lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 256) != 0:
+                log(f"[bench] rank 0: FAILED at communicator creation (unique id): {H.last_error()}")
+                uid[256] = 1
         tu = torch.from_numpy(uid)
         dist.broadcast(tu, src=0)
-        s = H.Solver.create_dist_from_shard(shard, prm, rank, world, uid)
+        if uid[256]:
+            raise SystemExit(3)  # every rank leaves: no line is better than a line for fewer GPUs
+        log(f"[bench] rank {rank}: creating its RCCL communicators (rank {rank} of {world}, device {local_rank})")
+        try:
+            s = H.Solver.create_dist_from_shard(shard, prm, rank, world, uid[:256])
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] rank {rank}: FAILED at communicator / solver creation: {e}")
+            raise SystemExit(3)
         dinfo = s.dist_info()
+        cinfo = s.dist_comm_info()
+        # what RCCL itself says, from every rank: communicator sizes and the device each rank sits on
+        tc = torch.tensor([cinfo["comm_ranks"], cinfo["comm_device"], cinfo["xcomm_ranks"], cinfo["hip_device"]], dtype=torch.int64)
+        allc = [torch.zeros_like(tc) for _ in range(world)]
+        dist.all_gather(allc, tc)
+        comm_report = {"rccl_ranks": int(min(int(t[0]) for t in allc)),
+                       "rccl_ranks_exchange_comm": int(min(int(t[2]) for t in allc)),
+                       "devices": [int(t[1]) for t in allc], "hip_devices": [int(t[3]) for t in allc],
+                       "overlap": bool(cinfo["overlap"])}
+        if comm_report["rccl_ranks"] != world or len(set(comm_report["devices"])) != world:
+            log(f"[bench] rank {rank}: RCCL reports {comm_report}: not {world} ranks on {world} distinct devices")
+            raise SystemExit(3)
         del shard
     else:
         lp = banded_lp(m, n, per_row, band)
@@ -357,6 +452,7 @@ def main():
         t0 = time.time()
         s = H.Solver(model, prm)
         dinfo = None
+        comm_report = None
         obj_star = lp["obj_star"]
         if args.no_solve:
             model.free()
@@ -375,6 +471,7 @@ def main():
     s.iterate(args.warmup)
     if dist:
         dist.barrier()
+    torch.cuda.set_device(local_rank)  # (for torch.cuda.synchronize below; the library selects its device itself)
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     tm = s.time_iterations(0, args.steps, 1)  # eager launches with HIP events around every kernel
@@ -418,6 +515,9 @@ def main():
                                    f"({'row-partitioned over %d GPUs, 2 RCCL exchanges per iteration' % P if P > 1 else 'one GPU'})",
                        "reordered_at_setup": bool(info.get("reordered")),
                        "m": m, "n": n, "nnz": nnz, "parallelism": f"rowpart{P}",
+                       "launcher": os.environ.get("HPRLP_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
+                                                  else "single process" if P == 1 else "external"),
+                       "rccl": comm_report,
                        "exchange": None if dinfo is None else {
                            "kind_m": "neighbour send/recv" if dinfo["m_sparse"] else "all-gather",
                            "kind_n": "neighbour send/recv" if dinfo["n_sparse"] else "all-gather",

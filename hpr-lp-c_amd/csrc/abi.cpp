@@ -18,7 +18,8 @@ using namespace hprlp;
 
 struct hprlp_solver {
     Solver s;
-    Comm *comm = nullptr;  // owned; destroyed after the solver's device state
+    Comm *comm = nullptr;   // owned; destroyed after the solver's device state
+    Comm *xcomm = nullptr;  // owned; the exchange stream's own communicator (second unique id), may be null
     ~hprlp_solver() {}
 };
 
@@ -332,6 +333,23 @@ extern "C" void hprlp_local_group_destroy(hprlp_local_group *h) {
     delete h;
 }
 
+// A launcher that hands over TWO unique ids (256 bytes, hprlp_dist_unique_id with a 256-byte buffer) gets a second
+// communicator for the exchange stream: the exchanges that overlap the local part of a half-step are enqueued on another
+// stream than the collectives of the check iterations, and one RCCL communicator must not be driven from two streams.
+static void make_exchange_comm(hprlp_solver *h, int rank, int size, const void *unique_id, int id_bytes, int device) {
+    if (!unique_id || id_bytes < 256) return;
+    h->xcomm = make_rccl_comm(rank, size, static_cast<const char *>(unique_id) + 128, 128, device);
+    h->s.xcomm = h->xcomm;
+}
+
+static void destroy_handle(hprlp_solver *h) {
+    if (!h) return;
+    Comm *c = h->comm, *x = h->xcomm;
+    delete h;  // the solver first: its device state (and a background tiling job) goes before the transport
+    delete x;
+    delete c;
+}
+
 // rank `rank` of `size`: RCCL communicator from unique_id, or (group != NULL) the in-process group
 static hprlp_solver *create_sharded(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
                                     const void *unique_id, int id_bytes, hprlp_local_group *group) {
@@ -354,6 +372,7 @@ static hprlp_solver *create_sharded(const LP_info_cpu *model, const HPRLP_parame
         } else if (size > 1 || (unique_id && id_bytes >= 128)) {
             // a unique id given with size 1 builds a one-rank RCCL communicator (exercises the collective path)
             h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
+            make_exchange_comm(h, rank, size, unique_id, id_bytes, p->device_number);
         }
         h->s.setup_shard(sh.m, sh.n, sh.row_off, sh.m_loc, sh.col_off, sh.n_loc, sh.A_rowptr, sh.A_col, sh.A_val,
                          sh.AT_rowptr, sh.AT_col, sh.AT_val, sh.AL, sh.AU, sh.l, sh.u, sh.c, sh.obj_constant, p, h->comm);
@@ -361,11 +380,7 @@ static hprlp_solver *create_sharded(const LP_info_cpu *model, const HPRLP_parame
         return h;
     } catch (const std::exception &e) {
         set_last_error(e.what());
-        if (h) {  // the solver first: a background tiling job may still read the shard arrays (its destructor joins it)
-            Comm *c = h->comm;
-            delete h;
-            delete c;
-        }
+        destroy_handle(h);  // the solver first: a background tiling job may still read the shard arrays (its destructor joins it)
         hprlp_free_shard(&sh);
         return nullptr;
     }
@@ -392,18 +407,16 @@ static hprlp_solver *create_from_shard(const hprlp_shard *sh, const HPRLP_parame
         h->s.verbose = false;
         HIP_CHECK(hipSetDevice(p->device_number));
         if (group) h->comm = make_local_comm(group->g, rank);
-        else if (size > 1 || (unique_id && id_bytes >= 128))
+        else if (size > 1 || (unique_id && id_bytes >= 128)) {
             h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
+            make_exchange_comm(h, rank, size, unique_id, id_bytes, p->device_number);
+        }
         h->s.setup_shard(sh->m, sh->n, sh->row_off, sh->m_loc, sh->col_off, sh->n_loc, sh->A_rowptr, sh->A_col, sh->A_val, sh->AT_rowptr,
                          sh->AT_col, sh->AT_val, sh->AL, sh->AU, sh->l, sh->u, sh->c, sh->obj_constant, p, h->comm);
         return h;
     } catch (const std::exception &e) {
         set_last_error(e.what());
-        if (h) {
-            Comm *c = h->comm;
-            delete h;
-            delete c;
-        }
+        destroy_handle(h);
         return nullptr;
     }
 }
@@ -441,6 +454,23 @@ extern "C" int hprlp_solver_dist_info(hprlp_solver *h, long out[8]) {
     return 0;
 }
 
+// out = {ranks / this rank / device as the main communicator reports them (RCCL: ncclCommCount, ncclCommUserRank,
+//        ncclCommCuDevice), the same three of the exchange stream's communicator (0, -1, -1 if there is none), the
+//        solver's HIP device, 1 if the exchange overlaps the local part of the half-steps}
+extern "C" int hprlp_solver_dist_comm_info(hprlp_solver *h, long out[8]) {
+    GUARD_BEGIN
+    if (!h || !out) throw std::runtime_error("null solver / output");
+    const Solver &s = h->s;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    out[1] = out[2] = out[4] = out[5] = -1;
+    if (s.comm) { out[0] = s.comm->reported_ranks(); out[1] = s.comm->reported_rank(); out[2] = s.comm->reported_device(); }
+    if (s.xcomm) { out[3] = s.xcomm->reported_ranks(); out[4] = s.xcomm->reported_rank(); out[5] = s.xcomm->reported_device(); }
+    out[6] = s.prm.device_number;
+    out[7] = s.overlap_enabled ? 1 : 0;
+    return 0;
+    GUARD_END(-1)
+}
+
 // One grouped send/recv of `count` doubles from this rank to ITSELF through the solver's communicator (pattern
 // i -> 3 i + 1), checked on the host: exercises the point-to-point entry points of the transport (RCCL: ncclGroupStart /
 // ncclSend / ncclRecv / ncclGroupEnd) on a box where no second rank can exist.  0 = delivered intact.
@@ -466,10 +496,7 @@ extern "C" int hprlp_solver_dist_loopback(hprlp_solver *h, int count) {
 
 extern "C" void hprlp_solver_destroy(hprlp_solver *h) {
     try {
-        if (!h) return;
-        Comm *c = h->comm;
-        delete h;
-        delete c;
+        destroy_handle(h);
     } catch (...) {
     }
 }

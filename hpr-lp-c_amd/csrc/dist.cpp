@@ -32,6 +32,9 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -58,6 +61,9 @@ RcclApi &rccl() {
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
+    api.CommCuDevice = reinterpret_cast<decltype(api.CommCuDevice)>(sym("ncclCommCuDevice"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
@@ -76,6 +82,18 @@ struct RcclComm : Comm {
     ncclComm_t comm = nullptr;
     ~RcclComm() override {
         if (comm) (void)rccl().CommDestroy(comm);
+    }
+    int reported_ranks() const override {
+        int v = -1;
+        return rccl().CommCount(comm, &v) == ncclSuccess ? v : -1;
+    }
+    int reported_rank() const override {
+        int v = -1;
+        return rccl().CommUserRank(comm, &v) == ncclSuccess ? v : -1;
+    }
+    int reported_device() const override {
+        int v = -1;
+        return rccl().CommCuDevice(comm, &v) == ncclSuccess ? v : -1;
     }
     void allgather_inplace(double *buf, size_t chunk, hipStream_t s) override {
         check(rccl().AllGather(buf + static_cast<size_t>(rank) * chunk, buf, chunk, ncclDouble, comm, s), "allgather");
@@ -205,11 +223,17 @@ Comm *make_local_comm(LocalGroup *g, int rank) {
     return c;
 }
 
+// One id per 128 bytes of the buffer, at most two: the second one is for the exchange stream's own communicator
+// (Solver::xcomm) -- no communicator is driven from two streams.
 void rccl_get_unique_id(void *out, size_t bytes) {
+    static_assert(sizeof(ncclUniqueId) == 128, "the launcher broadcasts 128 bytes per id");
     if (bytes < sizeof(ncclUniqueId)) throw std::runtime_error("unique-id buffer too small");
-    ncclUniqueId id;
-    check(rccl().GetUniqueId(&id), "get unique id");
-    std::memcpy(out, &id, sizeof(id));
+    const size_t ids = std::min<size_t>(bytes / sizeof(ncclUniqueId), 2);
+    for (size_t k = 0; k < ids; ++k) {
+        ncclUniqueId id;
+        check(rccl().GetUniqueId(&id), "get unique id");
+        std::memcpy(static_cast<char *>(out) + k * sizeof(id), &id, sizeof(id));
+    }
 }
 
 Comm *make_rccl_comm(int rank, int size, const void *unique_id, size_t id_bytes, int device) {

@@ -32,6 +32,11 @@ struct Comm {
     virtual void exchange(const P2P *ops, int nops, hipStream_t s) = 0;
     // true if the calls above block the host until the data has moved (the in-process group); RCCL only enqueues
     virtual bool host_blocking() const { return false; }
+    // what the transport itself reports (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice); the in-process group
+    // answers from its own fields with device -1
+    virtual int reported_ranks() const { return size; }
+    virtual int reported_rank() const { return rank; }
+    virtual int reported_device() const { return -1; }
 };
 
 // RCCL implementation; librccl.so is loaded at run time on first use so that a single-GPU process

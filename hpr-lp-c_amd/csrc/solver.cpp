@@ -653,14 +653,16 @@ void HaloPlan::build(Comm *comm, const int *cols, long nnz, int total, int chunk
 
 void Solver::gather_on(double *gbuf, bool is_m, hipStream_t s) {
     if (!comm) return;  // (a one-rank communicator still runs the collective: used to test the RCCL path)
+    // the exchange stream has its own communicator (one communicator, one stream)
+    Comm *cm = (xcomm && comm_stream && s == comm_stream) ? xcomm : comm;
     HaloPlan &h = is_m ? halo_m : halo_n;
     if (!h.sparse) {
-        const size_t chunk = static_cast<size_t>(is_m ? m_pad : n_pad) / comm->size;
-        comm->allgather_inplace(gbuf, chunk, s);
+        const size_t chunk = static_cast<size_t>(is_m ? m_pad : n_pad) / cm->size;
+        cm->allgather_inplace(gbuf, chunk, s);
         return;
     }
     launch_pack(gbuf, h.send_idx.p, h.sendbuf.p, h.nsend, s);
-    comm->exchange(h.ops.data(), static_cast<int>(h.ops.size()), s);
+    cm->exchange(h.ops.data(), static_cast<int>(h.ops.size()), s);
     launch_scatter(gbuf, h.recv_idx.p, h.recvbuf.p, h.nrecv, s);
 }
 
@@ -672,8 +674,12 @@ void Solver::verify_exchange() {
     if (!comm || comm->size <= 1) return;
     const bool inject = std::getenv("HPRLP_DIST_SELFTEST_FAIL") != nullptr;  // tests: first verdict reads "failed"
     DBuf<double> flag(1);
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool is_m = pass == 0;
+    // with a second communicator both transports are tested: passes 0, 1 through comm on the solver stream, passes 2, 3
+    // through xcomm on the exchange stream
+    if (xcomm) ensure_comm_stream();
+    for (int pass = 0; pass < (xcomm ? 4 : 2); ++pass) {
+        const bool is_m = (pass & 1) == 0;
+        hipStream_t vs = pass >= 2 ? comm_stream : stream;
         HaloPlan &h = is_m ? halo_m : halo_n;
         const int total = is_m ? m : n, pad = is_m ? m_pad : n_pad;
         const int chunk = pad / comm->size;
@@ -683,8 +689,8 @@ void Solver::verify_exchange() {
         DBuf<double> g(static_cast<size_t>(pad));
         for (int attempt = 0;; ++attempt) {
             g.upload(init.data(), init.size());
-            gather(g.p, is_m);
-            HIP_CHECK(hipStreamSynchronize(stream));
+            gather_on(g.p, is_m, vs);
+            HIP_CHECK(hipStreamSynchronize(vs));
             g.download(got.data(), got.size());
             double bad = 0.0;
             if (h.sparse) {
@@ -927,9 +933,7 @@ static void split_shard(const DeviceMatrix &M, int lo, int hi, Solver::SplitShar
     if (out->loc.view.tiled.valid) out->loc.view.tiled.grid = 8 * out->loc.view.tiled.per;
 }
 
-void Solver::prepare_overlap() {
-    finish_tiling();
-    HIP_CHECK(hipStreamSynchronize(stream));
+void Solver::ensure_comm_stream() {
     if (!comm_stream) {
         // highest priority: the few workgroups of the exchange must not queue behind the half-step's grid
         int prio_low = 0, prio_high = 0;
@@ -939,6 +943,12 @@ void Solver::prepare_overlap() {
         HIP_CHECK(hipEventCreateWithFlags(&ev_done_x, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_done_y, hipEventDisableTiming));
     }
+}
+
+void Solver::prepare_overlap() {
+    finish_tiling();
+    HIP_CHECK(hipStreamSynchronize(stream));
+    ensure_comm_stream();
     ovAT.reset(new SplitShard);  // A^T shard: n_loc rows, columns = rows of A; this rank owns y[row_off, row_off + m_loc)
     split_shard(AT, row_off, row_off + m_loc, ovAT.get(), stream);
     ovA.reset(new SplitShard);   // A shard: m_loc rows; this rank owns x_hat[col_off, col_off + n_loc)

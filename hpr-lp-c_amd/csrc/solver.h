@@ -85,6 +85,10 @@ struct Solver {
     bool verbose = true;
     hipStream_t stream = nullptr;
     Comm *comm = nullptr;
+    // Second communicator (its own unique id) for the exchanges enqueued on comm_stream beside the local part of a
+    // half-step: a communicator is only ever driven from ONE stream.  Null: the in-process group (host-blocking, no
+    // concurrency) or a launcher that handed over a single id -- then comm serves both streams as in rounds 1-2.
+    Comm *xcomm = nullptr;
 
     DeviceMatrix A, AT;  // A: m_loc x n (global columns); AT: n_loc x m (global columns)
     // Set-up time locality ordering (reorder.cpp): when set, the device holds P A Q and all per-row / per-column vectors
@@ -174,6 +178,7 @@ struct Solver {
     bool overlap_enabled = false, overlap_ready = false, y_exchange_pending = false;
     bool overlap_spmv_first = false;  // launch order of the local SpMV and the exchange (launch_normal_pair)
     void prepare_overlap();
+    void ensure_comm_stream();
     void allreduce_scalars();
     void finish_tiling();  // adopt tiled copies whose background build is still pending (no-op otherwise)
 

@@ -353,7 +353,7 @@ class Solver:
         self.model = model
         cp = (param or Parameters()).to_c()
         uid = None if unique_id is None else unique_id.ctypes.data_as(C.c_void_p)
-        self.h = L.hprlp_solver_create_dist(model._ptr, C.byref(cp), rank, size, uid, 0 if unique_id is None else 128)
+        self.h = L.hprlp_solver_create_dist(model._ptr, C.byref(cp), rank, size, uid, 0 if unique_id is None else len(unique_id))
         if not self.h:
             raise RuntimeError("hprlp_solver_create_dist failed: " + last_error())
         self._set_local_sizes(rank, size)
@@ -377,7 +377,7 @@ class Solver:
                                                               C.c_void_p, C.c_int]
             uid = None if unique_id is None else unique_id.ctypes.data_as(C.c_void_p)
             self.h = L.hprlp_solver_create_dist_from_shard(C.byref(shard.c_shard), C.byref(cp), rank, size, uid,
-                                                           0 if unique_id is None else 128)
+                                                           0 if unique_id is None else len(unique_id))
         if not self.h:
             raise RuntimeError("hprlp_solver_create_dist_from_shard failed: " + last_error())
         self.row_off, self.m_loc, self.col_off, self.n_loc = shard.row_off, shard.m_loc, shard.col_off, shard.n_loc
@@ -436,10 +436,21 @@ class Solver:
         keys = ("m_sparse", "m_sent", "m_received", "n_sparse", "n_sent", "n_received", "m_requests", "n_requests")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def dist_comm_info(self):
+        """What the transport reports (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice) for the main communicator
+        and for the exchange stream's own one (ranks 0 if there is none)."""
+        L = lib()
+        L.hprlp_solver_dist_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        out = (C.c_long * 8)()
+        self._chk(L.hprlp_solver_dist_comm_info(self.h, out))
+        keys = ("comm_ranks", "comm_rank", "comm_device", "xcomm_ranks", "xcomm_rank", "xcomm_device", "hip_device", "overlap")
+        return dict(zip(keys, [int(v) for v in out]))
+
     @staticmethod
-    def dist_unique_id():
-        uid = np.zeros(128, np.uint8)
-        if lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 128) != 0:
+    def dist_unique_id(ids=1):
+        """ids=2: a second id for the exchange stream's own communicator (one communicator, one stream)."""
+        uid = np.zeros(128 * ids, np.uint8)
+        if lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 128 * ids) != 0:
             raise RuntimeError(last_error())
         return uid
 

@@ -113,7 +113,10 @@ int hprlp_partition(int total, int parts, int rank, int *offset, int *count);
 /* host only: cut this rank's shard out of a full model (arrays malloc'd; release with hprlp_free_shard) */
 int hprlp_extract_shard(const LP_info_cpu *model, int rank, int size, hprlp_shard *out);
 void hprlp_free_shard(hprlp_shard *s);
-/* rank 0: create the 128-byte RCCL unique id; the launcher broadcasts it (bench.py: torch.distributed) */
+/* rank 0: create the RCCL unique id(s), 128 bytes each; the launcher broadcasts them (bench.py: torch.distributed).
+ * bytes >= 256 yields TWO ids: hprlp_solver_create_dist* called with id_bytes >= 256 then builds a second communicator
+ * for the exchange stream (exchanges that overlap the local part of a half-step), so that no communicator is driven
+ * from two streams; with one id the single communicator serves both. */
 int hprlp_dist_unique_id(void *out, int bytes);
 /* every rank: create the solver for its shard of `model` (param->device_number selects the GPU).
  * get_vector/run then return this rank's slices; scalars/residuals are global. */
@@ -131,6 +134,10 @@ hprlp_solver *hprlp_solver_create_dist_from_shard(const hprlp_shard *shard, cons
  * overrides (same value on every rank).
  * out = {m-vectors sparse?, entries sent, received, n-vectors sparse?, sent, received, all ranks' requests m, n} */
 int hprlp_solver_dist_info(hprlp_solver *s, long out[8]);
+/* What the transport itself reports: out = {ranks, this rank, device of the main communicator (RCCL: ncclCommCount,
+ * ncclCommUserRank, ncclCommCuDevice), the same three of the exchange stream's communicator (0, -1, -1 without one),
+ * the solver's HIP device, 1 if exchanges overlap the half-steps}.  bench.py prints these as rccl_ranks / devices. */
+int hprlp_solver_dist_comm_info(hprlp_solver *s, long out[8]);
 /* Test hook: one grouped send/recv of `count` doubles from this rank to itself through the solver's communicator,
  * verified on the host (0 = intact).  Exercises the point-to-point transport calls where no second rank exists. */
 int hprlp_solver_dist_loopback(hprlp_solver *s, int count);

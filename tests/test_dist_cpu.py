@@ -101,3 +101,38 @@ def test_threaded_host_transpose_equals_sequential():
     L.hprlp_free_shard.argtypes = [C.POINTER(Shard)]
     L.hprlp_free_shard(C.byref(sh))
     model.free()
+
+
+ROOT = os.path.dirname(HERE)
+
+
+def _bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=240)
+
+
+def test_bench_gpus2_without_a_launcher_starts_two_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start two ranks itself (child processes, the parent makes no HIP
+    call), both must get as far as building their RCCL communicators, and -- no GPU here -- the run must end non-zero WITHOUT
+    a result line: never a line that says n_gpus 1 for --gpus 2."""
+    r = _bench(["--gpus", "2", "--workload", "c5_tiny", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-side", "--no-solve"])
+    err = r.stderr.decode()
+    assert r.returncode != 0, err[-2000:]
+    assert r.stdout.decode().strip() == "", r.stdout
+    assert "started ranks as child processes" in err
+    assert "rank 0 assembled its shard of c5_tiny" in err and "over 2 ranks" in err
+    assert "rank 0: creating the RCCL unique ids for 2 ranks" in err
+    # each rank either reached communicator creation or was told by rank 0 that the id could not be made; both say FAILED
+    assert err.count("FAILED at communicator") >= 1
+    assert "no result line" in err
+
+
+def test_bench_refuses_a_world_that_does_not_match_gpus():
+    """Under a launcher whose WORLD_SIZE differs from --gpus the bench refuses (non-zero, no line) instead of measuring
+    another number of GPUs than it was asked for."""
+    r = _bench(["--gpus", "8", "--no-cpu", "--no-side", "--no-solve"], {"WORLD_SIZE": "1", "RANK": "0"}, drop=())
+    assert r.returncode != 0
+    assert r.stdout.decode().strip() == ""
+    assert "--gpus 8 but WORLD_SIZE=1" in r.stderr.decode()

@@ -9,14 +9,21 @@ from conftest import hprlp, lpgen
 pytestmark = pytest.mark.gpu
 
 
-def test_one_rank_rccl_path_equals_plain_solver(gpu):
+@pytest.mark.parametrize("ids", [1, 2])
+def test_one_rank_rccl_path_equals_plain_solver(gpu, ids):
+    """ids = 2: the launcher hands over two unique ids and the exchange stream gets its own communicator (no communicator
+    is driven from two streams); what RCCL reports about both is what bench.py prints as rccl_ranks / devices."""
     lp = lpgen.planted_lp(400, 650, 4000, 91)
     model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
                                  lp["l"], lp["u"], lp["c"])
     prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
     plain = hprlp.Solver(model, prm)
-    uid = hprlp.Solver.dist_unique_id()
+    uid = hprlp.Solver.dist_unique_id(ids)
+    assert len(uid) == 128 * ids and (ids == 1 or not np.array_equal(uid[:128], uid[128:]))
     dist = hprlp.Solver.create_dist(model, prm, 0, 1, uid)
+    ci = dist.dist_comm_info()
+    assert (ci["comm_ranks"], ci["comm_rank"], ci["comm_device"], ci["hip_device"]) == (1, 0, 0, 0), ci
+    assert (ci["xcomm_ranks"], ci["xcomm_rank"], ci["xcomm_device"]) == ((1, 0, 0) if ids == 2 else (0, -1, -1)), ci
     dist.dist_loopback(1 << 18)  # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd: rank 0 to itself, 2 MiB, verified
     out = []
     for s in (plain, dist):
