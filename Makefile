@@ -39,6 +39,16 @@ bin/solve_mps_file: tools/solve_mps_file.cpp lib/libhprlp.so include/HPRLP.h
 	@mkdir -p bin
 	g++ -O2 -std=c++11 -Iinclude -o $@ tools/solve_mps_file.cpp -Llib -lhprlp -Wl,-rpath,'$$ORIGIN/../lib'
 
+# developer variants of the library (kernel experiments, A/B on one GPU box through HPRLP_LIB=lib/variants/libhprlp_<NAME>.so):
+#   make variant NAME=noconf DEFS="-DHPRLP_DBG_NOCONFLICT=1"
+variant:
+	$(MAKE) BUILD=build_variants/$(NAME) CXXFLAGS='$(CXXFLAGS) $(DEFS)' build_variants/$(NAME)/libhprlp.so
+	@mkdir -p lib/variants
+	cp build_variants/$(NAME)/libhprlp.so lib/variants/libhprlp_$(NAME).so
+
+$(BUILD)/libhprlp.so: $(OBJS)
+	$(HIPCC) -shared -fPIC $(HIPFLAGS) -o $@ $(OBJS) -lz -ldl -Wl,--no-undefined
+
 clean:
 	rm -rf $(BUILD) lib bin
-.PHONY: all clean
+.PHONY: all clean variant

@@ -279,9 +279,9 @@ def xhalf_kernel_label(tiled):
     if not tiled & 2:
         return "k_spmv_fused<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern)"
     if os.environ.get("HPRLP_NO_FAR_PUSH", "0") == "1":
-        return ("k_far_products + k_tiled_fused<XEpi<false>> (x-half: SpMV(A^T,y) + prox + Halpern; avg_launch_ms = remainder "
+        return ("k_far_products + k_tiled_fused<XEpi<false, true>> (x-half: SpMV(A^T,y) + prox + Halpern; avg_launch_ms = remainder "
                 "pre-pass + fused kernel, the two launches of the half-step)")
-    return ("k_tiled_fused<XEpi<false>, REP, PUSH=true> (x-half: SpMV(A^T,y) + prox + Halpern in ONE launch; the products of its "
+    return ("k_tiled_fused<XEpi<false, true>, REP, PUSH=true> (x-half: SpMV(A^T,y) + prox + Halpern in ONE launch; the products of its "
             "far-column remainder were written by the preceding y-half's epilogue and its own epilogue writes the y-half's "
             "(hand-off, DESIGN.md section 4); shard-shaped matrices: k_tiled_part + k_tiled_finish)")
 

@@ -255,7 +255,15 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
 // row: tiles ascending from the rotation point, then the tiles below it, remainder entries last --
 // fixed by the matrix, so results are reproducible run to run.
 // ------------------------------------------------------------------------------------------------
+#ifndef HPRLP_DBG_NOBARRIER
+#define HPRLP_DBG_NOBARRIER 0
+#endif
+#if HPRLP_DBG_NOBARRIER
+// timing experiment only (races): the waves of a workgroup never wait for each other
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // field of sweep step r (uniform, 0..255) from the four table registers of a lane (lane l holds steps l, 64 + l, ...):
 // selects on a uniform condition, then one v_readlane -- no control flow
@@ -273,6 +281,43 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 // (the split form): a step cannot be shorter than the HBM latency / ED, so <3, 2>.
 #ifndef HPRLP_DBG_HALF_TILES
 #define HPRLP_DBG_HALF_TILES 0
+#endif
+#ifndef HPRLP_DBG_NOCONFLICT
+#define HPRLP_DBG_NOCONFLICT 0
+#endif
+#ifndef HPRLP_DBG_NOFOLD
+#define HPRLP_DBG_NOFOLD 0
+#endif
+#ifndef HPRLP_DBG_NOTILE
+#define HPRLP_DBG_NOTILE 0
+#endif
+#ifndef HPRLP_DBG_NOREM
+#define HPRLP_DBG_NOREM 0
+#endif
+#ifndef HPRLP_DBG_NOEPI
+#define HPRLP_DBG_NOEPI 0
+#endif
+#ifndef HPRLP_DBG_NOEPISTORE
+#define HPRLP_DBG_NOEPISTORE 0
+#endif
+#ifndef HPRLP_DBG_NOPUSHWORK
+#define HPRLP_DBG_NOPUSHWORK 0
+#endif
+#ifndef HPRLP_SWEEP_ED
+#define HPRLP_SWEEP_ED 2  // fused kernel: entry loads issued this many steps ahead ...
+#define HPRLP_SWEEP_TD 1  // ... and tile loads this many
+#endif
+// Cache policy of the half-step epilogues (XEpi / YEpi).  The streams a row's update reads and writes once per launch (x, c, l, u,
+// last_x / y, AL, AU, last_y) must not push the gathered vector's tiles out of the 4 MiB L2s: with default-policy accesses the
+// tile misses of a config-5 launch were three times those of a launch without epilogue (TCC counters,
+// profiles/r03_tiled_decomposition.md).  1: those loads and the store of x nontemporal; 2 (default): also the store of the
+// published vector (x_hat / y); 3: also the hand-off's scattered stores into P (slower: measured).  Same-box A/B/A/B on config 5:
+// 723 / 731 it/s (0) -> 735-741 (1) -> 752-761 (2) -> 722-735 (3).
+#ifndef HPRLP_EPI_NT
+#define HPRLP_EPI_NT 2
+#endif
+#ifndef HPRLP_DBG_NOBARRIER
+#define HPRLP_DBG_NOBARRIER 0
 #endif
 
 template <int ED, int TD, bool REP, bool STAMP = false>
@@ -295,6 +340,9 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
         eb = step_field(tb0, tb1, tb2, tb3, r);
         ee = step_field(te0, te1, te2, te3, r);
     };
+#if HPRLP_DBG_NOFOLD
+    double dbg_sink = 0.0;
+#endif
     struct Ent {
         d2_t va, vb;
         uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
@@ -346,6 +394,11 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
     auto process = [&](const Ent &E, int k) {
         int col0, eb, ee_;
         getstep(k, col0, eb, ee_);
+#if HPRLP_DBG_NOFOLD
+        // timing experiment only (results are wrong): the entries are consumed without any LDS access
+        if (K * tid < ee_ - eb) dbg_sink += E.va.x + E.va.y + E.vb.x + E.vb.y + static_cast<double>(E.i0 ^ E.i1 ^ E.i2);
+        return;
+#endif
         if (K * tid < ee_ - eb) {
             const double v[K] = {E.va.x, E.va.y, E.vb.x, E.vb.y};
             const uint32_t c0 = E.i0, c1 = E.i1, c2 = E.i2;
@@ -354,8 +407,14 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
             double y[K];
 #pragma unroll
             for (int k2 = 0; k2 < K; ++k2) {
+#if HPRLP_DBG_NOCONFLICT
+                // timing experiment only (results are wrong): every 32-lane half reads / writes 32 distinct bank pairs
+                rw[k2] = ((id[k2] & (R - 1)) & ~31u) | (tid & 31u);
+                y[k2] = ytile[((id[k2] >> kTileRowBits) & ~31u) | (tid & 31u)];
+#else
                 rw[k2] = id[k2] & (R - 1);
                 y[k2] = ytile[id[k2] >> kTileRowBits];
+#endif
             }
             double a[K];
 #pragma unroll
@@ -414,9 +473,14 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
             if (!same_tile(k + TD)) issue_tile(tl, k + TD);
             if (!keep) lds_barrier();  // tile visible
         } else {
+#if HPRLP_DBG_NOTILE
+            // timing experiment only (results are wrong): no tile loads, no LDS stores of the tile (barrier kept)
+            lds_barrier();
+#else
             store_tile(tl);
             issue_tile(tl, k + TD);
             lds_barrier();  // tile visible
+#endif
         }
         process(E, k);
         issue_entries(E, k + ED);
@@ -467,6 +531,9 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
 #pragma unroll
         for (int i = 0; i < 7; ++i) stamp[i] += ph[i];
     }
+#if HPRLP_DBG_NOFOLD
+    if (dbg_sink == 1.2345e-300) acc[tid] = dbg_sink;  // keeps the loads alive
+#endif
 }
 
 // Remainder steps [smid, s1) of a super-block (propagation blocking, tiled.h): the products were written by
@@ -592,7 +659,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
     for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
     epi.begin();
     int wg_round = 0;  // HPRLP_WG_TIMES diagnostic
-    if (t.wgtimes && tid == 0) t.wgtimes[blockIdx.x * 8] = wall_clock64();
+    const bool wg_stamp = t.wgtimes && tid == 0 && (t.wg_filter == 0 || (PUSH && NACC == 0));
+    if (wg_stamp) t.wgtimes[blockIdx.x * 8] = wall_clock64();
     for (int q = slot; q < per; q += slots) {
         const int sb = (blockIdx.x % 8) * per + q;
         if (sb >= t.nsb) break;
@@ -601,25 +669,38 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         const int ncols = A.cols;
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
-        if (s0 < smid) tiled_sweep<2, 1, REP>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
+        if (s0 < smid) tiled_sweep<HPRLP_SWEEP_ED, HPRLP_SWEEP_TD, REP>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
+#if !HPRLP_DBG_NOREM
         tiled_remainder(t, smid, s1, acc, ytile, tid);
+#endif
         lds_barrier();
         const int r0 = sb * R;
+#if HPRLP_DBG_NOEPI
+        const int nr = min(R, A.rows - r0) > 0 && acc[tid] == 1.2345e-300 ? 1 : 0;  // timing experiment only: no epilogue traffic
+#else
         const int nr = min(R, A.rows - r0);
+#endif
+        // the hand-off's list bounds travel while the epilogue runs (a uniform load waited for on the spot is one more
+        // exposed trip to memory per super-block)
+        int pb = 0, pe = 0;
+        if constexpr (PUSH) {
+            pb = epi.push.gptr[sb];
+            pe = epi.push.gptr[sb + 1];
+        }
         for (int i = tid; i < nr; i += NT) {
             const double sv[1] = {acc[i]};
             typename Epi::Row rw = epi.load_row(r0 + i);
             if constexpr (PUSH) acc[i] = epi.apply(r0 + i, rw, sv, racc);  // the published value replaces the row sum
             else epi.apply(r0 + i, rw, sv, racc);
         }
-        if constexpr (PUSH) {
+        if constexpr (PUSH && !HPRLP_DBG_NOEPI && !HPRLP_DBG_NOPUSHWORK) {
             // Hand-off (kernels.h: FarPush): this super-block's fresh values are the source group `sb` of the OTHER matrix'
             // remainder; write its products straight into that matrix' P -- what k_far_products would do in a launch of
             // its own after re-reading the vector from memory.  Same products bit for bit, same slots.
             static_assert(kFarGroup == kTileRows, "a source group of the remainder = the rows of one super-block");
             lds_barrier();
             const FarPush &f = epi.push;
-            const int b = f.gptr[sb], e = f.gptr[sb + 1];
+            const int b = pb, e = pe;
             int k = b + tid;
             for (; k + 3 * NT < e; k += 4 * NT) {
                 double a4[4];
@@ -632,13 +713,24 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
                     c4[u] = __builtin_nontemporal_load(f.lcol + k + u * NT);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) f.P[p4[u]] = a4[u] * acc[c4[u]];
+                for (int u = 0; u < 4; ++u) {
+#if HPRLP_EPI_NT >= 3
+                    __builtin_nontemporal_store(a4[u] * acc[c4[u]], f.P + p4[u]);
+#else
+                    f.P[p4[u]] = a4[u] * acc[c4[u]];
+#endif
+                }
             }
             for (; k < e; k += NT) f.P[f.pos[k]] = f.val[k] * acc[f.lcol[k]];
         }
-        if (t.wgtimes && tid == 0 && ++wg_round <= 6) t.wgtimes[blockIdx.x * 8 + wg_round] = wall_clock64();
+        if (wg_stamp && ++wg_round <= 5) t.wgtimes[blockIdx.x * 8 + wg_round] = wall_clock64();
     }
-    if (t.wgtimes && tid == 0) t.wgtimes[blockIdx.x * 8 + 7] = wall_clock64();
+    if (wg_stamp) {
+        t.wgtimes[blockIdx.x * 8 + 7] = wall_clock64();
+        // where the workgroup ran: HW_ID (id 4; CU_ID bits 11:8, SH_ID 12, SE_ID 15:13) and XCC_ID (id 20) of wave 0
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        t.wgtimes[blockIdx.x * 8 + 6] = (static_cast<unsigned long long>(xcc & 0xfu) << 32) | hw;
+    }
     if constexpr (NACC > 0) {
         // the tile buffer is the scratch of the block reduction: a separate array would push the workgroup past
         // 80 KiB of LDS and leave ONE workgroup per CU (measured: 0.92 instead of 0.73 ms per launch)
@@ -788,7 +880,9 @@ __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const 
 // ------------------------------------------------------------------------------------------------
 
 // x-half (reference update_zx_{normal,check}_kernel, HPR_cuda_kernels.cu:203-247)
-template <bool CHECK>
+// STREAMED (set for matrices that run the tiled kernels, whose gathered vector lives in L2 as tiles): cache policy of the
+// row's own streams, see HPRLP_EPI_NT above; small and mid-size LPs keep default-policy accesses (their vectors live in L2).
+template <bool CHECK, bool STREAMED = false>
 struct XEpi {
     static constexpr int NV = 1;
     static constexpr int NACC = CHECK ? 3 : 0;
@@ -813,7 +907,13 @@ struct XEpi {
         f2 = 1.0 - f1;
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->ky = k;
     }
-    __device__ __forceinline__ Row load_row(int r) const { return Row{x[r], c[r], l[r], u[r], last_x[r]}; }
+    __device__ __forceinline__ Row load_row(int r) const {
+        if constexpr (STREAMED && HPRLP_EPI_NT >= 1)
+            return Row{__builtin_nontemporal_load(x + r), __builtin_nontemporal_load(c + r), __builtin_nontemporal_load(l + r),
+                       __builtin_nontemporal_load(u + r), __builtin_nontemporal_load(last_x + r)};
+        else
+            return Row{x[r], c[r], l[r], u[r], last_x[r]};
+    }
     // returns the value the half-step publishes for the other half's gather (x_hat)
     __device__ __forceinline__ double apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 3 : 1]) const {
         const double gc = s[0] - w.ci;
@@ -821,8 +921,15 @@ struct XEpi {
         const double xb = fmin(w.ui, fmax(w.li, zt));
         const double xh = 2.0 * xb - w.xi;
         const double xn = f2 * xh + f1 * w.lx;
-        x_hat[r] = xh;
-        x[r] = xn;
+#if HPRLP_DBG_NOEPISTORE
+        if (xn == 1.2345e-300)  // timing experiment only: the epilogue's stores are skipped
+#endif
+        {
+            if constexpr (STREAMED && HPRLP_EPI_NT >= 2) __builtin_nontemporal_store(xh, x_hat + r);
+            else x_hat[r] = xh;
+            if constexpr (STREAMED && HPRLP_EPI_NT >= 1) __builtin_nontemporal_store(xn, x + r);
+            else x[r] = xn;
+        }
         if constexpr (CHECK) {
             const double zb = (xb - zt) / sigma;
             const double dx = xb - xh;
@@ -839,7 +946,7 @@ struct XEpi {
 
 // y-half (reference update_y_{normal,check}_kernel, HPR_cuda_kernels.cu:249-295) + the Halpern
 // counter advance (advance_halpern_factors_kernel, :192-200) folded in as the kx hand-off.
-template <bool CHECK>
+template <bool CHECK, bool STREAMED = false>
 struct YEpi {
     static constexpr int NV = 1;
     static constexpr int NACC = CHECK ? 2 : 0;
@@ -864,7 +971,13 @@ struct YEpi {
         hf2 = 1.0 - hf1;
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->kx = k + 1;
     }
-    __device__ __forceinline__ Row load_row(int r) const { return Row{y[r], AL[r], AU[r], last_y[r]}; }
+    __device__ __forceinline__ Row load_row(int r) const {
+        if constexpr (STREAMED && HPRLP_EPI_NT >= 1)
+            return Row{__builtin_nontemporal_load(y + r), __builtin_nontemporal_load(AL + r), __builtin_nontemporal_load(AU + r),
+                       __builtin_nontemporal_load(last_y + r)};
+        else
+            return Row{y[r], AL[r], AU[r], last_y[r]};
+    }
     // returns the value the half-step publishes for the other half's gather (y)
     __device__ __forceinline__ double apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 2 : 1]) const {
         const double v = s[0] - fact1 * w.yi;
@@ -872,7 +985,11 @@ struct YEpi {
         const double yb = fact2 * d;
         const double yh = 2.0 * yb - w.yi;
         const double yn = hf2 * yh + hf1 * w.ly;
-        y[r] = yn;
+#if HPRLP_DBG_NOEPISTORE
+        if (yn == 1.2345e-300)
+#endif
+        if constexpr (STREAMED && HPRLP_EPI_NT >= 2) __builtin_nontemporal_store(yn, y + r);
+        else y[r] = yn;
         if constexpr (CHECK) {
             const double dy = yb - yh;
             const double yo = v + d;
@@ -1119,6 +1236,10 @@ bool launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t
         XEpi<true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, a.x_bar, a.z_bar, a.x_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, a.push};
         return launch_fused(AT, e, s, a.far_ready);
     }
+    if (AT.tiled.valid) {  // the tiled kernels: the row's own streams bypass the L2s (HPRLP_EPI_NT)
+        XEpi<false, true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push};
+        return launch_fused(AT, e, s, a.far_ready);
+    }
     XEpi<false> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push};
     return launch_fused(AT, e, s, a.far_ready);
 }
@@ -1126,6 +1247,10 @@ bool launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t
 bool launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s) {
     if (check) {
         YEpi<true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, a.y_bar, a.y_obj, a.y_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, 0, a.push};
+        return launch_fused(A, e, s, a.far_ready);
+    }
+    if (A.tiled.valid) {
+        YEpi<false, true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, a.push};
         return launch_fused(A, e, s, a.far_ready);
     }
     YEpi<false> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, a.push};

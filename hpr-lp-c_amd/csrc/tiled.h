@@ -81,6 +81,7 @@ struct TiledDev {
     double *base = nullptr;           // rows doubles, zero except for the long rows
     unsigned long long *stamps = nullptr;  // HPRLP_TILE_STAMPS=1 (diagnostic): 16 shader-clock sums per piece
     unsigned long long *wgtimes = nullptr;  // HPRLP_WG_TIMES=1 (diagnostic): 8 wall-clock stamps per workgroup of the fused kernel
+    int wg_filter = 0;                      // HPRLP_WG_TIMES=2: only the normal half-step kernels (hand-off form, no reductions) stamp
     const int *sb_ptr = nullptr;   // nsb+1: steps of a super-block
     const int *sb_mid = nullptr;   // nsb: first remainder step
     const TileStep *steps = nullptr;

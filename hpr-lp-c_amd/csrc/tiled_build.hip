@@ -360,9 +360,10 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
             view.stamps = stamps.p;
         }
     }
-    if (const char *e = std::getenv("HPRLP_WG_TIMES"); e && e[0] == '1' && view.grid > 0) {
+    if (const char *e = std::getenv("HPRLP_WG_TIMES"); e && (e[0] == '1' || e[0] == '2') && view.grid > 0) {
         wgtimes.alloc_zero(static_cast<size_t>(view.grid) * 8);
         view.wgtimes = wgtimes.p;
+        view.wg_filter = e[0] == '2';
     }
     rot_period = 0;
     if (nsb <= 0 || n_steps <= 0) return;
@@ -793,6 +794,20 @@ void DeviceTiled::dump_wgtimes() const {
         t1 = std::max(t1, h[w * 8 + 7]);
     }
     if (t1 == 0) return;
+    if (const char *f = std::getenv("HPRLP_WG_TIMES_DUMP")) {
+        // raw table for tools/wgtimes_analyze.py: workgroup, XCC, CU key (SE/SH/CU bits of HW_ID), start, up to 5 super-block ends, end [us]
+        if (FILE *fp = std::fopen(f, "a")) {
+            std::fprintf(fp, "# launch grid %d\n", view.grid);
+            for (int w = 0; w < view.grid; ++w) {
+                if (h[w * 8] == 0) continue;
+                const unsigned long long id = h[w * 8 + 6];
+                std::fprintf(fp, "%d %llu %llu %.2f", w, id >> 32, (id >> 8) & 0xffull, (h[w * 8] - t0) / 100.0);
+                for (int q = 1; q <= 5; ++q) std::fprintf(fp, " %.2f", h[w * 8 + q] ? (h[w * 8 + q] - t0) / 100.0 : -1.0);
+                std::fprintf(fp, " %.2f\n", (h[w * 8 + 7] - t0) / 100.0);
+            }
+            std::fclose(fp);
+        }
+    }
     // wall clock: 100 MHz
     std::fprintf(stderr, "[wg times] %d workgroups, kernel span %.1f us (first start to last end)\n", view.grid, (t1 - t0) / 100.0);
     for (int x = 0; x < 8; ++x) {
@@ -806,14 +821,14 @@ void DeviceTiled::dump_wgtimes() const {
             e_sum += en;
             ++cnt;
             int r = 0;
-            for (int q = 1; q <= 6; ++q) r += h[w * 8 + q] != 0;
+            for (int q = 1; q <= 5; ++q) r += h[w * 8 + q] != 0;
             rounds_max = std::max(rounds_max, r);
         }
         if (cnt) std::fprintf(stderr, "[wg times]   XCD %d: %d workgroups, start %.1f..%.1f us, end %.1f..%.1f us (mean %.1f), up to %d super-blocks each\n", x, cnt,
                               s_min, s_max, e_min, e_max, e_sum / cnt, rounds_max);
     }
     // distribution of per-super-block durations by round
-    for (int q = 1; q <= 4; ++q) {
+    for (int q = 1; q <= 4; ++q) {  // (slot 6 holds the hardware id)
         double mn = 1e30, mx = 0, sum = 0;
         int cnt = 0;
         for (int w = 0; w < view.grid; ++w) {

@@ -51,7 +51,7 @@ calls = {}
 def half(tag):
     k = [v for n, v in res.items() if "k_tiled_fused" in n and tag in n and "bytes_per_launch" in v]
     return (k[0]["bytes_per_launch"] + (0.0 if handoff else far.get("bytes_per_launch", 0.0))) if k else None
-res["_half_steps"] = {"xhalf_hbm_bytes_per_launch": half("XEpi<false>"), "yhalf_hbm_bytes_per_launch": half("YEpi<false>"),
+res["_half_steps"] = {"xhalf_hbm_bytes_per_launch": half("XEpi<false"), "yhalf_hbm_bytes_per_launch": half("YEpi<false"),
                       "handoff": handoff, "launches": dict(calls), "note": "fused kernel (+ remainder pre-pass unless handed over by the producing half-step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (profiles/r01_pmc_summary.md: calibration)"}
 json.dump(res, open(f"{out}/pmc_traffic_per_kernel.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
