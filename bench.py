@@ -274,6 +274,15 @@ def side_configs():
     return out
 
 
+def xhalf_kernel_key(tiled):
+    """Short identity of the kernel avg_launch_ms covers; tools/profile_c5.sh stores the same key beside the counters it collects,
+    and the bench line carries `traffic` only when the two agree."""
+    if not tiled & 2:
+        return "k_spmv_fused<XEpi<false>>"
+    push = os.environ.get("HPRLP_NO_FAR_PUSH", "0") != "1"
+    return "k_tiled_fused<XEpi<false, true>, *, %s>" % ("true" if push else "false")
+
+
 def xhalf_kernel_label(tiled):
     """Name of what avg_launch_ms covers on one GPU (rocprofv3 kernel names in profiles/)."""
     if not tiled & 2:
@@ -498,13 +507,21 @@ def main():
         x_ms = tm["xhalf_ms"] / args.steps
         y_ms = tm["yhalf_ms"] / args.steps
         achieved = bx / (x_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 passes (tools/profile_c5.sh), not in this run.
+        # The line says where the figure comes from, and carries it only if it was taken on the kernel this run measured.
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf) and P == 1:
             try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get("xhalf_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                ent = json.load(open(tf)).get(args.workload, {})
+                traffic_source = {"file": "profiles/pmc_traffic.json", "entry": args.workload, "kernel": ent.get("kernel_key"),
+                                  "commit": ent.get("commit"), "date": ent.get("date"), "this_run_kernel": xhalf_kernel_key(tiled)}
+                if ent.get("kernel_key") == xhalf_kernel_key(tiled):
+                    traffic = ent.get("xhalf_hbm_bytes_per_launch")
+                else:
+                    traffic_source["note"] = "counters were taken on another kernel: traffic withheld"
+            except Exception as e:  # noqa: BLE001
+                traffic, traffic_source = None, {"error": str(e)}
         out = {
             "metric": "HPR iterations/sec (FP64)", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": P, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -528,7 +545,7 @@ def main():
                          if P == 1 else "x-half window of one rank: local-column SpMV beside the exchange of y, then the remote-column fused kernel "
                                         "(k_spmv_fused<WithBase<XEpi<false>>>); avg_launch_ms is that window, exchange wait included",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": bx, "avg_launch_ms": x_ms,
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bx, "avg_launch_ms": x_ms,
                          "frac_of_achievable_6300": achieved / 6300.0,
                          "yhalf_avg_launch_ms": y_ms,
                          "yhalf_GBps": ((12 * nnz + 4 * (m + P) + 40 * m) / P + 8 * n) / (y_ms * 1e-3) / 1e9,

@@ -101,3 +101,27 @@ def test_config5_sharded_over_four_thread_ranks(gpu):
         assert abs(o["obj"] - lp["obj_star"]) <= 2e-4 * (1 + abs(lp["obj_star"]))
         assert o["info"]["m_sparse"] == 1 and o["info"]["n_sparse"] == 1 and o["tiled"] == 3
         assert 0 < o["info"]["m_received"] < 0.3 * m
+
+
+@pytest.mark.parametrize("config,tol,iters", [("c2", 1e-4, 4050), ("c2", 1e-6, 61950), ("c3", 1e-4, 4400), ("c3", 1e-6, 15000)])
+def test_configs_2_and_3_whole_solve_equals_the_oracle(gpu, config, tol, iters):
+    """BASELINE configs 2 and 3 (shape-matched stand-ins, hpr-lp-c_amd/lpgen.py) solved WHOLE by the GPU path
+    (HPRLP_main_solve: scaling, power iteration, loop, collect_solution) and by the oracle (oracle/hpr_oracle.c, the
+    restatement of reference src/HPRLP.cu:154-310): same status, the SAME number of iterations (every restart decision
+    and the stopping check fall on the same iteration), objectives equal to 1e-10 relative, solutions equal to 1e-6.
+    The counts are the ones DESIGN.md section 3 quotes."""
+    from conftest import hprlp, lpgen
+    from oracle import oracle as O
+    lp = lpgen.c2_25fv47_like() if config == "c2" else lpgen.c3_pds20_like()
+    m, n = lp["m"], lp["n"]
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    r = model.solve(hprlp.Parameters(stop_tol=tol, use_presolve=False))
+    ref = O.solve(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                  params=O.Params.default(stop_tol=tol))
+    assert r.status == ref["status"] == "OPTIMAL"
+    assert r.iter == ref["iter"] == iters, (r.iter, ref["iter"], iters)
+    assert abs(r.primal_obj - ref["primal_obj"]) <= 1e-10 * (1 + abs(ref["primal_obj"])), (r.primal_obj, ref["primal_obj"])
+    assert abs(r.primal_obj - lp["obj_star"]) <= 10 * tol * (1 + abs(lp["obj_star"]))
+    scale = 1 + np.max(np.abs(ref["x"]))
+    np.testing.assert_allclose(r.x, ref["x"], rtol=0, atol=1e-6 * scale)
+    model.free()

@@ -55,5 +55,23 @@ res["_half_steps"] = {"xhalf_hbm_bytes_per_launch": half("XEpi<false"), "yhalf_h
                       "handoff": handoff, "launches": dict(calls), "note": "fused kernel (+ remainder pre-pass unless handed over by the producing half-step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (profiles/r01_pmc_summary.md: calibration)"}
 json.dump(res, open(f"{out}/pmc_traffic_per_kernel.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
+# the entry bench.py reads (profiles/pmc_traffic.json: copy gpurun_out/prof_<tag>/pmc_traffic_entry.json into it under the
+# workload's name): which kernel the counters were taken on, at which commit, when
+import datetime, subprocess
+xk = [n for n in res if "k_tiled_fused" in n and "XEpi<false" in n]
+hs = res["_half_steps"]
+key = None
+if xk:
+    push = xk[0].rstrip(">").split(",")[-1].strip()
+    key = "k_tiled_fused<XEpi<false, true>, *, %s>" % push if "XEpi<false, true>" in xk[0] else xk[0]
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    commit = os.environ.get("HPRLP_COMMIT")  # the GPU box has no .git: pass HPRLP_COMMIT=$(git rev-parse --short HEAD) into the call
+entry = {"xhalf_hbm_bytes_per_launch": hs["xhalf_hbm_bytes_per_launch"], "yhalf_hbm_bytes_per_launch": hs["yhalf_hbm_bytes_per_launch"],
+         "kernel_key": key, "kernel_name": xk[0] if xk else None, "commit": commit, "date": datetime.date.today().isoformat(),
+         "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; factor 2 calibrated on k_stream<1>/k_vec_scale (profiles/r01_pmc_summary.md)",
+         "collected_by": "tools/profile_c5.sh"}
+json.dump(entry, open(f"{out}/pmc_traffic_entry.json", "w"), indent=1)
 PY
 rm -rf "$out/trace" "$out/fetch" "$out/write"
