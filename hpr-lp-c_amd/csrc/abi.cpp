@@ -714,6 +714,37 @@ extern "C" int hprlp_solver_info(hprlp_solver *h, long out[8]) {
     GUARD_END(-1)
 }
 
+// One line per matrix saying which kernel form runs and on what structure (bench.py's ladder, tools/run_mps_dir.py)
+extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
+    GUARD_BEGIN
+    if (!h || !buf || cap <= 0) throw std::runtime_error("null solver / buffer");
+    Solver &s = h->s;
+    s.finish_tiling();
+    auto one = [](const char *name, const DeviceMatrix &M) {
+        const TiledDev &t = M.view.tiled;
+        std::string d = std::string(name) + ": ";
+        if (!t.valid) {
+            d += "stream kernel (k_spmv_fused, " + std::to_string(M.view.nblk) + " row blocks, " + std::to_string(M.view.nlong) + " split rows)";
+            if (M.declined_shape) d += " [tiled form not attempted: shape]";
+            else if (M.declined_sparse) d += " [tiled form declined: too few entries in dense tiles]";
+            return d;
+        }
+        d += t.n_pieces > 0 ? "tiled, piece form (k_tiled_part + k_tiled_finish, " + std::to_string(t.n_pieces) + " pieces)"
+                            : "tiled, fused (k_tiled_fused, grid " + std::to_string(t.grid) + ")";
+        d += ", " + std::to_string(t.nsb) + " super-blocks, " + std::to_string(M.tiled.n_steps) + " steps";
+        const double all = static_cast<double>(M.tiled.dense_entries) + static_cast<double>(M.tiled.n_rem);
+        if (all > 0) d += ", " + std::to_string(static_cast<int>(100.0 * M.tiled.dense_entries / all + 0.5)) + " % of the entries in staged tiles";
+        if (t.side_nblk > 0) d += ", long rows aside (" + std::to_string(t.side_nblk) + " blocks through the stream kernel)";
+        return d;
+    };
+    std::string d = one("A", s.A) + "; " + one("A^T", s.AT);
+    if (s.use_small && !s.comm) d += "; normal iterations in the single-workgroup kernel (k_small_iterations)";
+    if (!s.perm_r.empty()) d += "; locality ordering applied at set-up";
+    std::snprintf(buf, static_cast<size_t>(cap), "%s", d.c_str());
+    return static_cast<int>(d.size());
+    GUARD_END(-1)
+}
+
 extern "C" int hprlp_solver_time_iterations(hprlp_solver *h, int warmup, int steps, int mode, double *total_ms,
                                             double *xhalf_ms, double *yhalf_ms) {
     GUARD_BEGIN

@@ -717,8 +717,13 @@ void Solver::verify_exchange() {
 }
 
 void Solver::fetch_scalars() {
+    const auto t0 = time_now();
     HIP_CHECK(hipMemcpyAsync(scal_h.p, scal.p, kNumScalars * sizeof(double), hipMemcpyDeviceToHost, stream));
+    const auto t1 = time_now();
     HIP_CHECK(hipStreamSynchronize(stream));
+    fetch_enqueue_s += std::chrono::duration<double>(t1 - t0).count();
+    fetch_wait_s += time_since(t1);
+    ++fetches;
 }
 
 static void allreduce_slots(Solver *s, int first, int count) {
@@ -1305,6 +1310,9 @@ void Solver::solve_loop(HPRLP_results *out) {
         rs.inner += next - iter;
         iter = next;
     }
+    if (std::getenv("HPRLP_TIMING"))
+        std::cerr << "[timing] loop: " << time_since(t_loop) << " s, " << iter << " iterations; " << fetches << " scalar fetches: enqueue "
+                  << fetch_enqueue_s << " s, wait " << fetch_wait_s << " s" << std::endl;
     std::strncpy(out->status, status.c_str(), sizeof(out->status) - 1);
     out->status[sizeof(out->status) - 1] = '\0';
     out->iter = iter;

@@ -125,6 +125,8 @@ struct Solver {
     double b_scale = 1, c_scale = 1, norm_b = 0, norm_c = 0, norm_b_org = 1, norm_c_org = 1;
     double sigma = 1.0, lambda_max = 1.0;
     double setup_time = 0, scaling_time = 0, power_time = 0;
+    double fetch_enqueue_s = 0, fetch_wait_s = 0;  // HPRLP_TIMING: host time in fetch_scalars (enqueue of the copy / wait for the stream)
+    long fetches = 0;
     int power_iters = 0;
     bool use_graph = true;
     bool use_small = false;  // Netlib-scale LP on one GPU: normal iterations run in the single-workgroup kernel (small.hip)

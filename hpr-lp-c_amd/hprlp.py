@@ -210,6 +210,10 @@ class Model:
     def obj_constant(self):
         return self._ptr.contents.obj_constant
 
+    @property
+    def nnz(self):
+        return self._ptr.contents.A.contents.numElements
+
     @staticmethod
     def from_csr(m, n, rowptr, colind, values, AL, AU, l, u, c, is_csc=False):
         rp = _as(rowptr, np.int32); ci = _as(colind, np.int32); v = _as(values, np.float64)
@@ -522,6 +526,14 @@ class Solver:
         d["reordered"] = bool(d["tiled"] & 8)  # set-up time locality ordering in place (csrc/reorder.cpp)
         d["tiled"] &= 7
         return d
+
+    def describe(self):
+        """Which kernel form runs on A and A^T (hprlp_solver_describe)."""
+        buf = C.create_string_buffer(2048)
+        L = lib()
+        L.hprlp_solver_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        self._chk(L.hprlp_solver_describe(self.h, buf, 2048))
+        return buf.value.decode()
 
     def run(self, max_trace=4096):
         res = CResults()

@@ -131,3 +131,39 @@ def banded_lp(m, n, per_row, band, seed):
     out = _plant(rng, A)
     out.update(m=m, n=n, A=A, rowptr=A.indptr.astype(np.int32), colind=A.indices.astype(np.int32), values=A.data.copy())
     return out
+
+
+def block_angular_csr(K, mb, nb, per_row, link_rows, link_cols, link_len, seed):
+    """Block-angular pattern (multi-commodity / stochastic-programming shape): K diagonal blocks of mb x nb with `per_row`
+    random entries per row inside the block, plus `link_rows` linking ROWS and `link_cols` linking COLUMNS of `link_len`
+    entries each spread over all blocks (the dense rows / columns real LPs of this class carry: the long-row paths of the
+    kernels).  Returns (m, n, rowptr, colind, values) with m = K mb + link_rows, n = K nb + link_cols."""
+    rng = np.random.default_rng(seed)
+    m0, n0 = K * mb, K * nb
+    m, n = m0 + link_rows, n0 + link_cols
+    r = np.repeat(np.arange(m0, dtype=np.int64), per_row)
+    c = (r // mb) * nb + rng.integers(0, nb, size=len(r))
+    rows, cols = [r], [c]
+    for q in range(link_rows):      # a linking row: link_len columns anywhere
+        rows.append(np.full(link_len, m0 + q, np.int64))
+        cols.append(rng.choice(n0, size=link_len, replace=False))
+    for q in range(link_cols):      # a linking column: link_len rows anywhere
+        rows.append(rng.choice(m0, size=link_len, replace=False))
+        cols.append(np.full(link_len, n0 + q, np.int64))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    key = np.unique(rows * n + cols)
+    rows, cols = key // n, key % n
+    vals = rng.normal(size=len(key))
+    vals[np.abs(vals) < 1e-3] = 1e-3
+    A = sparse.csr_matrix((vals, (rows, cols)), shape=(m, n))
+    A.sort_indices()
+    return m, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+
+
+def block_angular_lp(K, mb, nb, per_row, link_rows, link_cols, link_len, seed):
+    """Planted LP on the block-angular pattern."""
+    m, n, rp, ci, v = block_angular_csr(K, mb, nb, per_row, link_rows, link_cols, link_len, seed)
+    A = sparse.csr_matrix((v, ci, rp), shape=(m, n))
+    out = _plant(np.random.default_rng(seed + 1), A)
+    out.update(m=m, n=n, A=A, rowptr=rp, colind=ci, values=v)
+    return out

@@ -73,6 +73,10 @@ int hprlp_solver_get_scalars(hprlp_solver *s, double out[16]);
  *        tiled flags (bit0: A, bit1: A^T use the column-tiled kernel)} */
 int hprlp_solver_info(hprlp_solver *s, long out[8]);
 
+/* Human-readable: which kernel form runs on A and on A^T (stream / tiled fused / tiled pieces), super-blocks, steps, share of the
+ * entries in staged tiles, long rows kept aside, small-LP kernel, locality ordering.  Returns the length (truncated to cap). */
+int hprlp_solver_describe(hprlp_solver *s, char *buf, int cap);
+
 /* Timed normal iterations for bench.py.  mode 0: graph replay as the product runs it; wall time by
  * HIP events around the whole batch.  mode 1: eager launches with an event pair around every kernel
  * on the solver's stream; xhalf_ms / yhalf_ms are the SUMS of the x-half / y-half kernel durations.  mode 2: the

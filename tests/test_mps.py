@@ -4,6 +4,7 @@ import gzip
 import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -203,3 +204,36 @@ def test_round_trip_at_benchmark_size(tmp_path, which, gz):
         assert np.array_equal(got[~ranged], want[~ranged])
         np.testing.assert_allclose(got[ranged], want[ranged], rtol=4e-16, atol=1e-15)
     mod.free()
+
+
+@pytest.mark.gpu
+def test_run_mps_dir_emits_the_baseline_table(gpu, tmp_path):
+    """tools/run_mps_dir.py: a directory of .mps(.gz) files -> one row of the BASELINE.md section-4 table per instance
+    (the reference's driver loop, src/solve_mps_file.cpp:120-131, over a directory).  Here: the config-2 stand-in, a
+    small planted LP (gzipped) and the reference's own known answer (data/model.mps content)."""
+    import gzip
+    import json
+    import shutil
+    lp2 = lpgen.c2_25fv47_like()
+    write_mps(str(tmp_path / "c2like.mps"), lp2)
+    lp1 = lpgen.planted_lp(120, 200, 1000, 5)
+    write_mps(str(tmp_path / "planted.mps"), lp1)
+    with open(tmp_path / "planted.mps", "rb") as f, gzip.open(tmp_path / "planted.mps.gz", "wb") as g:
+        g.write(f.read())
+    os.remove(tmp_path / "planted.mps")
+    shutil.copy(os.path.join(ROOT, "tests", "data", "lp_small.mps"), tmp_path / "model.mps")
+    out, js = tmp_path / "table.md", tmp_path / "rows.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_mps_dir.py"), str(tmp_path), "--tol", "1e-6", "--presolve", "false",
+                        "--out", str(out), "--json", str(js)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rows = {q["instance"]: q for q in json.load(open(js))}
+    assert set(rows) == {"c2like.mps", "planted.mps.gz", "model.mps"}
+    for name, q in rows.items():
+        assert q["status"] == "OPTIMAL", (name, q)
+        assert max(q["kkt_primal"], q["kkt_dual"], q["kkt_gap"]) <= 1e-5, (name, q)
+        assert q["iter4"] <= q["iterations"] and q["time4_s"] <= q["solver_time_s"] + 1e-9
+    assert abs(rows["model.mps"]["primal_obj"] - (-26.4)) <= 1e-4          # reference examples/cpp/example_direct_lp.cpp:14
+    assert abs(rows["c2like.mps"]["primal_obj"] - lp2["obj_star"]) <= 1e-4 * (1 + abs(lp2["obj_star"]))
+    assert "k_small_iterations" in rows["c2like.mps"]["kernels"]
+    text = open(out).read()
+    assert text.count("\n") == 2 + 3 and "| c2like.mps | 821 | 1571 |" in text

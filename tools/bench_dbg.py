@@ -278,46 +278,6 @@ def side_configs():
     return out
 
 
-def ladder():
-    """Size-and-structure ladder between config 3 (2.4e5 nnz) and config 5 (2e8): the Mittelmann regime.  Per point: which
-    kernels the library chose, the half-step times by HIP events around every kernel (hprlp_solver_time_iterations mode 1)
-    and the algorithmic-bytes fraction of 8 TB/s.  Banded points use the config-5 generator; the block-angular point
-    (hpr-lp-c_amd/lpgen.py) carries 200 linking rows and 200 linking columns of 5000 entries: the long-row paths."""
-    pts = [("band_2e6", lambda: banded_lp(100_000, 100_000, 20, 1_000)),
-           ("band_2e7", lambda: banded_lp(1_000_000, 1_000_000, 20, 10_000)),
-           ("band_6e7", lambda: banded_lp(3_000_000, 3_000_000, 20, 30_000)),
-           ("block_angular_2e7", lambda: G.block_angular_lp(1000, 1000, 2000, 18, 200, 200, 5000, 7))]
-    out = {}
-    for key, make in pts:
-        try:
-            lp = make()
-            m, n, nnz = lp["m"], lp["n"], len(lp["values"])
-            model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
-            del lp
-            s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
-            s.scale()
-            lam, _ = s.power_iteration(max_iter=50)
-            s.init(-1.0, lam * 1.01)
-            info = s.info()
-            steps = 100
-            t = s.time_iterations(20, steps, 1)
-            g = s.time_iterations(20, steps, 0)  # as the product runs it (graph replay where it applies)
-            s.iterate(0, True)
-            res = s.residuals(2 * steps + 41)
-            x_ms, y_ms = t["xhalf_ms"] / steps, t["yhalf_ms"] / steps
-            out[key] = {"m": m, "n": n, "nnz": nnz, "kernels": s.describe(), "tiled_flags": info["tiled"],
-                        "iterations_per_s": steps / (g["total_ms"] * 1e-3), "xhalf_ms": x_ms, "yhalf_ms": y_ms,
-                        "xhalf_frac_of_8000": bytes_x_half(m, n, nnz) / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "yhalf_frac_of_8000": bytes_y_half(m, n, nnz) / (y_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "iteration_frac_of_8000": bytes_per_iteration(m, n, nnz) * steps / (g["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "finite": bool(np.isfinite(res["kkt"]))}
-            s.close()
-            model.free()
-        except Exception as e:  # noqa: BLE001
-            out[key] = {"error": str(e)}
-    return out
-
-
 def xhalf_kernel_key(tiled):
     """Short identity of the kernel avg_launch_ms covers; tools/profile_c5.sh stores the same key beside the counters it collects,
     and the bench line carries `traffic` only when the two agree."""
@@ -413,7 +373,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-side", action="store_true", help="skip the config-2/3 side measurements")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-tolerance solve of the workload")
-    ap.add_argument("--no-ladder", action="store_true", help="skip the size-and-structure ladder (2e6 .. 6e7 nnz)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -627,14 +586,10 @@ def main():
             model.free()
         if not args.no_side:  # before the CPU leg: its OpenMP team keeps spinning for a while and disturbs the
             try:              # latency-bound small solves
-                out["other_configs"] = side_configs()
+                for _rep in range(3):
+                    out["other_configs"] = side_configs(); log("SIDE", _rep, out["other_configs"]["c2_25fv47_like"]["time_to_1e-4_parts_s"])
             except Exception as e:
                 out["other_configs"] = {"error": str(e)}
-        if not args.no_ladder and not args.no_side:
-            try:
-                out["ladder"] = ladder()
-            except Exception as e:  # noqa: BLE001
-                out["ladder"] = {"error": str(e)}
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload)
