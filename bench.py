@@ -46,6 +46,13 @@ WORKLOADS = {
     "c5_half": (5_000_000, 10_000_000, 20, 100_000),
     "c5_shard_like": (1_250_000, 1_250_000, 20, 100_000),  # rows and band of one of 8 shards of c5 (kernel-shape experiments)
     "c5_small": (1_000_000, 1_000_000, 20, 10_000),
+    "band_6e7": (3_000_000, 3_000_000, 20, 30_000),   # the ladder's points as workloads of their own (kernel experiments)
+    "band_6e6": (300_000, 300_000, 20, 3_000),
+    "band_1.2e7": (600_000, 600_000, 20, 6_000),
+    "band_1.6e7": (800_000, 800_000, 20, 8_000),
+    "band_3e7": (1_500_000, 1_500_000, 20, 15_000),
+    "band_4e7": (2_000_000, 2_000_000, 20, 20_000),
+    "band_2e7_wide": (1_000_000, 1_000_000, 20, 100_000),   # same size as c5_small, config 5's band: the short form must decline
     "c5_tiny": (100_000, 100_000, 20, 1_000),
     # exactly 2 / 3 rounds of super-blocks over the 512 resident workgroups (config 5 has 1221 = 2.38 rounds): tail-balance experiments
     "c5_2rounds": (8_388_608, 8_388_608, 20, 100_000),

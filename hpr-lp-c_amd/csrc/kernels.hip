@@ -323,7 +323,7 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 template <int ED, int TD, bool REP, bool STAMP = false>
 __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, int first, int count, const double *__restrict__ vec,
                                             int ncols, double *acc, double *ytile, int tid, unsigned long long *stamp = nullptr) {
-    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols, K = kTileChunk;
+    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols, K = kTileChunk;  // (R: the codes' row field, whatever the copy's height)
     constexpr int TPT = T / NT;
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const int lane = tid & 63;
@@ -646,12 +646,13 @@ __device__ __forceinline__ void tiled_remainder(const TiledDev &t, int smid, int
 template <class Epi, bool REP, bool PUSH = false>
 __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi epi) {  // 4 waves per SIMD = two workgroups per CU
     static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
-    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols;
+    constexpr int NT = kTileThreads, RMAX = kTileRows, T = kTileCols;
     constexpr int NACC = Epi::NACC;
-    __shared__ double acc[R];
+    __shared__ double acc[RMAX];
     __shared__ __attribute__((aligned(16))) double ytile[T];
     const TiledDev &t = A.tiled;
     const int tid = threadIdx.x;
+    const int R = t.R;  // rows per super-block of this copy (<= RMAX, tiled.h)
     const int per = t.per, slots = gridDim.x / 8;  // persistent: slot, slot + slots, ... of this XCD's range
     const int slot = blockIdx.x / 8;
     double racc[NACC > 0 ? NACC : 1];
@@ -697,7 +698,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
             // Hand-off (kernels.h: FarPush): this super-block's fresh values are the source group `sb` of the OTHER matrix'
             // remainder; write its products straight into that matrix' P -- what k_far_products would do in a launch of
             // its own after re-reading the vector from memory.  Same products bit for bit, same slots.
-            static_assert(kFarGroup == kTileRows, "a source group of the remainder = the rows of one super-block");
+            // (a source group of the consumer's remainder = the rows of one super-block here: push_into() checks G == R)
             lds_barrier();
             const FarPush &f = epi.push;
             const int b = pb, e = pe;
@@ -749,11 +750,12 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
 // ------------------------------------------------------------------------------------------------
 template <bool REP, bool STAMP = false>
 __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_part(CsrDev A, const double *__restrict__ vec) {
-    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols;
-    __shared__ double acc[R];
+    constexpr int NT = kTileThreads, RMAX = kTileRows, T = kTileCols;
+    __shared__ double acc[RMAX];
     __shared__ __attribute__((aligned(16))) double ytile[T];
     const TiledDev &t = A.tiled;
     const int tid = threadIdx.x;
+    const int R = t.R;
     // XCD-aware: a contiguous range of pieces per XCD (neighbouring pieces read the same vector tiles)
     const int per = (t.n_pieces + 7) / 8;
     const int pc = (blockIdx.x % 8) * per + blockIdx.x / 8;
@@ -784,7 +786,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_part(CsrDev A, const 
 
 template <class Epi>
 __global__ void __launch_bounds__(kThreads) k_tiled_finish(CsrDev A, Epi epi) {
-    constexpr int NACC = Epi::NACC, R = kTileRows;
+    constexpr int NACC = Epi::NACC;
+    const int R = A.tiled.R;
     double racc[NACC > 0 ? NACC : 1];
 #pragma unroll
     for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
@@ -793,7 +796,7 @@ __global__ void __launch_bounds__(kThreads) k_tiled_finish(CsrDev A, Epi epi) {
     if (r < A.rows) {
         const int sb = r / R;
         const int a = A.tiled.slot_ptr[sb], b = A.tiled.slot_ptr[sb + 1];
-        const double *p = A.tiled.parts + (r % R);
+        const double *p = A.tiled.parts + (r - sb * R);
         double sum = 0.0;
         for (int k = a; k < b; ++k) sum = (k == a) ? p[static_cast<size_t>(k) * R] : sum + p[static_cast<size_t>(k) * R];
         const double sv[1] = {sum};
@@ -829,11 +832,12 @@ __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const 
     // workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of groups, so that the runs its
     // workgroups write side by side in P (layout [super-block][group]) meet in ONE L2 and leave it as whole lines
     const int per = (t.n_groups + 7) / 8;
-    const int g = (blockIdx.x % 8) * per + blockIdx.x / 8, c0 = g * kFarGroup, tid = threadIdx.x;
+    const int G = t.G;  // columns per source group (at most kFarGroup)
+    const int g = (blockIdx.x % 8) * per + blockIdx.x / 8, c0 = g * G, tid = threadIdx.x;
     if (g >= t.n_groups) return;
     const int b = t.f_gptr[g], e = t.f_gptr[g + 1];
     if (b >= e) return;
-    const int w = min(kFarGroup, ncols - c0);
+    const int w = min(G, ncols - c0);
     // the first batch of entries does not depend on the staged slice: its loads go out before the slice's
     constexpr int U = 4;
     double a[U];
@@ -854,9 +858,11 @@ __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const 
         constexpr int S = kFarGroup / kFarThreads;
         double sv[S];
 #pragma unroll
-        for (int i = 0; i < S; ++i) sv[i] = vec[c0 + min(tid + i * kFarThreads, w - 1)];
+        for (int i = 0; i < S; ++i)
+            if (i * kFarThreads < G) sv[i] = vec[c0 + min(tid + i * kFarThreads, w - 1)];  // (uniform condition)
 #pragma unroll
-        for (int i = 0; i < S; ++i) v[tid + i * kFarThreads] = sv[i];
+        for (int i = 0; i < S; ++i)
+            if (i * kFarThreads < G) v[tid + i * kFarThreads] = sv[i];
     }
     __syncthreads();
     for (; k < e; k += U * kFarThreads) {
@@ -1194,29 +1200,26 @@ static bool launch_fused(const CsrDev &M, const Epi &e, hipStream_t s, bool far_
 
 template <class Epi>
 static bool launch_tiled(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready) {
-    {
-        {
-            if (M.tiled.n_groups > 0 && !far_ready)
-                hipLaunchKernelGGL(k_far_products, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
-            if (M.tiled.n_pieces > 0) {
-                if (M.tiled.stamps) hipLaunchKernelGGL((k_tiled_part<false, true>), dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
-                else if (M.tiled.repeats) hipLaunchKernelGGL(k_tiled_part<true>, dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
-                else hipLaunchKernelGGL(k_tiled_part<false>, dim3((M.tiled.n_pieces + 7) / 8 * 8), dim3(kTileThreads), 0, s, M, e.gv[0]);
-                hipLaunchKernelGGL(k_tiled_finish<Epi>, dim3(M.tiled_finish_grid()), dim3(kThreads), 0, s, M, e);
-                return false;
-            }
-            if constexpr (Publishes<Epi>::value) {
-                if (e.push.gptr) {
-                    if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
-                    else hipLaunchKernelGGL((k_tiled_fused<Epi, false, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
-                    return true;
-                }
-            }
-            if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
-            else hipLaunchKernelGGL((k_tiled_fused<Epi, false>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
-            return false;
+    if (M.tiled.n_groups > 0 && !far_ready)
+        hipLaunchKernelGGL(k_far_products, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
+    if (M.tiled.n_pieces > 0) {
+        const dim3 grid((M.tiled.n_pieces + 7) / 8 * 8);
+        if (M.tiled.stamps) hipLaunchKernelGGL((k_tiled_part<false, true>), grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
+        else if (M.tiled.repeats) hipLaunchKernelGGL(k_tiled_part<true>, grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
+        else hipLaunchKernelGGL(k_tiled_part<false>, grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
+        hipLaunchKernelGGL(k_tiled_finish<Epi>, dim3(M.tiled_finish_grid()), dim3(kThreads), 0, s, M, e);
+        return false;
+    }
+    if constexpr (Publishes<Epi>::value) {
+        if (e.push.gptr) {
+            if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+            else hipLaunchKernelGGL((k_tiled_fused<Epi, false, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+            return true;
         }
     }
+    if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+    else hipLaunchKernelGGL((k_tiled_fused<Epi, false>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+    return false;
 }
 
 FarPush far_push_of(const CsrDev &consumer) {

@@ -159,7 +159,10 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         // measured on shard-shaped matrices of the banded benchmark: 305 super-blocks 0.31 ms tiled vs
         // 0.38 ms stream, 153 super-blocks 0.21 ms both -> one super-block per CU is the break-even
         // (round 2: matrices with fewer super-blocks than CUs run the split form -- several workgroups per super-block)
-        const int min_rows = mr ? std::atoi(mr) : 32 * kTileRows;
+        const int rb = sb_rows, gb = far_group;  // (heights, not bit counts)
+        const bool short_form = rb < kTileRows;
+        // (lowered height: chosen by Solver::choose_sb_rows so that there is a super-block per workgroup slot)
+        const int min_rows = mr ? std::atoi(mr) : (short_form ? 256 * rb : 32 * kTileRows);
         const double min_dense = min_dense_override >= 0.0 ? min_dense_override : (md ? std::atof(md) : 0.5);
         declined_sparse = false;
         // Two more conditions on the shape (measured late in round 2, tools/longrow_ab.py):
@@ -170,7 +173,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         //    consecutive products (two dependent LDS reads each): five rows of 3000 entries took that launch from 31 to 203
         //    us.  Such matrices keep the stream kernel, which spreads a long row over a wave or several.
         const char *mc = std::getenv("HPRLP_TILED_MIN_COLS");
-        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (1 << 20));
+        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (short_form ? (1 << 19) : (1 << 20)));
         int longest = 0;
         if (rp)
             for (int i = 0; i < rows; ++i) longest = std::max(longest, rp[i + 1] - rp[i]);
@@ -199,12 +202,12 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
                 DBuf<int> d_rp_c(rp_c.size()), col_c(static_cast<size_t>(std::max<long>(nnz_c, 1))), map_c(static_cast<size_t>(std::max<long>(nnz_c, 1)));
                 d_rp_c.upload(rp_c.data(), rp_c.size());
                 compact_without_rows(nnz, rows, rowptr.p, d_rp_c.p, col.p, col_c.p, map_c.p, nullptr);
-                const bool ok = tiled.build_on_device(rows, cols, nnz_c, d_rp_c.p, col_c.p, min_rows, min_dense, nullptr);
+                const bool ok = tiled.build_on_device(rows, cols, nnz_c, d_rp_c.p, col_c.p, min_rows, min_dense, nullptr, rb);
                 if (pt.on)
                     std::cerr << "[timing]   tiled copy without " << long_rows.size() << " long rows (" << long_nnz << " entries, longest " << longest
                               << "): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, " << tiled.n_steps << " steps" << std::endl;
                 if (ok) {
-                    tiled.build_far(cols, nullptr);
+                    tiled.build_far(cols, nullptr, gb);
                     tiled.compose_perms(map_c.p, nullptr);
                     tiled.set_side(rows, rp, long_rows);
                     view.tiled = tiled.view;
@@ -221,7 +224,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
             // built on the device from the device CSR arrays (tiled_build.hip); HPRLP_TILING_CHECK=1 also runs the
             // host builder and compares every array
-            const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr);
+            const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr, rb);
             declined_sparse = !ok;  // rows >= min_rows here: what was missing is dense tiles
             if (pt.on)
                 std::cerr << "[timing]   tiled copy (device build): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, "
@@ -230,23 +233,23 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
             const char *chk = std::getenv("HPRLP_TILING_CHECK");
             if (chk && chk[0] == '1' && ci) {
                 TiledHost th;
-                const bool hok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense);
+                const bool hok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense, rb);
                 if (hok != ok) throw std::runtime_error("tiling check: host and device builders disagree on acceptance");
                 if (ok) tiled.compare_with(th);
             }
             if (ok) {
-                tiled.build_far(cols, nullptr);  // consumes the remainder lists the check above compares
+                tiled.build_far(cols, nullptr, gb);  // consumes the remainder lists the check above compares
                 view.tiled = tiled.view;
                 launch_tiled_refresh(tiled, val.p, nullptr);
                 HIP_CHECK(hipDeviceSynchronize());
             }
             pt.tick("  build tiled copy (device)");
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && ci) {  // the host builder needs the host column indices
-            planned_grid = std::max(((rows + kTileRows - 1) / kTileRows + 7) / 8 * 8, (rows + kThreads - 1) / kThreads);  // fused grid or the split form's finish grid
+            planned_grid = std::max(((rows + rb - 1) / rb + 7) / 8 * 8, (rows + kThreads - 1) / kThreads);  // fused grid or the split form's finish grid
             tiling = std::async(std::launch::async, [=]() -> std::shared_ptr<TiledHost> {
                 (void)keep;  // keeps the host arrays alive for the duration of the build
                 auto th = std::make_shared<TiledHost>();
-                return build_tiled(rows, cols, rp, ci, th.get(), min_rows, min_dense) ? th : nullptr;
+                return build_tiled(rows, cols, rp, ci, th.get(), min_rows, min_dense, rb) ? th : nullptr;
             });
         }
     }
@@ -265,8 +268,8 @@ void DeviceMatrix::finish_tiling(hipStream_t s) {
         std::cerr << "[timing]   tiled copy: " << th->sb_mid.size() << " super-blocks, " << th->steps.size() << " steps, "
                   << th->dense_entries << " entries in tiles + " << th->padding << " padding, " << th->n_rem
                   << " in the remainder list" << std::endl;
-    tiled.upload(*th);
-    tiled.build_far(view.cols, s);
+    tiled.upload(*th, sb_rows);
+    tiled.build_far(view.cols, s, far_group);
     view.tiled = tiled.view;
     launch_tiled_refresh(tiled, val.p, s);
     HIP_CHECK(hipStreamSynchronize(s));
@@ -331,6 +334,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     if (!As || As->row != m || As->col != n) throw std::runtime_error("model matrix dimensions inconsistent");
     const long nnz = As->numElements;
     PhaseTimer pt;
+    choose_sb_rows(model);
     A.upload(m, n, As->rowPtr, As->colIndex, As->value);
     pt.tick("A upload total");
     {   // explicit A^T built on the host, stable in row order (reference src/preprocess.cu:78-82); its index
@@ -447,6 +451,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
 // gathered vector from which the all-remainder tiled form beats the stream kernel on a pattern without locality (measured,
 // tools/unstructured_ab.py, uniformly random 10 per row: 1M columns 0.154 vs 0.125 ms per half-step, 2M 0.218 vs 0.318, 3M 0.316
 // vs 0.508, 4.2M 0.46 vs 0.75, 6M 0.59 vs 1.13)
+constexpr double kMaxTileShare = 0.6;  // choose_sb_rows: most tile bytes per entry byte a lowered super-block may stage
 constexpr long kPbMinCols = 1500000;
 
 bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
@@ -456,6 +461,60 @@ bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
     if (nt && nt[0] == '1') return false;
     static const long min_cols = std::getenv("HPRLP_PB_MIN_COLS") ? std::atol(std::getenv("HPRLP_PB_MIN_COLS")) : kPbMinCols;
     return !comm && !M.view.tiled.valid && M.declined_sparse && M.view.cols >= min_cols && M.view.nnz >= 4000000;
+}
+
+// Super-block heights of this LP's tiled copies (tiled.h).  A matrix with fewer than 512 full-height super-blocks cannot give
+// every workgroup slot of the chip a whole super-block: it ran the piece form (three launches, partial sums through memory) or,
+// below 2^20 columns, the stream kernel.  With R = rows / 512 every slot gets exactly one, the epilogue stays fused, a half-step
+// is one launch and there is no tail.  What a lower super-block costs is tile traffic -- a staged tile serves R rows -- so the
+// column window of a super-block must stay narrow against its entries: estimated from the column span of the middle 90 % of the
+// entries of 2048 sampled rows (the far entries of a band matrix do not count: they go through the remainder lists).  A
+// source group of one matrix' remainder lists is a super-block of the other (hand-off, kernels.h FarPush): far_group of A is
+// sb_rows of A^T and vice versa.  Same-box A/B (profiles/r03_ab_rows*.txt): 1M x 1M, band 1e4: 3658 it/s stream kernel, 3393
+// pieces, 5287 with 2048-row super-blocks; the 1.25M x 10M shard of config 5 (window of 2e5 columns): a loss, declined here.
+void Solver::choose_sb_rows(const LP_info_cpu *model) {
+    A.sb_rows = A.far_group = AT.sb_rows = AT.far_group = kTileRows;
+    if (const char *force = std::getenv("HPRLP_TILE_ROWS")) {  // tests / A/B runs: one height for both matrices
+        const int R = std::max(64, std::min(kTileRows, std::atoi(force) / 64 * 64));
+        A.sb_rows = A.far_group = AT.sb_rows = AT.far_group = R;
+        return;
+    }
+    if (comm) return;  // row shards: all columns of the LP against 1 / P of the rows -- full height
+    const sparseMatrix *As = model->A;
+    const long nnz = As->numElements;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int slots = cus * kTileResidentPerCu;
+    // the height that gives one super-block per slot; nothing to do if the full height already fills a round, nothing to gain
+    // below kTileRowsMin (launch-bound matrices: the stream kernel)
+    auto height = [&](int rows) { return ((rows + slots - 1) / slots + 63) / 64 * 64; };
+    const int ra = height(m), rat = height(n);
+    if (nnz < 4000000 || ra >= kTileRows || rat >= kTileRows || ra < kTileRowsMin || rat < kTileRowsMin) return;
+    // median column span of the middle 90 % of a row's entries
+    std::vector<long> span;
+    const int samples = 2048;
+    for (int q = 0; q < samples; ++q) {
+        const int i = static_cast<int>(static_cast<long>(q) * m / samples);
+        const int b = As->rowPtr[i], e = As->rowPtr[i + 1], len = e - b;
+        if (len < 2) continue;
+        const int cut = len / 20;
+        span.push_back(static_cast<long>(As->colIndex[e - 1 - cut]) - As->colIndex[b + cut]);
+    }
+    if (span.size() < 16) return;
+    std::nth_element(span.begin(), span.begin() + span.size() / 2, span.end());
+    const double w_a = static_cast<double>(span[span.size() / 2]);
+    const double slope = static_cast<double>(n) / m;  // columns per row along the "diagonal"
+    // bytes of the vector tiles a super-block stages against the bytes of its entries
+    const double ratio_a = (w_a + ra * slope) * 8.0 / (static_cast<double>(nnz) / m * ra * 11.0);
+    const double ratio_at = (w_a / slope + rat / slope) * 8.0 / (static_cast<double>(nnz) / n * rat * 11.0);
+    const bool ok = ratio_a <= kMaxTileShare && ratio_at <= kMaxTileShare;
+    if (ok) {
+        A.sb_rows = AT.far_group = ra;
+        AT.sb_rows = A.far_group = rat;
+    }
+    if (std::getenv("HPRLP_TIMING"))
+        std::cerr << "[timing] super-block heights for one round of " << slots << " slots: " << ra << " (A), " << rat << " (A^T); median row span " << w_a
+                  << " columns, tile bytes / entry bytes " << ratio_a << ", " << ratio_at << " -> " << (ok ? "lowered" : "full height (8192)") << std::endl;
 }
 
 // Large matrix whose given order failed the tiling test: look for a locality ordering (reorder.cpp).  On entry A (device
@@ -968,6 +1027,7 @@ FarPush Solver::push_into(const DeviceMatrix &consumer, const DeviceMatrix &prod
     static const bool off = std::getenv("HPRLP_NO_FAR_PUSH") && std::getenv("HPRLP_NO_FAR_PUSH")[0] == '1';
     const TiledDev &pt = producer.view.tiled;
     if (off || comm || !pt.valid || pt.n_pieces > 0) return FarPush{};
+    if (consumer.view.tiled.valid && consumer.view.tiled.G != pt.R) return FarPush{};  // a source group must be ONE super-block of the producer
     return far_push_of(consumer.view);
 }
 

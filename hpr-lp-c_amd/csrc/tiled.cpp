@@ -22,8 +22,8 @@ struct Local {  // what one builder thread produces for a contiguous range of su
     long dense = 0, pad = 0;
 };
 
-void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int sb1, Local *L) {
-    const int R = kTileRows, T = kTileCols, K = kTileChunk;
+void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int sb1, Local *L, int R) {
+    const int T = kTileCols, K = kTileChunk;
     const int ntile = (cols + T - 1) / T;
     std::vector<int> cnt(static_cast<size_t>(ntile), 0), slot(static_cast<size_t>(ntile), -1);
     std::vector<int> touched;
@@ -152,12 +152,13 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
 }  // namespace
 
 bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
-                 double min_dense_fraction) {
+                 double min_dense_fraction, int R) {
     *out = TiledHost();
     if (rows < min_rows || rows <= 0 || cols <= 0) return false;
     const long nnz = rowptr[rows];
     if (nnz <= 0) return false;
-    const int nsb = (rows + kTileRows - 1) / kTileRows;
+    if (R < 64 || R > kTileRows || R % 64 != 0) throw std::runtime_error("tiled build: unsupported super-block height");
+    const int nsb = (rows + R - 1) / R;
     // 16: a GPU's usual share of the host's cores (measured on the 16-CPU quota of the test box: 8 threads 1.01 s
     // of set-up, 16 0.69 s, 32 0.73 s, 64 0.70 s)
     int nt = static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
@@ -169,7 +170,7 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
     for (int t = 0; t < nt; ++t) {
         const int a = t * per, b = std::min(nsb, a + per);
         if (a >= b) break;
-        th.emplace_back(build_range, rows, cols, rowptr, col, a, b, &loc[t]);
+        th.emplace_back(build_range, rows, cols, rowptr, col, a, b, &loc[t], R);
     }
     for (auto &t : th) t.join();
     long dense = 0, pad = 0;
@@ -220,7 +221,7 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
     return true;
 }
 
-void DeviceTiled::upload(const TiledHost &h) {
+void DeviceTiled::upload(const TiledHost &h, int R) {
     n_tile = static_cast<long>(h.n_tile);
     n_rem = static_cast<long>(h.n_rem);
     n_steps = static_cast<int>(h.steps.size());
@@ -251,6 +252,7 @@ void DeviceTiled::upload(const TiledHost &h) {
         ro += pc.rcol.size();
     }
     view.valid = true;
+    view.R = R;
     view.nsb = nsb;
     view.sb_ptr = sb_ptr.p;
     view.sb_mid = sb_mid.p;

@@ -27,7 +27,7 @@
 namespace hprlp {
 
 constexpr int kTileThreads = 512;  // workgroup of the tiled kernel (8 waves)
-constexpr int kTileRows = 8192;    // rows per super-block: 64 KiB of accumulators in LDS
+constexpr int kTileRows = 8192;    // rows per super-block of the tall form: 64 KiB of accumulators in LDS
 constexpr int kTileCols = 2048;    // columns per tile: 16 KiB of the gathered vector in LDS
 constexpr int kTileChunk = 4;      // entries per lane per step
 constexpr int kTileStepCap = kTileThreads * kTileChunk;                       // entries per tile step
@@ -38,13 +38,22 @@ constexpr int kTileMaxRow = 1024;  // matrices with a longer row are not tiled: 
                                    // (2M x 2M, five rows of L entries, per launch: L = 1000 192 us, 3000 265-327 us, 8000 433-470 us; stream kernel 262 us)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
 static_assert(kTileRemK >= 1, "tile buffer too small for the remainder scratch");
-constexpr int kTileRowBits = 13;  // local row in an entry code
+constexpr int kTileRowBits = 13;  // local row in an entry code of the tall form
+// Super-block height (round 3).  The accumulators of a super-block take 8 bytes of LDS per row, so 8192 rows is the most;
+// a copy may use fewer (TiledDev::R, any multiple of 64 from kTileRowsMin up; the codes keep 13 bits for the local row).
+// Why: a matrix with fewer than 512 tall super-blocks does not fill the chip's 512 workgroup slots with whole super-blocks
+// and ran the piece form (three launches, partial sums through memory) or, below 2^20 columns, the stream kernel.  With
+// R = rows / 512 every slot gets exactly one super-block, the epilogue stays fused and a half-step is ONE launch with no
+// tail: 1M x 1M, band 1e4: 3658 it/s (stream kernel) / 3393 (pieces) -> 5287 (2048-row super-blocks, same-box A/B,
+// profiles/r03_ab_rows.txt).  The price is tile traffic -- a staged tile serves R rows -- so the height is only lowered
+// when a super-block's column window stays narrow against its entries (Solver::choose_sb_rows).
+constexpr int kTileRowsMin = 1024;
 static_assert((1 << kTileRowBits) == kTileRows && kTileCols <= (1 << (24 - kTileRowBits)) && kTileChunk == 4,
               "entry codes are 24 bits: 13 of local row, 11 of local column, four per chunk");
 inline uint32_t tile_code(int lcol, int row) { return (static_cast<uint32_t>(lcol) << kTileRowBits) | static_cast<uint32_t>(row); }
 
 constexpr int kTileResidentPerCu = 2;  // 80 KiB of LDS per workgroup, 160 KiB per CU
-constexpr int kFarGroup = 8192;        // source columns per workgroup of the remainder pre-pass (64 KiB of LDS)
+constexpr int kFarGroup = kTileRows;   // most source columns per workgroup of the remainder pre-pass (64 KiB of LDS); TiledDev::G
 constexpr int kFarThreads = 512;
 
 struct TileStep {
@@ -56,6 +65,9 @@ struct TileStep {
 
 struct TiledDev {
     bool valid = false;
+    int R = kTileRows;         // rows per super-block (kTileRowsMin .. kTileRows, multiple of 64)
+    int G = kTileRows;         // columns per source group of the remainder lists (= R of the matrix whose half-step produces
+                               // the gathered vector, so that its epilogue can hand the products over: kernels.h FarPush)
     int nsb = 0;               // super-blocks
     int per = 0;               // super-blocks per XCD: nsb rounded up to a multiple of 8, / 8
     int grid = 0;              // launch grid: 8 * min(per, resident workgroups of one XCD)
@@ -123,7 +135,7 @@ struct TiledHost {
 // Builds the tiled structure of a CSR pattern (rows x cols).  Returns false (and leaves `out` empty)
 // when the matrix is too small or too scattered for the tiled kernel to pay off.
 bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
-                 double min_dense_fraction);
+                 double min_dense_fraction, int R = kTileRows);
 
 // col_c / map_c (device, compact nnz entries): the CSR pattern without the rows whose compact length is zero (tiled_build.hip)
 void compact_without_rows(long nnz, int rows, const int *rp_dev, const int *rp_c_dev, const int *col_dev, int *col_c, int *map_c, hipStream_t s);
@@ -144,9 +156,10 @@ struct DeviceTiled {
     long n_tile = 0, n_rem = 0;
     long dense_entries = 0, padding = 0;
     int n_steps = 0;
-    void upload(const TiledHost &h);
+    void upload(const TiledHost &h, int R = kTileRows);
     void pack_indices(hipStream_t s);  // tidx -> tidx3
-    void build_far(int cols, hipStream_t s);  // remainder lists (rcol, rrow, rperm) -> the propagation-blocking lists
+    // remainder lists (rcol, rrow, rperm) -> the propagation-blocking lists with source groups of G columns
+    void build_far(int cols, hipStream_t s, int G = kTileRows);
     // launch shape (persistent workgroups per XCD) and the rotation of every super-block's sweep; rot_period is the
     // alignment period in tiles (0 = no rotation)
     void finish_schedule(hipStream_t s);
@@ -168,7 +181,7 @@ struct DeviceTiled {
     // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,
     // too scattered, or too large for 32-bit entry offsets) and nothing is valid.
     bool build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
-                         double min_dense_fraction, hipStream_t s);
+                         double min_dense_fraction, hipStream_t s, int R = kTileRows);
     // throws std::runtime_error naming the first difference between this (device-built) copy and the host builder's
     void compare_with(const TiledHost &h) const;
 };

@@ -25,9 +25,8 @@ namespace hprlp {
 
 namespace {
 
-constexpr int R = kTileRows, T = kTileCols, K = kTileChunk;
-constexpr int kRowBits = kTileRowBits;
-static_assert((1 << kRowBits) == R && kRowBits == kTileRowBits, "the key and the entry codes pack the local row in 13 bits");
+constexpr int T = kTileCols, K = kTileChunk;
+constexpr int kRowBits = kTileRowBits;  // the key and the entry codes pack the local row in 13 bits whatever the height R (<= 8192)
 
 __device__ __forceinline__ int row_of_entry(const int *__restrict__ rowptr, int rows, int k) {
     int lo = 0, hi = rows;  // rowptr[lo] <= k < rowptr[hi]
@@ -39,7 +38,7 @@ __device__ __forceinline__ int row_of_entry(const int *__restrict__ rowptr, int 
     return lo;
 }
 
-__global__ void __launch_bounds__(kThreads) k_make_keys(long nnz, int rows, int tile_bits, const int *__restrict__ rowptr,
+__global__ void __launch_bounds__(kThreads) k_make_keys(long nnz, int rows, int tile_bits, int R, const int *__restrict__ rowptr,
                                                        const int *__restrict__ col, unsigned long long *__restrict__ key,
                                                        int *__restrict__ idx) {
     const long k = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
@@ -72,13 +71,14 @@ __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long 
                                         char *__restrict__ flag_sorted, uint32_t *__restrict__ tidx, int *__restrict__ tperm,
                                         int out0, int *dense, int *pad) {
     int len_out = 0;  // entries emitted so far (position in the tile list)
-    int last_row = static_cast<int>(skey[begin] & (R - 1));
+    constexpr int RM = (1 << kRowBits) - 1;
+    int last_row = static_cast<int>(skey[begin] & RM);
     int i = begin;
     while (i < end) {
         const unsigned long long rkey = skey[i];
         int j = i + 1;
         while (j < end && skey[j] == rkey) ++j;
-        const int len = j - i, row = static_cast<int>(rkey & (R - 1));
+        const int len = j - i, row = static_cast<int>(rkey & RM);
         if (len > K) {  // long segment: remainder
             if (PASS == 1)
                 for (int q = i; q < j; ++q) flag_sorted[q] = 1;
@@ -100,7 +100,7 @@ __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long 
             if (PASS == 2) {
                 const int src = sperm[q];
                 tperm[out0 + len_out] = src;
-                tidx[out0 + len_out] = (static_cast<uint32_t>(col[src] - col0) << kTileRowBits) | static_cast<uint32_t>(row);
+                tidx[out0 + len_out] = (static_cast<uint32_t>(col[src] - col0) << kRowBits) | static_cast<uint32_t>(row);
             }
             ++len_out;
         }
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter_flags(long nnz, const char
     flag_orig[sperm[p]] = flag_sorted[p];
 }
 
-__global__ void __launch_bounds__(kThreads) k_rem_before(int nsb, int rows, const int *__restrict__ rowptr, const int *__restrict__ rem_prefix,
+__global__ void __launch_bounds__(kThreads) k_rem_before(int nsb, int rows, int R, const int *__restrict__ rowptr, const int *__restrict__ rem_prefix,
                                                         int *__restrict__ rem_before) {
     const int sb = blockIdx.x * kThreads + threadIdx.x;
     if (sb > nsb) return;
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(kThreads) k_rem_before(int nsb, int rows, cons
     rem_before[sb] = rem_prefix[rowptr[r < rows ? r : rows]];
 }
 
-__global__ void __launch_bounds__(kThreads) k_fill_remainder(int n_rem, int rows, const int *__restrict__ rem_k, const int *__restrict__ rowptr,
+__global__ void __launch_bounds__(kThreads) k_fill_remainder(int n_rem, int rows, int R, const int *__restrict__ rem_k, const int *__restrict__ rowptr,
                                                             const int *__restrict__ col, int *__restrict__ rperm, int *__restrict__ rcol,
                                                             uint16_t *__restrict__ rrow) {
     const int e = blockIdx.x * kThreads + threadIdx.x;
@@ -295,6 +295,8 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
     // forces a piece count (tests), 0 disables.
     view.n_pieces = 0;
     int want = (nsb > 0 && nsb <= resident * 8) ? resident * 8 : 0;
+    // a lowered super-block height (tiled.h) was chosen so that the slots get whole super-blocks: pieces only below one per CU
+    if (view.R < kTileRows && nsb >= cus) want = 0;
     if (const char *e = std::getenv("HPRLP_TILE_PIECES")) want = std::max(0, std::atoi(e));
     if (want > 0 && nsb > 0) {
         std::vector<int> h_ptr(static_cast<size_t>(nsb) + 1), h_mid(static_cast<size_t>(nsb));
@@ -349,7 +351,7 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
         piece_ptr.alloc(h_piece.size()); piece_ptr.upload(h_piece.data(), h_piece.size());
         slot_ptr.alloc(h_slot.size()); slot_ptr.upload(h_slot.data(), h_slot.size());
         segs.alloc(h_segs.size()); segs.upload(h_segs.data(), h_segs.size());
-        parts.alloc_zero(h_segs.size() * static_cast<size_t>(kTileRows));
+        parts.alloc_zero(h_segs.size() * static_cast<size_t>(view.R));
         view.n_pieces = np;
         view.piece_ptr = piece_ptr.p;
         view.slot_ptr = slot_ptr.p;
@@ -383,8 +385,9 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
 }
 
 bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
-                                  double min_dense_fraction, hipStream_t s) {
+                                  double min_dense_fraction, hipStream_t s, int R) {
     if (rows < min_rows || rows <= 0 || cols <= 0 || nnz <= 0 || nnz >= 2000000000L) return false;
+    if (R < 64 || R > kTileRows || R % 64 != 0) throw std::runtime_error("tiled build: unsupported super-block height");
     const int nsb = (rows + R - 1) / R;
     const int ntile = (cols + T - 1) / T;
     int tile_bits = 1;
@@ -395,7 +398,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
 
     DBuf<unsigned long long> key_in(static_cast<size_t>(nnz)), skey(static_cast<size_t>(nnz));
     DBuf<int> idx_in(static_cast<size_t>(nnz)), sperm(static_cast<size_t>(nnz));
-    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, rows, tile_bits, rowptr, col, key_in.p, idx_in.p);
+    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, rows, tile_bits, R, rowptr, col, key_in.p, idx_in.p);
     size_t tmp_bytes = 0;
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), 0,
                                                  key_bits, s));
@@ -471,7 +474,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     DBuf<int> first_run(static_cast<size_t>(nsb) + 1), rem_before(static_cast<size_t>(nsb) + 1);
     hipLaunchKernelGGL(k_first_run_of_sb, dim3(grid_for(nsb + 1)), dim3(kThreads), 0, s, nsb, nruns, tile_bits, run_start.p, skey.p,
                        first_run.p);
-    hipLaunchKernelGGL(k_rem_before, dim3(grid_for(nsb + 1)), dim3(kThreads), 0, s, nsb, rows, rowptr, rem_prefix.p, rem_before.p);
+    hipLaunchKernelGGL(k_rem_before, dim3(grid_for(nsb + 1)), dim3(kThreads), 0, s, nsb, rows, R, rowptr, rem_prefix.p, rem_before.p);
     HIP_CHECK(hipStreamSynchronize(s));
     DBuf<int> dsteps(static_cast<size_t>(nsb) + 1);  // tile steps before each super-block
     hipLaunchKernelGGL(k_gather_int, dim3(grid_for(nsb + 1)), dim3(kThreads), 0, s, nsb + 1, first_run.p, run_step_off.p, dsteps.p);
@@ -511,7 +514,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
         HIP_CHECK(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota, flag_orig.p, rem_k.p, nsel.p, static_cast<int>(nnz), s));
         DBuf<char> tmp(bytes + 16);
         HIP_CHECK(hipcub::DeviceSelect::Flagged(tmp.p, bytes, iota, flag_orig.p, rem_k.p, nsel.p, static_cast<int>(nnz), s));
-        hipLaunchKernelGGL(k_fill_remainder, dim3(grid_for(n_rem)), dim3(kThreads), 0, s, static_cast<int>(n_rem), rows, rem_k.p, rowptr, col,
+        hipLaunchKernelGGL(k_fill_remainder, dim3(grid_for(n_rem)), dim3(kThreads), 0, s, static_cast<int>(n_rem), rows, R, rem_k.p, rowptr, col,
                            rperm.p, rcol.p, rrow.p);
         HIP_CHECK(hipStreamSynchronize(s));
     }
@@ -523,6 +526,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     n_steps = total_steps;
     view = TiledDev();
     view.valid = true;
+    view.R = R;
     view.nsb = nsb;
     view.sb_ptr = sb_ptr.p;
     view.sb_mid = sb_mid.p;
@@ -566,11 +570,11 @@ __global__ void __launch_bounds__(kThreads) k_far_step_of(int nsb, const int *__
     }
 }
 
-__global__ void __launch_bounds__(kThreads) k_far_key_p(int n, const int *__restrict__ sb_of, const int *__restrict__ rcol,
+__global__ void __launch_bounds__(kThreads) k_far_key_p(int n, int G, const int *__restrict__ sb_of, const int *__restrict__ rcol,
                                                        unsigned long long *__restrict__ key, int *__restrict__ val) {
     const int e = blockIdx.x * kThreads + threadIdx.x;
     if (e >= n) return;
-    key[e] = (static_cast<unsigned long long>(sb_of[e]) << 32) | static_cast<unsigned long long>(rcol[e] / kFarGroup);
+    key[e] = (static_cast<unsigned long long>(sb_of[e]) << 32) | static_cast<unsigned long long>(rcol[e] / G);
     val[e] = e;
 }
 
@@ -594,22 +598,22 @@ __global__ void __launch_bounds__(kThreads) k_far_fill_q(int n, const unsigned l
     rq[i] = (static_cast<uint32_t>(slot) << 16) | static_cast<uint32_t>(rrow[e]);
 }
 
-__global__ void __launch_bounds__(kThreads) k_far_key_f(int n, const int *__restrict__ e_of_p, const int *__restrict__ rcol,
+__global__ void __launch_bounds__(kThreads) k_far_key_f(int n, int G, const int *__restrict__ e_of_p, const int *__restrict__ rcol,
                                                        unsigned long long *__restrict__ key, int *__restrict__ val) {
     const int p = blockIdx.x * kThreads + threadIdx.x;
     if (p >= n) return;
-    key[p] = (static_cast<unsigned long long>(rcol[e_of_p[p]] / kFarGroup) << 32) | static_cast<unsigned long long>(p);
+    key[p] = (static_cast<unsigned long long>(rcol[e_of_p[p]] / G) << 32) | static_cast<unsigned long long>(p);
     val[p] = e_of_p[p];
 }
 
-__global__ void __launch_bounds__(kThreads) k_far_fill_f(int n, const unsigned long long *__restrict__ skey, const int *__restrict__ e_sorted,
+__global__ void __launch_bounds__(kThreads) k_far_fill_f(int n, int G, const unsigned long long *__restrict__ skey, const int *__restrict__ e_sorted,
                                                         const int *__restrict__ rcol, const int *__restrict__ rperm, int *__restrict__ f_pos,
                                                         uint16_t *__restrict__ f_lcol, int *__restrict__ f_perm) {
     const int f = blockIdx.x * kThreads + threadIdx.x;
     if (f >= n) return;
     const int g = static_cast<int>(skey[f] >> 32), e = e_sorted[f];
     f_pos[f] = static_cast<int>(skey[f] & 0xffffffffu);
-    f_lcol[f] = static_cast<uint16_t>(rcol[e] - g * kFarGroup);
+    f_lcol[f] = static_cast<uint16_t>(rcol[e] - g * G);
     f_perm[f] = rperm[e];
 }
 
@@ -642,8 +646,10 @@ int bits_for(long v) {
 
 }  // namespace
 
-void DeviceTiled::build_far(int cols, hipStream_t s) {
+void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
     static_assert(kFarGroup <= 65536 && kTileRemCap <= 65536 && kTileRows <= 65536, "16-bit local columns, slots and rows");
+    if (G < 64 || G > kFarGroup) throw std::runtime_error("remainder lists: unsupported source-group size");
+    view.G = G;
     view.P = nullptr;
     view.rq = nullptr;
     view.n_groups = 0;
@@ -652,7 +658,7 @@ void DeviceTiled::build_far(int cols, hipStream_t s) {
         return;
     }
     const int n = static_cast<int>(n_rem), nsb = view.nsb;
-    const int ngroups = (cols + kFarGroup - 1) / kFarGroup;
+    const int ngroups = (cols + G - 1) / G;
     DBuf<int> step_of(static_cast<size_t>(n)), sb_of(static_cast<size_t>(n));
     const char *no2 = std::getenv("HPRLP_NO_REM2");  // diagnostic: long runs of the remainder added by one lane, as before
     hipLaunchKernelGGL(k_far_step_of, dim3(nsb), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, rrow.p, step_of.p, sb_of.p, !(no2 && no2[0] == '1'));
@@ -676,7 +682,7 @@ void DeviceTiled::build_far(int cols, hipStream_t s) {
     DBuf<unsigned long long> kin(static_cast<size_t>(n)), kout(static_cast<size_t>(n));
     DBuf<int> vin(static_cast<size_t>(n)), e_of_p(static_cast<size_t>(n));
     // P order
-    hipLaunchKernelGGL(k_far_key_p, dim3(grid_for(n)), dim3(kThreads), 0, s, n, sb_of.p, rcol.p, kin.p, vin.p);
+    hipLaunchKernelGGL(k_far_key_p, dim3(grid_for(n)), dim3(kThreads), 0, s, n, G, sb_of.p, rcol.p, kin.p, vin.p);
     sort_pairs(kin, kout, vin, e_of_p, n, 32 + bits_for(nsb), s);
     sb_of.release();
     // rq: the entries of every step range of P in e order
@@ -688,14 +694,14 @@ void DeviceTiled::build_far(int cols, hipStream_t s) {
     HIP_CHECK(hipStreamSynchronize(s));
     step_of.release();
     // source side
-    hipLaunchKernelGGL(k_far_key_f, dim3(grid_for(n)), dim3(kThreads), 0, s, n, e_of_p.p, rcol.p, kin.p, vin.p);
+    hipLaunchKernelGGL(k_far_key_f, dim3(grid_for(n)), dim3(kThreads), 0, s, n, G, e_of_p.p, rcol.p, kin.p, vin.p);
     sort_pairs(kin, kout, vin, p_sorted, n, 32 + bits_for(ngroups), s);  // p_sorted now holds e in f order
     f_pos.alloc_zero(static_cast<size_t>(n) + 8);
     f_lcol.alloc_zero(static_cast<size_t>(n) + 8);
     f_perm.alloc(static_cast<size_t>(n) + 8);
     f_val.alloc_zero(static_cast<size_t>(n) + 8);
     f_gptr.alloc(static_cast<size_t>(ngroups) + 1);
-    hipLaunchKernelGGL(k_far_fill_f, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kout.p, p_sorted.p, rcol.p, rperm.p, f_pos.p, f_lcol.p, f_perm.p);
+    hipLaunchKernelGGL(k_far_fill_f, dim3(grid_for(n)), dim3(kThreads), 0, s, n, G, kout.p, p_sorted.p, rcol.p, rperm.p, f_pos.p, f_lcol.p, f_perm.p);
     hipLaunchKernelGGL(k_far_gptr, dim3(grid_for(ngroups + 1)), dim3(kThreads), 0, s, ngroups, n, kout.p, f_gptr.p);
     P.alloc_zero(static_cast<size_t>(n) + 8);
     HIP_CHECK(hipStreamSynchronize(s));

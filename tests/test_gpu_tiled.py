@@ -190,3 +190,68 @@ def test_tiled_matrix_with_long_rows(gpu, force_tiled):
     s2 = hprlp.Solver(model2, hprlp.Parameters(use_presolve=False))
     assert s2.info()["tiled"] & 1 == 0
     s2.close(); model2.free()
+
+
+@pytest.mark.parametrize("rows_sb,pieces", [(1984, None), (3008, None), (2048, 5)])
+def test_lowered_super_block_height_matches_oracle(gpu, force_tiled, rows_sb, pieces):
+    """Super-blocks of fewer than 8192 rows (tiled.h: one super-block per workgroup slot for mid-size matrices; any multiple of
+    64): fused form, hand-off between the half-steps (a source group of one matrix' remainder = a super-block of the other)
+    and the piece form on top of it -- same iterates as the oracle, device and host builders equal array for array."""
+    old = {k: os.environ.get(k) for k in ("HPRLP_TILE_ROWS", "HPRLP_TILE_PIECES", "HPRLP_TILING_CHECK")}
+    os.environ["HPRLP_TILE_ROWS"] = str(rows_sb)
+    os.environ["HPRLP_TILING_CHECK"] = "1"  # (the host builder needs host column indices: both matrices have them below 4 M entries)
+    os.environ["HPRLP_TILE_PIECES"] = str(pieces or 0)  # (0: the fused form although the test matrix has few super-blocks)
+    try:
+        m, n = 30011, 26000
+        lp, model = build(m, n, 12, 600)
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+        assert s.info()["tiled"] == 3
+        d = s.describe()
+        assert f"{-(-m // rows_sb)} super-blocks" in d and f"{-(-n // rows_sb)} super-blocks" in d, d
+        assert ("piece form" in d) == bool(pieces), d
+        ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                         O.Params.default(use_CR_scaling=0))
+        s.scale()
+        adopt_gpu_data(s, ref)
+        st = run_steps(s, ref, 0.6, 1.4, [(23, True), (5, True), (11, False)])
+        for name in NAMES_N + NAMES_M:
+            np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+        lam, it = s.power_iteration()
+        lam_ref, it_ref = ref.power_iteration()
+        assert it == it_ref and abs(lam - lam_ref) <= 1e-11 * lam_ref
+        s.close(); model.free()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_mid_size_banded_lp_gets_one_super_block_per_slot(gpu):
+    """No environment overrides: a 1M x 1M LP with a window of 2e4 columns has 123 full-height super-blocks -- fewer than the
+    chip's 512 workgroup slots.  Solver::choose_sb_rows lowers the height so that there are at most 512 and at least 384,
+    the half-steps run the FUSED tiled kernel (one launch each), and the whole solve reaches the planted optimum in the
+    same number of iterations as with the stream kernel (+- the usual fork at a thresholded restart decision)."""
+    m = n = 1_000_000
+    lp = bh.banded_lp(m, n, 20, 10_000)
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    d = s.describe()
+    s.close()
+    assert "tiled, fused" in d and "piece form" not in d and "stream kernel" not in d, d
+    import re
+    nsb = [int(x) for x in re.findall(r"(\d+) super-blocks", d)]
+    assert len(nsb) == 2 and all(384 <= k <= 512 for k in nsb), d
+    prm = hprlp.Parameters(stop_tol=1e-4, use_presolve=False, max_iter=20000)
+    r = model.solve(prm)
+    os.environ["HPRLP_NO_TILED"] = "1"
+    try:
+        r0 = model.solve(prm)
+    finally:
+        os.environ.pop("HPRLP_NO_TILED", None)
+    assert r.status == r0.status == "OPTIMAL"
+    assert abs(r.iter - r0.iter) <= 0.1 * r0.iter + 150, (r.iter, r0.iter)
+    assert abs(r.primal_obj - lp["obj_star"]) <= 1e-3 * (1 + abs(lp["obj_star"]))
+    assert abs(r.primal_obj - r0.primal_obj) <= 1e-4 * (1 + abs(r0.primal_obj))
+    model.free()
