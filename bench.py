@@ -628,7 +628,9 @@ def main():
                                       # the reference's own instrument (HPRLP_results.time4 / iter4, include/structs.h:50-57)
                                       "time4_s": r.time4, "iter4": r.iter4,
                                       "reference_style_iterations_per_s": r.iter / max(r.time, 1e-9),
-                                      "status": r.status, "rel_obj_err": abs(r.primal_obj - obj_star) / (1 + abs(obj_star))}
+                                      "status": r.status, "rel_obj_err": abs(r.primal_obj - obj_star) / (1 + abs(obj_star)),
+                                      # where `seconds` goes (hprlp_last_solve_phases); the reference's `time` = power iteration + loop
+                                      "phases_s": H.last_solve_phases()}
             except Exception as e:
                 out["time_to_tol"] = {"error": str(e)}
             model.free()

@@ -51,14 +51,28 @@ static void print_banner_and_parameters(const HPRLP_parameters *p) {
 extern "C" const char *hprlp_last_error(void) { return last_error_cstr(); }
 extern "C" const char *hprlp_backend(void) { return HPRLP_BACKEND_STRING; }
 
+// phases of the calling thread's last HPRLP_main_solve (hprlp_last_solve_phases): device set-up (upload, transpose, tiled
+// copies, ordering), scaling, power iteration, loop, solution's way back, teardown of the device state, whole call
+static thread_local double g_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+extern "C" int hprlp_last_solve_phases(double out[8]) {
+    if (!out) return -1;
+    for (int i = 0; i < 8; ++i) out[i] = g_phases[i];
+    return 0;
+}
+
 // reference src/HPRLP.cu:116-311
 extern "C" HPRLP_results HPRLP_main_solve(const LP_info_cpu *model, const HPRLP_parameters *param) {
     if (!model || !param) {
         std::cerr << "[error] Null model or parameter pointer" << std::endl;
         return make_error_result("ERROR");
     }
+    const auto t_call = time_now();
     try {
         print_banner_and_parameters(param);
+        HPRLP_results out;
+        auto t_down = time_now();
+        {
         Solver s;
         s.setup(model, param);
         std::cout << "Setup (copy and allocation) time = " << std::fixed << std::setprecision(2) << s.setup_time
@@ -71,9 +85,17 @@ extern "C" HPRLP_results HPRLP_main_solve(const LP_info_cpu *model, const HPRLP_
         std::cout << "ESTIMATING MAXIMUM EIGENVALUE time = " << std::fixed << std::setprecision(2) << s.power_time
                   << " seconds" << std::endl << std::defaultfloat;
         s.init_iteration_state();
-        HPRLP_results out;
+        const auto t_loop = time_now();
         s.solve_loop(&out);
+        const double loop_s = time_since(t_loop);
+        const auto t_col = time_now();
         s.collect_solution(&out);
+        g_phases[0] = s.setup_time; g_phases[1] = s.scaling_time; g_phases[2] = s.power_time; g_phases[3] = loop_s;
+        g_phases[4] = time_since(t_col);
+        t_down = time_now();
+        }  // (the solver's device state goes here: part of the call's wall time)
+        g_phases[5] = time_since(t_down);
+        g_phases[6] = time_since(t_call);
         std::cout << "\n=== Solution Summary ===\n"
                   << "Status: " << out.status << "\nIterations: " << out.iter << "\nTime: " << out.time
                   << " seconds\nPrimal Objective: " << std::scientific << std::setprecision(12) << out.primal_obj

@@ -142,8 +142,10 @@ void launch_resid_p(const CsrDev &A, const double *xbar_full, const double *xtem
 // <A x_temp, y_temp> partials only (reference compute_weighted_norm, main_iterate.cu:486-515)
 void launch_gap(const CsrDev &A, const double *xtemp_full, const double *y_temp, double *partials, hipStream_t s);
 // out = M v ; optionally partials of out.out and out.q  (power iteration)
+// plain product whose epilogue hands the remainder products of the OTHER matrix over (returns true if it did)
+bool launch_spmv_push(const CsrDev &M, const double *v_full, double *out, const FarPush &push, hipStream_t s);
 void launch_spmv_plain(const CsrDev &M, const double *v_full, double *out, const double *q, bool with_dots,
-                       double *partials, int stride, hipStream_t s);
+                       double *partials, int stride, hipStream_t s, bool far_ready = false);
 
 void launch_finalize(const FinalizeArgs &f, double *scalars, hipStream_t s);
 
@@ -199,6 +201,8 @@ struct SmallArgs {
 };
 bool small_path_fits(int m, int n, long nnz, int max_row_A, int max_row_AT);
 void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s);
+// the whole power iteration of a small LP in one launch (small.hip): z0 = start vector (m), out = {lambda, iterations done}
+void launch_small_power(const SmallArgs &a, const double *z0, int max_iter, double tol, double *out, hipStream_t s);
 
 // device CSR -> device CSR of the transpose, stable in row order (transpose.hip); all pointers are device memory,
 // trp has cols+1 entries, tci / tv nnz

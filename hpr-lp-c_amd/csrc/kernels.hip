@@ -1095,6 +1095,24 @@ struct PlainEpi {
     }
 };
 
+// plain product whose result is the OTHER matrix' gathered vector next (power iteration: A^T q feeds A): the epilogue hands the
+// remainder products over like the half-steps do (kernels.h FarPush)
+struct PlainPushEpi {
+    static constexpr int NV = 1;
+    static constexpr int NACC = 0;
+    const double *gv[1];
+    double *out;
+    FarPush push;
+    static constexpr bool kPublishes = true;
+    struct Row {};
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ Row load_row(int) const { return Row{}; }
+    __device__ __forceinline__ double apply(int r, const Row &, const double (&s)[1], double (&)[1]) const {
+        out[r] = s[0];
+        return s[0];
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers of the fused kernel
 // ------------------------------------------------------------------------------------------------
@@ -1299,11 +1317,19 @@ void launch_gap(const CsrDev &A, const double *xtemp_full, const double *y_temp,
     launch_fused(A, e, s);
 }
 
+bool launch_spmv_push(const CsrDev &M, const double *v_full, double *out, const FarPush &push, hipStream_t s) {
+    PlainPushEpi e{{v_full}, out, push};
+    return launch_fused(M, e, s);
+}
+
 void launch_spmv_plain(const CsrDev &M, const double *v_full, double *out, const double *q, bool with_dots,
-                       double *partials, int stride, hipStream_t s) {
+                       double *partials, int stride, hipStream_t s, bool far_ready) {
     if (with_dots) {
         PlainEpi<true> e{{v_full}, out, q, partials, stride};
-        launch_fused(M, e, s);
+        launch_fused(M, e, s, far_ready);
+    } else if (far_ready) {
+        PlainEpi<false> e{{v_full}, out, nullptr, nullptr, 0};
+        launch_fused(M, e, s, true);
     } else {
         PlainEpi<false> e{{v_full}, out, nullptr, nullptr, 0};
         launch_fused(M, e, s);

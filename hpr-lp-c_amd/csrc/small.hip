@@ -181,6 +181,155 @@ __global__ void __launch_bounds__(NT) k_small_iterations(SmallArgs a, int K, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The power iteration of a small LP (reference power_method_cusparse, src/power_iteration.cu:20-119) in ONE launch of the
+// same single workgroup: q = z / sqrt(z.z + eps), z = A (A^T q), every 10th iteration lambda = q.z and the stopping test
+// |z - lambda q| < tol -- decided on the device, so the host neither launches 6 kernels per iteration nor waits for the
+// stream every 10th (config 2: 600 iterations, 10 ms -> 2 ms).  Same row sums as the regular kernels (products added in
+// CSR order); the three dot products are added in a fixed tree order (thread, wave shuffle, 16 wave sums), i.e. they
+// agree with the oracle's sequential sums to rounding.  out = {lambda, iterations done}.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int KMAX, int R>
+__global__ void __launch_bounds__(NT) k_small_power(SmallArgs a, int K, const double *__restrict__ z0, int max_iter, double tol,
+                                                   double *__restrict__ out) {
+    __shared__ double prod[NT * KMAX + NT * KMAX / 32 + 1];
+    __shared__ double qs[NT * R];   // q (length m), gathered by the products of A^T q
+    __shared__ double gs[NT * R];   // A^T q (length n), gathered by the products of A (A^T q)
+    __shared__ double red[2][3][NT / 64];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    double v[KMAX];
+    unsigned int ij[KMAX], pa[KMAX / 2];
+    const int e0 = t * K;
+#pragma unroll
+    for (int k = 0; k < KMAX; k += 2) {
+        const int q0 = e0 + k, q1 = q0 + 1;
+        const bool on0 = k < K && q0 < a.nnz, on1 = k + 1 < K && q1 < a.nnz;
+        v[k] = on0 ? a.AT_val[q0] : 0.0;
+        v[k + 1] = on1 ? a.AT_val[q1] : 0.0;
+        ij[k] = on0 ? static_cast<unsigned int>(a.ent_ij[q0]) : 0u;
+        ij[k + 1] = on1 ? static_cast<unsigned int>(a.ent_ij[q1]) : 0u;
+        const unsigned int park = static_cast<unsigned int>(NT * KMAX - 1);
+        const unsigned int p0 = on0 ? static_cast<unsigned int>(a.ent_posA[q0]) : park;
+        const unsigned int p1 = on1 ? static_cast<unsigned int>(a.ent_posA[q1]) : park;
+        pa[k >> 1] = p0 | (p1 << 16);
+    }
+    double z[R];
+    unsigned int xseg[R], yseg[R], own[R];
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int slot = t + NT * q;
+        const bool on = slot < a.n, oni = slot < a.m;
+        const int j = on ? a.order_x[slot] : 0, i = oni ? a.order_y[slot] : 0;
+        own[q] = static_cast<unsigned int>(on ? j : 0xffff) | (static_cast<unsigned int>(oni ? i : 0xffff) << 16);
+        const int xs = on ? a.AT_rowptr[j] : 0, xe = on ? a.AT_rowptr[j + 1] : 0;
+        xseg[q] = static_cast<unsigned int>(xs) | (static_cast<unsigned int>(xe - xs) << 16);
+        const int ysb = oni ? a.A_rowptr[i] : 0, ye = oni ? a.A_rowptr[i + 1] : 0;
+        yseg[q] = static_cast<unsigned int>(ysb) | (static_cast<unsigned int>(ye - ysb) << 16);
+        z[q] = oni ? z0[i] : 0.0;
+        part += z[q] * z[q];
+    }
+    // block sums of up to three values, identical in every thread: thread partial -> wave shuffle -> the 16 wave sums in order
+    int flip = 0;
+    auto block_sum3 = [&](double &s0, double &s1, double &s2) {
+        const double w0 = wave_sum64(s0), w1 = wave_sum64(s1), w2 = wave_sum64(s2);
+        if (lane == 0) {
+            red[flip][0][wave] = w0;
+            red[flip][1][wave] = w1;
+            red[flip][2][wave] = w2;
+        }
+        lds_sync();
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) {
+            r0 += red[flip][0][w];
+            r1 += red[flip][1][w];
+            r2 += red[flip][2][w];
+        }
+        flip ^= 1;  // the next sum writes the other buffer: no barrier needed before it
+        s0 = r0; s1 = r1; s2 = r2;
+    };
+    double zz = part, d1 = 0.0, d2 = 0.0;
+    block_sum3(zz, d1, d2);
+    double lambda = 1.0;
+    int done = max_iter;
+    for (int it = 1; it <= max_iter; ++it) {
+        const double invn = 1.0 / sqrt(zz + 2.220446049250313e-16);
+        double qv[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            qv[q] = invn * z[q];
+            if ((own[q] >> 16) != 0xffffu) qs[own[q] >> 16] = qv[q];
+        }
+        lds_sync();
+        // A^T q: products in A^T order, row sums in CSR order
+#pragma unroll
+        for (int k = 0; k < KMAX; k += 2) {
+            const double g0 = qs[fresh(ij[k]) & 0xffffu], g1 = qs[fresh(ij[k + 1]) & 0xffffu];
+            const int qq = static_cast<int>(fresh(static_cast<unsigned int>(e0))) + k;
+            if (k < K) prod[pad(qq)] = v[k] * g0;
+            if (k + 1 < K) prod[pad(qq + 1)] = v[k + 1] * g1;
+        }
+        lds_sync();
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const double sx = seq_sum(prod, static_cast<int>(xseg[q] & 0xffffu), static_cast<int>(xseg[q] >> 16));
+            if ((own[q] & 0xffffu) != 0xffffu) gs[own[q] & 0xffffu] = sx;
+        }
+        lds_sync();
+        // A (A^T q): products scattered to their position in the CSR order of A
+#pragma unroll
+        for (int k = 0; k < KMAX; k += 2) {
+            const double g0 = gs[fresh(ij[k]) >> 16], g1 = gs[fresh(ij[k + 1]) >> 16];
+            const unsigned int pp = fresh(pa[k >> 1]);
+            prod[pad(static_cast<int>(pp & 0xffffu))] = v[k] * g0;
+            prod[pad(static_cast<int>(pp >> 16))] = v[k + 1] * g1;
+        }
+        lds_sync();
+        double pzz = 0.0, pqz = 0.0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const double sy = seq_sum(prod, static_cast<int>(yseg[q] & 0xffffu), static_cast<int>(yseg[q] >> 16));
+            z[q] = (own[q] >> 16) != 0xffffu ? sy : 0.0;
+            pzz += z[q] * z[q];
+            pqz += z[q] * qv[q];
+        }
+        double dummy = 0.0;
+        block_sum3(pzz, pqz, dummy);
+        zz = pzz;
+        if (it % 10 == 0) {
+            lambda = pqz;
+            double pe = 0.0, u1 = 0.0, u2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const double d = -lambda * qv[q] + 1.0 * z[q];
+                pe += d * d;
+            }
+            block_sum3(pe, u1, u2);
+            if (sqrt(pe) < tol) {  // (the same value in every thread: a uniform exit)
+                done = it;
+                break;
+            }
+        }
+    }
+    if (t == 0) {
+        out[0] = lambda;
+        out[1] = static_cast<double>(done);
+    }
+}
+
+template <int KMAX, int R>
+void launch_power_kr(const SmallArgs &a, const double *z0, int max_iter, double tol, double *out, hipStream_t s) {
+    const int K = (a.nnz + NT - 1) / NT;
+    hipLaunchKernelGGL((k_small_power<KMAX, R>), dim3(1), dim3(NT), 0, s, a, K, z0, max_iter, tol, out);
+}
+
 template <int KMAX, int R>
 void launch_kr(const SmallArgs &a, int count, hipStream_t s) {
     const int K = (a.nnz + NT - 1) / NT;
@@ -192,6 +341,17 @@ void launch_kr(const SmallArgs &a, int count, hipStream_t s) {
 bool small_path_fits(int m, int n, long nnz, int max_row_A, int max_row_AT) {
     return m >= 1 && n >= 1 && m <= NT * kSmallMaxR && n <= NT * kSmallMaxR && nnz >= 1 &&
            nnz < static_cast<long>(NT) * kSmallMaxK && max_row_A <= kSmallMaxRow && max_row_AT <= kSmallMaxRow;
+}
+
+void launch_small_power(const SmallArgs &a, const double *z0, int max_iter, double tol, double *out, hipStream_t s) {
+    const int K = (a.nnz + NT - 1) / NT;
+    const int R = (std::max(a.m, a.n) + NT - 1) / NT;
+    if (K <= 4 && R <= 1) launch_power_kr<4, 1>(a, z0, max_iter, tol, out, s);
+    else if (K <= 4) launch_power_kr<4, 2>(a, z0, max_iter, tol, out, s);
+    else if (K <= 8 && R <= 1) launch_power_kr<8, 1>(a, z0, max_iter, tol, out, s);
+    else if (K <= 8) launch_power_kr<8, 2>(a, z0, max_iter, tol, out, s);
+    else if (R <= 1) launch_power_kr<12, 1>(a, z0, max_iter, tol, out, s);
+    else launch_power_kr<12, 2>(a, z0, max_iter, tol, out, s);
 }
 
 void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s) {

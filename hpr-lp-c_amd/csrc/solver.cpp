@@ -915,6 +915,21 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
         HIP_CHECK(hipMemcpyAsync(z, z0.data(), sizeof(double) * m_loc, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
+    const bool no_small_power = std::getenv("HPRLP_NO_SMALL_POWER") != nullptr;  // tests: the regular kernels instead
+    if (use_small && !comm && !no_small_power) {
+        // Netlib-scale LP: the whole power iteration in one launch of the single-workgroup kernel (small.hip), stopping test on
+        // the device; the host waits once
+        const SmallArgs a{m, n, A.view.nnz, A.view.rowptr, AT.view.rowptr, AT.view.val, small_ij.p, small_posA.p,
+                          small_order_x.p, small_order_y.p, x.p, x_hat, y, l.p, u.p, c.p, last_x.p, AL.p, AU.p, last_y.p, ctrl.p};
+        launch_small_power(a, z, max_iter, tol, scal.p + S_TMP1, stream);
+        fetch_scalars();
+        const double lambda_dev = scal_h[S_TMP1];
+        const int done_dev = static_cast<int>(scal_h[S_TMP1 + 1]);
+        if (iters) *iters = done_dev;
+        power_iters = done_dev;
+        power_time = time_since(t0);
+        return lambda_dev;
+    }
     launch_norm2(z, m_loc, part_v.p, kReduceBlocks, stream);
     FinalizeArgs f0{};
     f0.n = 1;
@@ -928,9 +943,10 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
     for (int i = 1; i <= max_iter; ++i) {
         launch_pw_normalize(z, q, m_loc, scal.p, stream);
         gather(gsm.p, true);
-        launch_spmv_plain(AT.view, gsm.p, ATq, nullptr, false, nullptr, 0, stream);
+        // A^T q: its epilogue writes the products A's remainder needs (hand-off, as between the half-steps): A runs without a pre-pass
+        const bool handed = launch_spmv_push(AT.view, gsm.p, ATq, push_into(A, AT), stream);
         gather(gsn.p, false);
-        launch_spmv_plain(A.view, gsn.p, z, q, true, part_y.p, stride_y, stream);
+        launch_spmv_plain(A.view, gsn.p, z, q, true, part_y.p, stride_y, stream, handed);
         FinalizeArgs f{};
         f.n = 2;
         f.item[0] = {part_y.p, gridA, S_PW_ZZ};

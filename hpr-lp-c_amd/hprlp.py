@@ -291,6 +291,16 @@ class Presolved:
             self.h = None
 
 
+def last_solve_phases():
+    """Phases [s] of this thread's last HPRLP_main_solve (hprlp_last_solve_phases)."""
+    out = (C.c_double * 8)()
+    L = lib()
+    L.hprlp_last_solve_phases.argtypes = [C.POINTER(C.c_double)]
+    L.hprlp_last_solve_phases(out)
+    keys = ("device_setup", "scaling", "power_iteration", "loop", "collect_solution", "teardown", "whole_call")
+    return dict(zip(keys, [float(v) for v in out]))
+
+
 def original_kkt(model, x, y, z):
     """Relative primal / dual infeasibility and gap of (x, y, z) on the model as given."""
     x, y, z = _as(x, np.float64), _as(y, np.float64), _as(z, np.float64)

@@ -73,6 +73,12 @@ int hprlp_solver_get_scalars(hprlp_solver *s, double out[16]);
  *        tiled flags (bit0: A, bit1: A^T use the column-tiled kernel)} */
 int hprlp_solver_info(hprlp_solver *s, long out[8]);
 
+/* Wall-clock phases [s] of the calling thread's last HPRLP_main_solve (what solve() runs after presolve):
+ * out = {device set-up (upload, transpose, tiled copies, ordering), scaling, power iteration, loop, solution's way back,
+ *        teardown of the device state, whole call, 0}.  The reference's instrument covers power iteration + loop only
+ * (HPRLP_results.time, src/HPRLP.cu:150,246). */
+int hprlp_last_solve_phases(double out[8]);
+
 /* Human-readable: which kernel form runs on A and on A^T (stream / tiled fused / tiled pieces), super-blocks, steps, share of the
  * entries in staged tiles, long rows kept aside, small-LP kernel, locality ordering.  Returns the length (truncated to cap). */
 int hprlp_solver_describe(hprlp_solver *s, char *buf, int cap);

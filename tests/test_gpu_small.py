@@ -24,6 +24,9 @@ def make(lp):
 def iterate_states(model, prm, plan, no_small):
     old = os.environ.get("HPRLP_NO_SMALL")
     os.environ["HPRLP_NO_SMALL"] = "1" if no_small else "0"
+    # (what is compared bit for bit are the ITERATION kernels: lambda_max comes from the regular power iteration in both runs;
+    # the single-launch one adds its dot products in another order -- test_small_power_iteration_matches_... below)
+    os.environ["HPRLP_NO_SMALL_POWER"] = "1"
     try:
         s = hprlp.Solver(model, prm)
         assert bool(s.info()["tiled"] & 4) == (not no_small)
@@ -39,6 +42,7 @@ def iterate_states(model, prm, plan, no_small):
         s.close()
         return out, res
     finally:
+        os.environ.pop("HPRLP_NO_SMALL_POWER", None)
         if old is None:
             os.environ.pop("HPRLP_NO_SMALL", None)
         else:
@@ -101,16 +105,47 @@ def test_small_kernel_matches_oracle(gpu, dense):
     s.close(); model.free()
 
 
+def test_small_power_iteration_matches_regular_kernels_and_oracle(gpu):
+    """The whole power iteration in one launch of the single-workgroup kernel (k_small_power, stopping test on the device):
+    same number of iterations as the regular kernels (host test every 10th) and as the oracle, lambda equal to rounding
+    (the three dot products are added in another order)."""
+    for lp in (lpgen.c2_25fv47_like(), lpgen.planted_lp(400, 650, 4000, 8), lpgen.planted_lp(1900, 1200, 9000, 4)):
+        model = make(lp)
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        assert s.info()["tiled"] & 4
+        s.scale()
+        lam, it = s.power_iteration()
+        os.environ["HPRLP_NO_SMALL_POWER"] = "1"
+        try:
+            lam_r, it_r = s.power_iteration()
+        finally:
+            os.environ.pop("HPRLP_NO_SMALL_POWER", None)
+        ref = O.ScaledLP(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                         O.Params.default())
+        lam_o, it_o = ref.power_iteration()
+        assert it == it_r == it_o, (it, it_r, it_o)
+        assert abs(lam - lam_r) <= 1e-12 * lam_r and abs(lam - lam_o) <= 1e-11 * lam_o, (lam, lam_r, lam_o)
+        # a capped run stops at the cap and still reports the last lambda it formed
+        lam_c, it_c = s.power_iteration(max_iter=25)
+        assert it_c == 25 and lam_c > 0
+        s.close(); model.free()
+
+
 def test_whole_solve_on_the_small_path(gpu):
     lp = lpgen.c2_25fv47_like()
     model = make(lp)
     prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+    # (bit-for-bit comparison of the ITERATION kernels: both solves take lambda_max from the regular power iteration --
+    # the single-launch one adds its dot products in another order, test above)
+    os.environ["HPRLP_NO_SMALL_POWER"] = "1"
     os.environ["HPRLP_NO_SMALL"] = "1"
     try:
         r_reg = model.solve(prm)
+        os.environ.pop("HPRLP_NO_SMALL", None)
+        r_small = model.solve(prm)
     finally:
         os.environ.pop("HPRLP_NO_SMALL", None)
-    r_small = model.solve(prm)
+        os.environ.pop("HPRLP_NO_SMALL_POWER", None)
     assert r_small.status == r_reg.status == "OPTIMAL"
     assert r_small.iter == r_reg.iter and r_small.primal_obj == r_reg.primal_obj
     assert np.array_equal(r_small.x, r_reg.x) and np.array_equal(r_small.y, r_reg.y)
