@@ -233,20 +233,29 @@ def side_configs():
         nnz = len(lp["values"])
         rate = 2000 / (t["total_ms"] * 1e-3)
         s.close()
-        s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
-        s.scale()
-        lam, pw_it = s.power_iteration()
-        s.init(-1.0, lam * 1.01)
-        t0 = time.time()
-        r = s.run()
-        tt = time.time() - t0
+        # time to 1e-4 = power iteration + loop (wall of hprlp_solver_run incl. the solution's way back).  These solves are
+        # 30-50 ms of ~1500 launches and ~400 host waits: a neighbour on the host's cores or a GPU clock that has dropped
+        # shows as a 3 x longer run now and then (tools/probe_small_env.py: 0.029 s or 0.10 s for the same loop), so the
+        # leg runs three times; the figure is the fastest, all three are listed
+        runs = []
+        for _rep in range(3):
+            s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
+            s.scale()
+            lam, pw_it = s.power_iteration()
+            s.init(-1.0, lam * 1.01)
+            t0 = time.time()
+            r = s.run()
+            tt = time.time() - t0
+            runs.append({"power_iteration": s.scalars()["power_time"], "power_iterations": int(pw_it), "loop_wall": tt,
+                         "solver_reported": r.time, "total": tt + s.scalars()["power_time"]})
+            if _rep < 2:
+                s.close()
+        best = min(runs, key=lambda q: q["total"])
         out[key] = {"m": lp["m"], "n": lp["n"], "nnz": nnz, "iterations_per_s": rate,
                     "GBps_algorithmic": bytes_per_iteration(lp["m"], lp["n"], nnz) * rate / 1e9,
-                    "time_to_1e-4_s": tt + s.scalars()["power_time"], "iters_to_1e-4": r.iter, "status": r.status,
-                    # what the figure is made of: power iteration + the loop (wall of hprlp_solver_run incl. the solution's
-                    # way back); solver_reported_s is HPRLP_results.time (power iteration + loop, reference src/HPRLP.cu:150,246)
-                    "time_to_1e-4_parts_s": {"power_iteration": s.scalars()["power_time"], "power_iterations": int(pw_it),
-                                             "loop_wall": tt, "solver_reported": r.time},
+                    "time_to_1e-4_s": best["total"], "iters_to_1e-4": r.iter, "status": r.status,
+                    # solver_reported is HPRLP_results.time (power iteration + loop, reference src/HPRLP.cu:150,246)
+                    "time_to_1e-4_parts_s": best, "time_to_1e-4_all_runs_s": [q["total"] for q in runs],
                     "rel_obj_err": abs(r.primal_obj - lp["obj_star"]) / (1 + abs(lp["obj_star"]))}
         s.close()
         if key == "c3_pds20_like":
