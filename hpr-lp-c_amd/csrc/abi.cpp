@@ -681,6 +681,10 @@ extern "C" int hprlp_solver_set_vector(hprlp_solver *h, const char *name, const 
             HIP_CHECK(hipMemcpy(v.p, in, sizeof(double) * v.n, hipMemcpyHostToDevice));
         }
     }
+    if (v.p == h->s.l.p || v.p == h->s.u.p) {  // the bound codes follow the arrays
+        h->s.refresh_bound_codes();
+        HIP_CHECK(hipStreamSynchronize(h->s.stream));
+    }
     return 0;
     GUARD_END(-1)
 }

@@ -99,7 +99,14 @@ struct XHalfArgs {
     int stride;
     FarPush push;            // x_hat's products into the remainder buffer of A (consumed by the y-half)
     bool far_ready = false;  // A^T's remainder buffer already holds the products of y_full (pushed by the y-half before)
+    // one byte per column saying which of l[j], u[j] the update has to READ (launch_bound_codes): the common bounds -- lower
+    // bound 0 or -inf, upper bound +inf -- are constants of the code and cost no 8-byte load (LPs have l = 0, u = +inf on
+    // most columns: 16 of the x-half's 56 bytes per column).  nullptr: always load both.
+    const unsigned char *lu_code = nullptr;
 };
+// bit 0: l[j] must be loaded (neither -inf nor +0.0); bit 1: u[j] must be loaded (not +inf); bit 2: l[j] is +0.0
+constexpr unsigned kLoadL = 1u, kLoadU = 2u, kZeroL = 4u;
+void launch_bound_codes(int n, const double *l, const double *u, unsigned char *code, hipStream_t s);
 
 struct YHalfArgs {
     const double *xhat_full;

@@ -902,6 +902,7 @@ struct XEpi {
     // filled by begin()
     double sigma, f1, f2;
     FarPush push;  // hand-off of x_hat's remainder products to the y-half (kernels.h)
+    const unsigned char *lu_code;  // which bounds to read (kernels.h: XHalfArgs::lu_code), or nullptr
     static constexpr bool kPublishes = true;
     struct Row {
         double xi, ci, li, ui, lx;
@@ -914,11 +915,19 @@ struct XEpi {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->ky = k;
     }
     __device__ __forceinline__ Row load_row(int r) const {
-        if constexpr (STREAMED && HPRLP_EPI_NT >= 1)
-            return Row{__builtin_nontemporal_load(x + r), __builtin_nontemporal_load(c + r), __builtin_nontemporal_load(l + r),
-                       __builtin_nontemporal_load(u + r), __builtin_nontemporal_load(last_x + r)};
-        else
-            return Row{x[r], c[r], l[r], u[r], last_x[r]};
+        constexpr bool NT = STREAMED && HPRLP_EPI_NT >= 1;
+        auto ld = [](const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+        double li, ui;
+        if (lu_code) {
+            // the same values the arrays hold, without reading the constant ones (codes are derived from the arrays: launch_bound_codes)
+            const unsigned cd = NT ? __builtin_nontemporal_load(lu_code + r) : lu_code[r];
+            li = (cd & kLoadL) ? ld(l + r) : ((cd & kZeroL) ? 0.0 : -__builtin_huge_val());
+            ui = (cd & kLoadU) ? ld(u + r) : __builtin_huge_val();
+        } else {
+            li = ld(l + r);
+            ui = ld(u + r);
+        }
+        return Row{ld(x + r), ld(c + r), li, ui, ld(last_x + r)};
     }
     // returns the value the half-step publishes for the other half's gather (x_hat)
     __device__ __forceinline__ double apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 3 : 1]) const {
@@ -1254,14 +1263,14 @@ FarPush far_push_of(const CsrDev &consumer) {
 
 bool launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t s) {
     if (check) {
-        XEpi<true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, a.x_bar, a.z_bar, a.x_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, a.push};
+        XEpi<true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, a.x_bar, a.z_bar, a.x_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, a.push, a.lu_code};
         return launch_fused(AT, e, s, a.far_ready);
     }
     if (AT.tiled.valid) {  // the tiled kernels: the row's own streams bypass the L2s (HPRLP_EPI_NT)
-        XEpi<false, true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push};
+        XEpi<false, true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push, a.lu_code};
         return launch_fused(AT, e, s, a.far_ready);
     }
-    XEpi<false> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push};
+    XEpi<false> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push, a.lu_code};
     return launch_fused(AT, e, s, a.far_ready);
 }
 
@@ -1280,7 +1289,7 @@ bool launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t 
 
 
 void launch_x_half_base(const CsrDev &AT_remote, const XHalfArgs &a, const double *base, hipStream_t s) {
-    WithBase<XEpi<false>> e{{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, FarPush{}}, base};
+    WithBase<XEpi<false>> e{{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, FarPush{}, a.lu_code}, base};
     launch_fused(AT_remote, e, s);
 }
 
@@ -1721,6 +1730,19 @@ __global__ void __launch_bounds__(kThreads) k_norm2(const double *x, int n, doub
 }
 void launch_norm2(const double *x, int n, double *partials, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(k_norm2, dim3(nblocks), dim3(kThreads), 0, s, x, n, partials);
+}
+
+// which of l[j], u[j] the x-half has to read (kernels.h: XHalfArgs::lu_code); derived from the arrays as they are on the
+// device (after scaling: zero stays zero, infinite stays infinite), so a coded bound is bit for bit the stored one
+__global__ void __launch_bounds__(kThreads) k_bound_codes(int n, const double *l, const double *u, unsigned char *code) {
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    const double lj = l[j], uj = u[j];
+    const bool l_zero = __double_as_longlong(lj) == 0, l_minf = lj == -__builtin_huge_val(), u_pinf = uj == __builtin_huge_val();
+    code[j] = static_cast<unsigned char>((l_zero || l_minf ? 0u : kLoadL) | (u_pinf ? 0u : kLoadU) | (l_zero ? kZeroL : 0u));
+}
+void launch_bound_codes(int n, const double *l, const double *u, unsigned char *code, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_bound_codes, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n, l, u, code);
 }
 
 // ------------------------------------------------------------------------------------------------

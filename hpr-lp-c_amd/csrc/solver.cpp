@@ -888,6 +888,7 @@ void Solver::scale() {
     finish_tiling();  // tiled copies still being built pick up the scaled values here ...
     A.refresh_tiled(stream);  // ... finished ones are refreshed
     AT.refresh_tiled(stream);
+    refresh_bound_codes();
     HIP_CHECK(hipMemsetAsync(gsm.p, 0, sizeof(double) * m_pad, stream));
     HIP_CHECK(hipMemsetAsync(gsn.p, 0, sizeof(double) * n_pad, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -986,9 +987,17 @@ void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
     launch_set_ctrl(ctrl.p, sigma, lambda_max, reset_k ? 1 : 0, stream);
 }
 
+void Solver::refresh_bound_codes() {
+    static const bool off = std::getenv("HPRLP_NO_BOUND_CODES") != nullptr;  // A/B runs: always read l and u
+    if (off || n_loc <= 0) return;
+    if (lu_code.n != static_cast<size_t>(n_loc)) lu_code.alloc(static_cast<size_t>(n_loc));
+    launch_bound_codes(n_loc, l.p, u.p, lu_code.p, stream);
+}
+
 void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
     finish_tiling();
     invalidate_far();
+    refresh_bound_codes();
     if (overlap_enabled && !overlap_ready) prepare_overlap();  // set-up work, not part of the first iteration
     const double s0 = (norm_b > 1e-8 && norm_c > 1e-8) ? norm_b / norm_c : 1.0;
     set_sigma_lambda(s0, lambda_max, true);
@@ -1049,6 +1058,7 @@ FarPush Solver::push_into(const DeviceMatrix &consumer, const DeviceMatrix &prod
 
 void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev) {
     XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
+    xa.lu_code = lu_code.p;
     YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};  // (push / far_ready set below)
     if (ev) HIP_CHECK(hipEventRecord(ev[0], stream));
     if (!overlap_enabled) {
@@ -1107,6 +1117,7 @@ void Solver::step(bool check) {
         return;
     }
     XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, x_bar, z_bar.p, x_temp, ctrl.p, part_x.p, stride_x};
+    xa.lu_code = lu_code.p;
     xa.push = push_into(A, AT);
     xa.far_ready = far_AT_ready;
     far_A_ready = launch_x_half(AT.view, xa, true, stream);

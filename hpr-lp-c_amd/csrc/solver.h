@@ -114,6 +114,8 @@ struct Solver {
     FarPush push_into(const DeviceMatrix &consumer, const DeviceMatrix &producer) const;  // called by setup() for a large matrix that failed the tiling test
     HaloPlan halo_m, halo_n;  // exchange of length-m / length-n gathered vectors (multi-GPU only)
     DBuf<double> AL, AU, l, u, c, row_norm, col_norm;
+    DBuf<unsigned char> lu_code;  // per column: which of l, u the x-half reads (kernels.h); follows l / u (refresh_bound_codes)
+    void refresh_bound_codes();
     // local work vectors
     DBuf<double> x, last_x, z_bar, last_y, y_obj, y_temp;
     // gathered vectors (length *_pad); the local slice starts at *_off
