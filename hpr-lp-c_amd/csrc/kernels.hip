@@ -300,6 +300,9 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 #ifndef HPRLP_DBG_NOEPISTORE
 #define HPRLP_DBG_NOEPISTORE 0
 #endif
+#ifndef HPRLP_DBG_NOXSTORE
+#define HPRLP_DBG_NOXSTORE 0
+#endif
 #ifndef HPRLP_DBG_NOPUSHWORK
 #define HPRLP_DBG_NOPUSHWORK 0
 #endif
@@ -942,8 +945,13 @@ struct XEpi {
         {
             if constexpr (STREAMED && HPRLP_EPI_NT >= 2) __builtin_nontemporal_store(xh, x_hat + r);
             else x_hat[r] = xh;
-            if constexpr (STREAMED && HPRLP_EPI_NT >= 1) __builtin_nontemporal_store(xn, x + r);
-            else x[r] = xn;
+#if HPRLP_DBG_NOXSTORE
+            if (CHECK || xn == 1.2345e-300)  // timing experiment only (results are wrong): normal x-halves do not store x
+#endif
+            {
+                if constexpr (STREAMED && HPRLP_EPI_NT >= 1) __builtin_nontemporal_store(xn, x + r);
+                else x[r] = xn;
+            }
         }
         if constexpr (CHECK) {
             const double zb = (xb - zt) / sigma;

@@ -467,7 +467,7 @@ bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
 // every workgroup slot of the chip a whole super-block: it ran the piece form (three launches, partial sums through memory) or,
 // below 2^20 columns, the stream kernel.  With R = rows / 512 every slot gets exactly one, the epilogue stays fused, a half-step
 // is one launch and there is no tail.  What a lower super-block costs is tile traffic -- a staged tile serves R rows -- so the
-// column window of a super-block must stay narrow against its entries: estimated from the column span of the middle 90 % of the
+// column window of a super-block must stay narrow against its entries: estimated from the column span of the middle three quarters of the
 // entries of 2048 sampled rows (the far entries of a band matrix do not count: they go through the remainder lists).  A
 // source group of one matrix' remainder lists is a super-block of the other (hand-off, kernels.h FarPush): far_group of A is
 // sb_rows of A^T and vice versa.  Same-box A/B (profiles/r03_ab_rows*.txt): 1M x 1M, band 1e4: 3658 it/s stream kernel, 3393
@@ -490,15 +490,18 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     auto height = [&](int rows) { return ((rows + slots - 1) / slots + 63) / 64 * 64; };
     const int ra = height(m), rat = height(n);
     if (nnz < 4000000 || ra >= kTileRows || rat >= kTileRows || ra < kTileRowsMin || rat < kTileRowsMin) return;
-    // median column span of the middle 90 % of a row's entries
+    // median column span of a row without its outermost entries
     std::vector<long> span;
     const int samples = 2048;
     for (int q = 0; q < samples; ++q) {
         const int i = static_cast<int>(static_cast<long>(q) * m / samples);
         const int b = As->rowPtr[i], e = As->rowPtr[i + 1], len = e - b;
-        if (len < 2) continue;
-        const int cut = len / 20;
-        span.push_back(static_cast<long>(As->colIndex[e - 1 - cut]) - As->colIndex[b + cut]);
+        if (len < 4) continue;
+        // an eighth of the entries off either end (at least one: a 16-entry row of config 5's kind carries one far entry),
+        // the span of the rest scaled back to the whole row
+        const int cut = std::max(1, len / 8);
+        const long inner = static_cast<long>(As->colIndex[e - 1 - cut]) - As->colIndex[b + cut];
+        span.push_back(inner * (len - 1) / std::max(1, len - 1 - 2 * cut));
     }
     if (span.size() < 16) return;
     std::nth_element(span.begin(), span.begin() + span.size() / 2, span.end());

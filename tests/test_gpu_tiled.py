@@ -255,3 +255,40 @@ def test_mid_size_banded_lp_gets_one_super_block_per_slot(gpu):
     assert abs(r.primal_obj - lp["obj_star"]) <= 1e-3 * (1 + abs(lp["obj_star"]))
     assert abs(r.primal_obj - r0.primal_obj) <= 1e-4 * (1 + abs(r0.primal_obj))
     model.free()
+
+
+def test_lowered_heights_differ_between_a_and_its_transpose(gpu):
+    """m != n in the mid-size regime: A and A^T get different super-block heights (rows / 512 each); the source groups of one
+    matrix' remainder lists are the super-blocks of the other, so the hand-off between the half-steps still applies.  Iterates,
+    residuals and lambda_max against the stream kernel on the same LP."""
+    m, n = 800_000, 1_100_000
+    lp = bh.banded_lp(m, n, 16, 8_000)
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+
+    def run():
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        d = s.describe()
+        s.scale()
+        lam, it = s.power_iteration(max_iter=40)
+        s.init(0.8, 1.2 * lam)
+        s.iterate(25, True)
+        s.iterate(6, False)
+        out = (d, lam, {k: s.get(k) for k in ("x", "y", "x_hat", "x_bar", "y_bar", "z_bar")}, s.residuals(33, True))
+        s.close()
+        return out
+
+    d, lam, st, res = run()
+    import re
+    nsb = [int(x) for x in re.findall(r"(\d+) super-blocks", d)]
+    assert "tiled, fused" in d and "stream kernel" not in d and len(nsb) == 2 and all(384 <= k <= 512 for k in nsb), d
+    os.environ["HPRLP_NO_TILED"] = "1"
+    try:
+        d0, lam0, st0, res0 = run()
+    finally:
+        os.environ.pop("HPRLP_NO_TILED", None)
+    assert "tiled" not in d0.replace("tiled form not attempted", "")
+    assert abs(lam - lam0) <= 1e-11 * abs(lam0)
+    for k in st:
+        np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    assert abs(res["kkt"] - res0["kkt"]) <= 1e-9 * (1 + abs(res0["kkt"]))
+    model.free()
