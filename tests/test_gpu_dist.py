@@ -1,6 +1,8 @@
 """GPU: the RCCL code path of the row-partitioned solver with a ONE-rank communicator (the box has one
 GPU).  Exercises librccl loading, communicator creation, the in-place all-gathers after every
 half-step and the scalar all-reduces; with one rank they must not change any result."""
+import os
+
 import numpy as np
 import pytest
 
@@ -26,16 +28,22 @@ def test_one_rank_rccl_path_equals_plain_solver(gpu, ids):
     assert (ci["xcomm_ranks"], ci["xcomm_rank"], ci["xcomm_device"]) == ((1, 0, 0) if ids == 2 else (0, -1, -1)), ci
     dist.dist_loopback(1 << 18)  # ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd: rank 0 to itself, 2 MiB, verified
     out = []
-    for s in (plain, dist):
-        s.scale()
-        lam, it = s.power_iteration()
-        s.init(-1.0, lam * 1.01)
-        s.iterate(37, True)
-        res = s.residuals(38, True)
-        state = {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}
-        r = s.run()
-        out.append((lam, it, res, state, r))
-        s.close()
+    # (bit-for-bit: both take lambda_max from the regular power iteration; the plain solver's single-launch one for small LPs
+    # adds its dot products in another order -- tests/test_gpu_small.py)
+    os.environ["HPRLP_NO_SMALL_POWER"] = "1"
+    try:
+        for s in (plain, dist):
+            s.scale()
+            lam, it = s.power_iteration()
+            s.init(-1.0, lam * 1.01)
+            s.iterate(37, True)
+            res = s.residuals(38, True)
+            state = {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}
+            r = s.run()
+            out.append((lam, it, res, state, r))
+            s.close()
+    finally:
+        os.environ.pop("HPRLP_NO_SMALL_POWER", None)
     (l0, i0, r0, s0, f0), (l1, i1, r1, s1, f1) = out
     assert (l0, i0) == (l1, i1)
     for k in s0:
