@@ -46,9 +46,11 @@ def sweep(count=36, tol=1e-6, max_iter=200000, seed0=2026):
         elif kind == 1:  # stream kernel
             m = int(rng.integers(500, 4000)); n = int(rng.integers(m, 6000)); nnz = int(rng.integers(13000, 40000))
             env = {"HPRLP_NO_SMALL": "1"}
-        else:            # tiled kernel forced
+        else:            # tiled kernel forced; every other one with a lowered super-block height (round 3: tiled.h), fused form
             m = int(rng.integers(3000, 9000)); n = int(rng.integers(m, 12000)); nnz = int(rng.integers(20000, 60000))
             env = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "0.0"}
+            if (t // 3) % 2 == 1:
+                env.update({"HPRLP_TILE_ROWS": str(64 * int(rng.integers(4, 33))), "HPRLP_TILE_PIECES": "0"})
         out.append(one(m, n, nnz, (100 if seed0 == 2026 else seed0) + t, tol, env, max_iter))
     return out
 
