@@ -3,11 +3,8 @@
 // A block belongs to the device it was allocated on, whatever device the freeing thread has current: put() asks the
 // runtime for the owner (hipPointerGetAttributes), waits for THAT device and files the block under it; get() serves the
 // calling thread's current device, like hipMalloc.  The cap is per device and bounded by a third of the device's memory.
-#include <cstring>
 #include <map>
 #include <mutex>
-#include <thread>
-#include <vector>
 
 #include "common.h"
 #include "hprlp_amd.h"
@@ -127,84 +124,6 @@ void *device_malloc_or_trim(size_t bytes) {
     if (e != hipSuccess)
         throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in hipMalloc of " + std::to_string(bytes) + " bytes");
     return p;
-}
-
-// ------------------------------------------------------------------------------------------------
-// staged upload (common.h)
-// ------------------------------------------------------------------------------------------------
-namespace {
-
-constexpr int kStageThreads = 4;                  // host threads copying into pinned memory
-constexpr int kStageDepth = 2;                    // staging buffers per thread (copy into one while the other is in flight)
-constexpr size_t kStageChunk = size_t(8) << 20;   // bytes per chunk
-
-struct StagePool {  // pinned staging memory, allocated once per process and device on first use
-    std::mutex mu;  // one staged upload at a time (the pool is shared)
-    int device = -1;
-    char *pinned = nullptr;
-    hipStream_t stream[kStageThreads] = {};
-    hipEvent_t done[kStageThreads][kStageDepth] = {};
-    bool ready = false;
-    bool init() {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (ready && dev == device) return true;
-        if (ready) return false;  // another device than the pool's: plain copy (multi-GPU processes use one device each)
-        if (hipHostMalloc(reinterpret_cast<void **>(&pinned), kStageChunk * kStageThreads * kStageDepth, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            pinned = nullptr;
-            return false;
-        }
-        for (int t = 0; t < kStageThreads; ++t) {
-            if (hipStreamCreateWithFlags(&stream[t], hipStreamNonBlocking) != hipSuccess) return false;
-            for (int d = 0; d < kStageDepth; ++d)
-                if (hipEventCreateWithFlags(&done[t][d], hipEventDisableTiming) != hipSuccess) return false;
-        }
-        device = dev;
-        ready = true;
-        return true;
-    }
-};
-
-StagePool &stage_pool() {
-    static StagePool p;
-    return p;
-}
-
-}  // namespace
-
-void staged_upload(void *dst_device, const void *src_host, size_t bytes) {
-    static const bool off = std::getenv("HPRLP_NO_STAGED_UPLOAD") != nullptr;
-    StagePool &pool = stage_pool();
-    std::unique_lock<std::mutex> lock(pool.mu, std::try_to_lock);
-    if (off || !lock.owns_lock() || !pool.init()) {
-        HIP_CHECK(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
-        return;
-    }
-    const size_t nchunks = (bytes + kStageChunk - 1) / kStageChunk;
-    const int dev = pool.device;
-    std::vector<hipError_t> err(kStageThreads, hipSuccess);
-    auto work = [&](int t) {
-        hipError_t e = hipSetDevice(dev);
-        int slot = 0;
-        for (size_t c = static_cast<size_t>(t); c < nchunks && e == hipSuccess; c += kStageThreads, slot = (slot + 1) % kStageDepth) {
-            const size_t off_b = c * kStageChunk, len = std::min(kStageChunk, bytes - off_b);
-            char *buf = pool.pinned + (static_cast<size_t>(t) * kStageDepth + slot) * kStageChunk;
-            if (c >= static_cast<size_t>(kStageThreads) * kStageDepth) e = hipEventSynchronize(pool.done[t][slot]);  // the buffer's previous copy has left
-            if (e != hipSuccess) break;
-            std::memcpy(buf, static_cast<const char *>(src_host) + off_b, len);
-            e = hipMemcpyAsync(static_cast<char *>(dst_device) + off_b, buf, len, hipMemcpyHostToDevice, pool.stream[t]);
-            if (e == hipSuccess) e = hipEventRecord(pool.done[t][slot], pool.stream[t]);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(pool.stream[t]);
-        err[t] = e;
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < kStageThreads; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    for (hipError_t e : err)
-        if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in staged_upload");
 }
 
 }  // namespace hprlp

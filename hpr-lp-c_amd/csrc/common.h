@@ -59,13 +59,6 @@ bool device_cache_put(void *p, size_t capacity);        // false: not cached (ca
 void device_cache_trim();
 void *device_malloc_or_trim(size_t bytes);              // hipMalloc; on out-of-memory: trim the cache, retry once, then throw
 
-// Host -> device copy of a LARGE pageable buffer (alloc.cpp).  hipMemcpy from pageable memory runs at about 19 GB/s on the MI355X
-// hosts (config 5's matrix: 2.4 GB, 0.13 s of a 1.5 s solve); here a few host threads copy chunks into pinned staging buffers and
-// queue asynchronous copies behind them, so the CPU copies and the DMA overlap.  Blocking like hipMemcpy: returns when the data is
-// on the device.  HPRLP_NO_STAGED_UPLOAD=1 falls back to hipMemcpy.
-constexpr size_t kStagedUploadMinBytes = size_t(64) << 20;
-void staged_upload(void *dst_device, const void *src_host, size_t bytes);
-
 // Device buffer with RAII; sized in elements.
 template <class T>
 struct DBuf {
@@ -117,9 +110,7 @@ struct DBuf {
         cap_bytes = 0;
     }
     void upload(const T *src, size_t count) {
-        if (!count) return;
-        if (count * sizeof(T) >= kStagedUploadMinBytes) staged_upload(p, src, count * sizeof(T));  // large pageable source: pipelined
-        else HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        if (count) HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
     }
     void download(T *dst, size_t count) const {
         if (count) HIP_CHECK(hipMemcpy(dst, p, count * sizeof(T), hipMemcpyDeviceToHost));
