@@ -48,6 +48,8 @@ WORKLOADS = {
     "c5_small": (1_000_000, 1_000_000, 20, 10_000),
     "band_6e7": (3_000_000, 3_000_000, 20, 30_000),   # the ladder's points as workloads of their own (kernel experiments)
     "band_6e6": (300_000, 300_000, 20, 3_000),
+    "band_1.2e8": (6_000_000, 6_000_000, 20, 60_000),
+    "band_1e8": (5_000_000, 5_000_000, 20, 50_000),
     "band_1.2e7": (600_000, 600_000, 20, 6_000),
     "band_1.6e7": (800_000, 800_000, 20, 8_000),
     "band_3e7": (1_500_000, 1_500_000, 20, 15_000),

@@ -451,7 +451,8 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
 // gathered vector from which the all-remainder tiled form beats the stream kernel on a pattern without locality (measured,
 // tools/unstructured_ab.py, uniformly random 10 per row: 1M columns 0.154 vs 0.125 ms per half-step, 2M 0.218 vs 0.318, 3M 0.316
 // vs 0.508, 4.2M 0.46 vs 0.75, 6M 0.59 vs 1.13)
-constexpr double kMaxTileShare = 0.6;  // choose_sb_rows: most tile bytes per entry byte a lowered super-block may stage
+constexpr double kMaxTileShare = 0.6;  // choose_sb_rows: most tile bytes per entry byte a lowered super-block may stage (one round)
+constexpr double kMaxTileShareRounds = 0.9;  // ... when the height only trims a partial last round of a larger matrix
 constexpr long kPbMinCols = 1500000;
 
 bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
@@ -485,11 +486,20 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int slots = cus * kTileResidentPerCu;
-    // the height that gives one super-block per slot; nothing to do if the full height already fills a round, nothing to gain
-    // below kTileRowsMin (launch-bound matrices: the stream kernel)
-    auto height = [&](int rows) { return ((rows + slots - 1) / slots + 63) / 64 * 64; };
+    // Heights considered for a matrix of `rows` rows: with k = the rounds the FULL height needs (ceil of its super-blocks over the
+    // slots), the height that fills exactly k rounds.  k = 1: one super-block per slot (mid-size matrices).  k >= 2: the same
+    // number of rounds as now without the partial last one -- only when the full height wastes more than a fifth of its rounds
+    // (6M x 6M, band 6e4: 733 super-blocks = 1.43 rounds run as 2; 1020 of 5888 rows: 1121 -> 1148 it/s; 5M x 5M: 1264 -> 1321;
+    // profiles/r03_ab_rows7.txt).  Nothing to gain below kTileRowsMin (launch-bound matrices: the stream kernel).
+    auto height = [&](int rows) {
+        const int nsb_full = (rows + kTileRows - 1) / kTileRows;
+        const int k = std::max(1, (nsb_full + slots - 1) / slots);
+        if (k > 1 && static_cast<double>(nsb_full) / (static_cast<double>(k) * slots) >= 0.8) return kTileRows;  // rounds nearly full already
+        const int per = (rows + k * slots - 1) / (k * slots);
+        return std::min(kTileRows, (per + 63) / 64 * 64);
+    };
     const int ra = height(m), rat = height(n);
-    if (nnz < 4000000 || ra >= kTileRows || rat >= kTileRows || ra < kTileRowsMin || rat < kTileRowsMin) return;
+    if (nnz < 4000000 || (ra >= kTileRows && rat >= kTileRows) || ra < kTileRowsMin || rat < kTileRowsMin) return;
     // median column span of a row without its outermost entries
     std::vector<long> span;
     const int samples = 2048;
@@ -507,16 +517,19 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     std::nth_element(span.begin(), span.begin() + span.size() / 2, span.end());
     const double w_a = static_cast<double>(span[span.size() / 2]);
     const double slope = static_cast<double>(n) / m;  // columns per row along the "diagonal"
-    // bytes of the vector tiles a super-block stages against the bytes of its entries
+    // bytes of the vector tiles a super-block stages against the bytes of its entries; a height that only trims a partial round
+    // may stage a little more (it saves a fifth of the rounds or more)
     const double ratio_a = (w_a + ra * slope) * 8.0 / (static_cast<double>(nnz) / m * ra * 11.0);
     const double ratio_at = (w_a / slope + rat / slope) * 8.0 / (static_cast<double>(nnz) / n * rat * 11.0);
-    const bool ok = ratio_a <= kMaxTileShare && ratio_at <= kMaxTileShare;
+    const bool multi = static_cast<long>(ra) * slots < m || static_cast<long>(rat) * slots < n;  // more than one round
+    const double most = multi ? kMaxTileShareRounds : kMaxTileShare;
+    const bool ok = ratio_a <= most && ratio_at <= most;
     if (ok) {
         A.sb_rows = AT.far_group = ra;
         AT.sb_rows = A.far_group = rat;
     }
     if (std::getenv("HPRLP_TIMING"))
-        std::cerr << "[timing] super-block heights for one round of " << slots << " slots: " << ra << " (A), " << rat << " (A^T); median row span " << w_a
+        std::cerr << "[timing] super-block heights for whole rounds of " << slots << " slots: " << ra << " (A), " << rat << " (A^T); median row span " << w_a
                   << " columns, tile bytes / entry bytes " << ratio_a << ", " << ratio_at << " -> " << (ok ? "lowered" : "full height (8192)") << std::endl;
 }
 
