@@ -2,11 +2,13 @@
 // one MI355X.  Replaces reference src/batched_solver.cu (kernels :122-323, SpMM wrappers :428-477,
 // loop :1017-1084, host restart/sigma logic :667-762, set-up :792-885, results :887-935).
 //
-// Layout: every panel is stored ROW-major in the batch index: element (row j, problem k) lives at
-// P[j*Bp + k], Bp = B padded to a power of two (<=64) or to a multiple of 64.  A gathered row of the
-// panel is then one contiguous Bp*8-byte run (512 B at B=64): the SpMM is a CSR row loop in which
-// lane k of a wave follows problem k, the matrix entry is wave-uniform and every gather is a fully
-// coalesced load.  Each problem's row sums are accumulated sequentially in CSR order, exactly like
+// Layout: the batch (padded to Bp = a power of two <= 64, or a multiple of 64) is cut into chunks of Bc problems
+// (Bc = Bp below 64, else 8..64: choose_chunk); a panel of `rows` rows is stored chunk after chunk, each chunk
+// ROW-major in the batch index: element (row j, problem k) lives at P[((k / Bc) * rows + j) * Bc + k % Bc].
+// A gathered row of a chunk is one contiguous Bc*8-byte run: the SpMM is a CSR row loop in which a lane follows
+// one problem, 64 / Bc rows per wave.  A workgroup works on ONE chunk, chunk = blockIdx.x % (number of chunks):
+// workgroups go round-robin to the 8 XCDs, so with 8 chunks every XCD gathers from the same eighth of the
+// gathered panel (config 4: 2.2 MB of Y instead of 17 MB -- it stays in the XCD's 4 MiB L2).  Each problem's row sums are accumulated sequentially in CSR order, exactly like
 // the single-LP stream kernel, so the result is bit-identical to the oracle's batched restatement.
 // The half-step update (projection, reflection, Halpern average, per-problem sigma / inner counter /
 // active mask) is fused into the SpMM epilogue: one launch per half-step, no per-iteration host sync
@@ -19,6 +21,7 @@
 #include <iostream>
 #include <limits>
 #include <string>
+#include <type_traits>
 
 #include "HPRLP.h"
 #include "solver.h"
@@ -39,24 +42,40 @@ struct BatchCtl {  // per-problem device scalars
     int *restart_flag;
 };
 
-// thread -> (row slot, problem): lane l of a wave handles sub-row l / Bw and problem kc*64 + l % Bw
-// with Bw = min(Bp, 64); a 256-thread block covers 4 * (64/Bw) rows of one 64-wide problem chunk.
+// thread -> (row slot, problem): lane l of a wave handles sub-row l / Bw and problem chunk*Bw + l % Bw, Bw = Bc = the
+// chunk width; a 256-thread block covers 4 * (64/Bw) rows of one chunk.
 struct Geo {
-    int Bp, Bw, rows_per_wave, rows_per_block;
+    int Bp, Bw, nchunk, rows_per_wave, rows_per_block;
 };
-__host__ __device__ inline Geo make_geo(int Bp) {
+inline Geo make_geo(int Bp, int Bc) {
     Geo g;
     g.Bp = Bp;
-    g.Bw = Bp < 64 ? Bp : 64;
+    g.Bw = Bc;
+    g.nchunk = Bp / Bc;
     g.rows_per_wave = 64 / g.Bw;
     g.rows_per_block = 4 * g.rows_per_wave;
     return g;
 }
+// which chunk / which block of rows a workgroup works on (1-D grids of nchunk * row blocks, chunk fastest)
+struct Blk {
+    int chunk, rb, nrb;
+};
+__device__ __forceinline__ Blk decode_block(const Geo &g) {
+    Blk b;
+    b.chunk = blockIdx.x % g.nchunk;
+    b.rb = blockIdx.x / g.nchunk;
+    b.nrb = gridDim.x / g.nchunk;
+    return b;
+}
+// element (row r, local problem kl) of a chunk of a panel with `rows` rows
+__device__ __forceinline__ size_t pidx(const Geo &g, int chunk, int rows, int r, int kl) {
+    return (static_cast<size_t>(chunk) * rows + r) * g.Bw + kl;
+}
 
 // Sum `NACC` per-thread accumulators over all threads of the block that share a problem index and
-// store them to partials[(blockIdx.x * NACC + i) * Bp + k].  Fixed order => deterministic.
+// store them to partials[(rb * NACC + i) * Bp + k] (rb: the workgroup's row block).  Fixed order => deterministic.
 template <int NACC>
-__device__ __forceinline__ void block_store_per_problem(double (&acc)[NACC], const Geo &g, int k, bool kvalid,
+__device__ __forceinline__ void block_store_per_problem(double (&acc)[NACC], const Geo &g, int rb, int k, bool kvalid,
                                                         double *partials) {
     __shared__ double red[4][NACC][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -71,7 +90,7 @@ __device__ __forceinline__ void block_store_per_problem(double (&acc)[NACC], con
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
             const double v = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
-            partials[(static_cast<size_t>(blockIdx.x) * NACC + i) * g.Bp + k] = v;
+            partials[(static_cast<size_t>(rb) * NACC + i) * g.Bp + k] = v;
         }
     }
 }
@@ -92,6 +111,7 @@ constexpr bool kNtStoreX = HPRLP_BATCH_NT >= 2;
 
 struct HalfArgs {
     const double *V;                   // gathered panel
+    int vrows;                         // its rows (= columns of the matrix)
     double *P, *P_hat;                 // X / X_hat  or  Y / (unused)
     const double *lo, *hi, *cost;      // L,U,C  or  AL,AU,(unused)
     const double *last;
@@ -145,10 +165,10 @@ __device__ __forceinline__ void half_update(const HalfArgs &a, size_t t, double 
 
 template <bool XHALF, bool CHECK>
 __global__ void __launch_bounds__(256) kb_half(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                               const double *__restrict__ val, int Bp, HalfArgs a) {
-    const Geo g = make_geo(Bp);
+                                               const double *__restrict__ val, Geo g, HalfArgs a) {
+    const Blk blk = decode_block(g);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.y * 64 + (lane % g.Bw);
+    const int kl = lane % g.Bw, k = blk.chunk * g.Bw + kl;
     const int sub = lane / g.Bw;
     constexpr int NACC = CHECK ? (XHALF ? 3 : 2) : 1;
     double acc[NACC];
@@ -161,16 +181,16 @@ __global__ void __launch_bounds__(256) kb_half(int rows, const int *__restrict__
     const double f1 = 1.0 / (static_cast<double>(kk) + 2.0), f2 = 1.0 - f1;
     const double fact1 = a.lambda_max * sig;
     // counter hand-off (see Ctrl in kernels.h): the x-half publishes ky, the y-half advances kx
-    if (blockIdx.x == 0 && wave == 0 && sub == 0) {
+    if (blk.rb == 0 && wave == 0 && sub == 0) {
         if (XHALF) a.ctl.ky[k] = kk;
         else if (act) a.ctl.kx[k] = kk + 1;
     }
-    for (int r = blockIdx.x * g.rows_per_block + wave * g.rows_per_wave + sub; r < rows;
-         r += gridDim.x * g.rows_per_block) {
+    const double *__restrict__ V = a.V + pidx(g, blk.chunk, a.vrows, 0, kl);
+    for (int r = blk.rb * g.rows_per_block + wave * g.rows_per_wave + sub; r < rows; r += blk.nrb * g.rows_per_block) {
         if (!act) continue;
         // the panel operands do not depend on the row sum: issue their loads first so that they
         // overlap the gather chain of the SpMM loop
-        const size_t t = static_cast<size_t>(r) * Bp + k;
+        const size_t t = pidx(g, blk.chunk, rows, r, kl);
         const double p_i = a.P[t], p_lo = a.lo[t], p_hi = a.hi[t], p_last = a.last[t];
         const double p_cost = XHALF ? a.cost[t] : 0.0;
         double s = 0.0;
@@ -181,7 +201,7 @@ __global__ void __launch_bounds__(256) kb_half(int rows, const int *__restrict__
             for (int u = 0; u < 4; ++u) {
                 const int q = min(p + u, e - 1);
                 av[u] = val[q];
-                gv[u] = a.V[static_cast<size_t>(col[q]) * Bp + k];
+                gv[u] = V[static_cast<size_t>(col[q]) * g.Bw];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -189,10 +209,10 @@ __global__ void __launch_bounds__(256) kb_half(int rows, const int *__restrict__
         }
         half_update<XHALF, CHECK, NACC>(a, t, s, p_i, p_lo, p_hi, p_last, p_cost, sig, fact1, f1, f2, acc);
     }
-    if (CHECK) block_store_per_problem<NACC>(acc, g, k, true, a.partials);
+    if (CHECK) block_store_per_problem<NACC>(acc, g, blk.rb, k, true, a.partials);
 }
 
-// Bp >= 64 (a wave = 64 problems of ONE row): the row index is wave-uniform, so row pointers, column
+// Chunks of 64 problems (a wave = 64 problems of ONE row): the row index is wave-uniform, so row pointers, column
 // indices and values come through the scalar cache, and a wave works on kRowsPerWave consecutive rows
 // at once -- their nonzeros are one contiguous CSR range -- with all panel loads and up to 8 gathers
 // in flight before the first use.  Each row is still summed in CSR order.
@@ -200,12 +220,12 @@ constexpr int kRowsPerWave = 4;
 
 template <bool XHALF, bool CHECK>
 __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                 const double *__restrict__ val, int Bp, HalfArgs a) {
+                                                 const double *__restrict__ val, Geo g, HalfArgs a) {
     constexpr int RW = kRowsPerWave, G = 8;
     static_assert(RW == 4, "the row select below is written for 4 rows");
-    const Geo g = make_geo(Bp);
+    const Blk blk = decode_block(g);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.y * 64 + lane;
+    const int k = blk.chunk * 64 + lane;
     constexpr int NACC = CHECK ? (XHALF ? 3 : 2) : 1;
     double acc[NACC];
 #pragma unroll
@@ -216,16 +236,16 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
     const double sig = a.ctl.sigma[k];
     const double f1 = 1.0 / (static_cast<double>(kk) + 2.0), f2 = 1.0 - f1;
     const double fact1 = a.lambda_max * sig;
-    if (blockIdx.x == 0 && wave == 0) {
+    if (blk.rb == 0 && wave == 0) {
         if (XHALF) a.ctl.ky[k] = kk;
         else if (act) a.ctl.kx[k] = kk + 1;
     }
-    const double *__restrict__ V = a.V + k;
+    const double *__restrict__ V = a.V + pidx(g, blk.chunk, a.vrows, 0, lane);
     // Row groups in launch order: the few groups with long rows first (BatchWS::order_*).  A 200-entry row is 26 dependent
     // trips to memory for its wave (about 50 us): dispatched wherever it falls in the row order it ends up as the launch's
     // tail (config 4: 53 such rows of A^T, x-half 101 -> 71 us without them); dispatched first it runs beside everything else.
     const int ngroups = (rows + RW - 1) / RW;
-    for (int gi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); gi < ngroups; gi += gridDim.x * 4) {
+    for (int gi = __builtin_amdgcn_readfirstlane(blk.rb * 4 + wave); gi < ngroups; gi += blk.nrb * 4) {
         const int rb = (a.order ? a.order[gi] : gi) * RW;
         int pb[RW + 1];
 #pragma unroll
@@ -233,7 +253,7 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
         double p_i[RW], p_lo[RW], p_hi[RW], p_last[RW], p_cost[RW], s[RW];
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            const size_t t = static_cast<size_t>(min(rb + i, rows - 1)) * Bp + k;
+            const size_t t = pidx(g, blk.chunk, rows, min(rb + i, rows - 1), lane);
             if ((HPRLP_DBG_MODE & 1) && !CHECK) {
                 p_i[i] = 0.5, p_lo[i] = 0.0, p_hi[i] = 1.0, p_last[i] = 0.25, p_cost[i] = 0.125;
             } else if (kNtPanels) {  // the panel streams are read once per half-step: keep them out of the gathered panel's way in the caches
@@ -253,7 +273,7 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
             for (int u = 0; u < G; ++u) {
                 const int q = min(p + u, pend - 1);
                 av[u] = val[q];
-                gv[u] = ((HPRLP_DBG_MODE & 4) && !CHECK) ? static_cast<double>(col[q]) : V[static_cast<size_t>(col[q]) * Bp];
+                gv[u] = ((HPRLP_DBG_MODE & 4) && !CHECK) ? static_cast<double>(col[q]) : V[static_cast<size_t>(col[q]) * 64];
             }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
@@ -271,30 +291,118 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
 #pragma unroll
             for (int i = 0; i < RW; ++i)
                 if (rb + i < rows)
-                    half_update<XHALF, CHECK, NACC>(a, static_cast<size_t>(rb + i) * Bp + k, s[i], p_i[i], p_lo[i], p_hi[i],
+                    half_update<XHALF, CHECK, NACC>(a, pidx(g, blk.chunk, rows, rb + i, lane), s[i], p_i[i], p_lo[i], p_hi[i],
                                                     p_last[i], p_cost[i], sig, fact1, f1, f2, acc);
         }
     }
-    if (CHECK) block_store_per_problem<NACC>(acc, g, k, true, a.partials);
+    if (CHECK) block_store_per_problem<NACC>(acc, g, blk.rb, k, true, a.partials);
+}
+
+// Chunks of BW = 8 / 16 / 32 problems: a wave is SUBS = 64 / BW lane groups; lane group `sub` of a wave that works on the
+// 4 * SUBS consecutive rows from r0 takes rows r0 + i * SUBS + sub, i = 0..3, so that every panel load of the wave (fixed i)
+// reads SUBS consecutive rows = one contiguous 512-byte run.  Same structure as kb_half64 otherwise -- all panel loads and up
+// to 8 gathers in flight per lane before the first use, every row summed in CSR order -- but the CSR arrays come through
+// vector loads (the rows are uniform per lane group, not per wave) and a lane group's entries are four separate CSR ranges,
+// walked as one concatenated range.
+template <bool XHALF, bool CHECK, int BW>
+__global__ void __launch_bounds__(256) kb_halfN(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                const double *__restrict__ val, Geo g, HalfArgs a) {
+    constexpr int RW = kRowsPerWave, G = 8, SUBS = 64 / BW;
+    static_assert(RW == 4, "the row select below is written for 4 rows");
+    const Blk blk = decode_block(g);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kl = lane % BW, sub = lane / BW, k = blk.chunk * BW + kl;
+    constexpr int NACC = CHECK ? (XHALF ? 3 : 2) : 1;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+
+    const bool act = a.ctl.active[k] != 0;
+    const int kk = XHALF ? a.ctl.kx[k] : a.ctl.ky[k];
+    const double sig = a.ctl.sigma[k];
+    const double f1 = 1.0 / (static_cast<double>(kk) + 2.0), f2 = 1.0 - f1;
+    const double fact1 = a.lambda_max * sig;
+    if (blk.rb == 0 && wave == 0 && sub == 0) {
+        if (XHALF) a.ctl.ky[k] = kk;
+        else if (act) a.ctl.kx[k] = kk + 1;
+    }
+    const double *__restrict__ V = a.V + pidx(g, blk.chunk, a.vrows, 0, kl);
+    const int ngroups = (rows + RW * SUBS - 1) / (RW * SUBS);
+    for (int gi = blk.rb * 4 + wave; gi < ngroups; gi += blk.nrb * 4) {
+        const int r0 = (a.order ? a.order[gi] : gi) * (RW * SUBS) + sub;
+        int pb[RW], pe[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int r = min(r0 + i * SUBS, rows);
+            pb[i] = rowptr[r];
+            pe[i] = rowptr[min(r + 1, rows)];
+        }
+        double p_i[RW], p_lo[RW], p_hi[RW], p_last[RW], p_cost[RW], s[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const size_t t = pidx(g, blk.chunk, rows, min(r0 + i * SUBS, rows - 1), kl);
+            if (kNtPanels) {
+                p_i[i] = __builtin_nontemporal_load(a.P + t), p_lo[i] = __builtin_nontemporal_load(a.lo + t);
+                p_hi[i] = __builtin_nontemporal_load(a.hi + t), p_last[i] = __builtin_nontemporal_load(a.last + t);
+                p_cost[i] = XHALF ? __builtin_nontemporal_load(a.cost + t) : 0.0;
+            } else {
+                p_i[i] = a.P[t], p_lo[i] = a.lo[t], p_hi[i] = a.hi[t], p_last[i] = a.last[t];
+                p_cost[i] = XHALF ? a.cost[t] : 0.0;
+            }
+            s[i] = 0.0;
+        }
+        // position e of the concatenated range -> CSR position e + (offset of the row e falls in)
+        const int c1 = pe[0] - pb[0], c2 = c1 + (pe[1] - pb[1]), c3 = c2 + (pe[2] - pb[2]), total = c3 + (pe[3] - pb[3]);
+        const int d0 = pb[0], d1 = pb[1] - c1, d2 = pb[2] - c2, d3 = pb[3] - c3;
+        for (int p = 0; p < total; p += G) {
+            double gv[G], av[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int e = min(p + u, total - 1);
+                const int q = e + (e < c1 ? d0 : e < c2 ? d1 : e < c3 ? d2 : d3);
+                av[u] = val[q];
+                gv[u] = V[static_cast<size_t>(col[q]) * BW];
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int e = p + u;
+                if (e < total) {
+                    const double prod = av[u] * gv[u];
+                    if (e < c1) s[0] += prod;
+                    else if (e < c2) s[1] += prod;
+                    else if (e < c3) s[2] += prod;
+                    else s[3] += prod;
+                }
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < RW; ++i)
+                if (r0 + i * SUBS < rows)
+                    half_update<XHALF, CHECK, NACC>(a, pidx(g, blk.chunk, rows, r0 + i * SUBS, kl), s[i], p_i[i], p_lo[i], p_hi[i],
+                                                    p_last[i], p_cost[i], sig, fact1, f1, f2, acc);
+        }
+    }
+    if (CHECK) block_store_per_problem<NACC>(acc, g, blk.rb, k, true, a.partials);
 }
 
 // ---- residual SpMMs (reference compute_batched_Rd/Rp_kernel :238-263 + SpMM) ---------------------
 // WHICH 0: |(C - A^T Ybar - Zbar) .* col_norm|^2 ; 1: |Rp|^2 ; 2: |Rp|^2 and <A DX, DY> ; 3: <A DX, DY>
 template <int WHICH>
 __global__ void __launch_bounds__(256) kb_resid(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                const double *__restrict__ val, int Bp, const double *V,
+                                                const double *__restrict__ val, Geo g, int vrows, const double *V,
                                                 const double *V2, const double *p0, const double *p1,
                                                 const double *norm, const double *dvec, double *partials) {
-    const Geo g = make_geo(Bp);
+    const Blk blk = decode_block(g);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.y * 64 + (lane % g.Bw);
+    const int kl = lane % g.Bw, k = blk.chunk * g.Bw + kl;
     const int sub = lane / g.Bw;
+    const size_t vbase = pidx(g, blk.chunk, vrows, 0, kl);
     constexpr int NACC = (WHICH == 2) ? 2 : 1;
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-    for (int r = blockIdx.x * g.rows_per_block + wave * g.rows_per_wave + sub; r < rows;
-         r += gridDim.x * g.rows_per_block) {
+    for (int r = blk.rb * g.rows_per_block + wave * g.rows_per_wave + sub; r < rows; r += blk.nrb * g.rows_per_block) {
         double s = 0.0, s2 = 0.0;
         const int e = rowptr[r + 1];
         for (int p = rowptr[r]; p < e; p += 4) {  // four entries in flight (a dependent trip per entry made long rows a 300 us tail); summed in CSR order
@@ -302,7 +410,7 @@ __global__ void __launch_bounds__(256) kb_resid(int rows, const int *__restrict_
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = min(p + u, e - 1);
-                const size_t gi = static_cast<size_t>(col[q]) * Bp + k;
+                const size_t gi = vbase + static_cast<size_t>(col[q]) * g.Bw;
                 av[u] = val[q];
                 g1[u] = WHICH != 3 ? V[gi] : 0.0;
                 g2[u] = WHICH >= 2 ? V2[gi] : 0.0;
@@ -314,7 +422,7 @@ __global__ void __launch_bounds__(256) kb_resid(int rows, const int *__restrict_
                     if (WHICH >= 2) s2 += av[u] * g2[u];
                 }
         }
-        const size_t t = static_cast<size_t>(r) * Bp + k;
+        const size_t t = pidx(g, blk.chunk, rows, r, kl);
         if (WHICH == 0) {
             const double rd = (p0[t] - s - p1[t]) * norm[r];
             acc[0] += rd * rd;
@@ -326,77 +434,77 @@ __global__ void __launch_bounds__(256) kb_resid(int rows, const int *__restrict_
             acc[0] += s2 * dvec[t];
         }
     }
-    block_store_per_problem<NACC>(acc, g, k, true, partials);
+    block_store_per_problem<NACC>(acc, g, blk.rb, k, true, partials);
 }
 
 // iteration-0 bound violation (reference compute_batched_lu_violation_kernel :265-278)
-__global__ void __launch_bounds__(256) kb_lu(int n, int Bp, const double *Xb, const double *L, const double *U,
+__global__ void __launch_bounds__(256) kb_lu(int n, Geo g, const double *Xb, const double *L, const double *U,
                                              const double *col_norm, double *DX, double *partials) {
-    const Geo g = make_geo(Bp);
+    const Blk blk = decode_block(g);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.y * 64 + (lane % g.Bw);
+    const int kl = lane % g.Bw, k = blk.chunk * g.Bw + kl;
     const int sub = lane / g.Bw;
     double acc[1] = {0.0};
-    for (int r = blockIdx.x * g.rows_per_block + wave * g.rows_per_wave + sub; r < n; r += gridDim.x * g.rows_per_block) {
-        const size_t t = static_cast<size_t>(r) * Bp + k;
+    for (int r = blk.rb * g.rows_per_block + wave * g.rows_per_wave + sub; r < n; r += blk.nrb * g.rows_per_block) {
+        const size_t t = pidx(g, blk.chunk, n, r, kl);
         const double x = Xb[t];
         const double viol = x < L[t] ? L[t] - x : (x > U[t] ? x - U[t] : 0.0);
         const double v = viol / col_norm[r];
         DX[t] = v;
         acc[0] += v * v;
     }
-    block_store_per_problem<1>(acc, g, k, true, partials);
+    block_store_per_problem<1>(acc, g, blk.rb, k, true, partials);
 }
 
 // DX = Xbar - lastX, DY = Ybar - lastY for ALL problems, with their squared norms
 // (reference batched_restart_movement_kernel :280-294 + the per-problem nrm2 calls :662-663)
-__global__ void __launch_bounds__(256) kb_movement(int n, int m, int Bp, const double *Xb, const double *lastX,
+__global__ void __launch_bounds__(256) kb_movement(int n, int m, Geo g, const double *Xb, const double *lastX,
                                                    double *DX, const double *Yb, const double *lastY, double *DY,
                                                    double *partials) {
-    const Geo g = make_geo(Bp);
+    const Blk blk = decode_block(g);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.y * 64 + (lane % g.Bw);
+    const int kl = lane % g.Bw, k = blk.chunk * g.Bw + kl;
     const int sub = lane / g.Bw;
     double acc[2] = {0.0, 0.0};
-    const int r0 = blockIdx.x * g.rows_per_block + wave * g.rows_per_wave + sub, rs = gridDim.x * g.rows_per_block;
+    const int r0 = blk.rb * g.rows_per_block + wave * g.rows_per_wave + sub, rs = blk.nrb * g.rows_per_block;
     for (int r = r0; r < n; r += rs) {
-        const size_t t = static_cast<size_t>(r) * Bp + k;
+        const size_t t = pidx(g, blk.chunk, n, r, kl);
         const double d = Xb[t] - lastX[t];
         DX[t] = d;
         acc[0] += d * d;
     }
     for (int r = r0; r < m; r += rs) {
-        const size_t t = static_cast<size_t>(r) * Bp + k;
+        const size_t t = pidx(g, blk.chunk, m, r, kl);
         const double d = Yb[t] - lastY[t];
         DY[t] = d;
         acc[1] += d * d;
     }
-    block_store_per_problem<2>(acc, g, k, true, partials);
+    block_store_per_problem<2>(acc, g, blk.rb, k, true, partials);
 }
 
 // where restart_flag[k]: X = lastX = Xbar, Y = lastY = Ybar, inner counter reset
 // (reference do_batched_restart_kernel :296-323)
-__global__ void __launch_bounds__(256) kb_restart(int n, int m, int Bp, double *X, double *lastX, const double *Xb,
+__global__ void __launch_bounds__(256) kb_restart(int n, int m, Geo g, double *X, double *lastX, const double *Xb,
                                                   double *Y, double *lastY, const double *Yb, BatchCtl ctl) {
-    const Geo g = make_geo(Bp);
+    const Blk blk = decode_block(g);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.y * 64 + (lane % g.Bw);
+    const int kl = lane % g.Bw, k = blk.chunk * g.Bw + kl;
     const int sub = lane / g.Bw;
     if (!ctl.restart_flag[k]) return;
-    const int r0 = blockIdx.x * g.rows_per_block + wave * g.rows_per_wave + sub, rs = gridDim.x * g.rows_per_block;
+    const int r0 = blk.rb * g.rows_per_block + wave * g.rows_per_wave + sub, rs = blk.nrb * g.rows_per_block;
     for (int r = r0; r < n; r += rs) {
-        const size_t t = static_cast<size_t>(r) * Bp + k;
+        const size_t t = pidx(g, blk.chunk, n, r, kl);
         const double v = Xb[t];
         X[t] = v;
         lastX[t] = v;
     }
     for (int r = r0; r < m; r += rs) {
-        const size_t t = static_cast<size_t>(r) * Bp + k;
+        const size_t t = pidx(g, blk.chunk, m, r, kl);
         const double v = Yb[t];
         Y[t] = v;
         lastY[t] = v;
     }
-    if (blockIdx.x == 0 && wave == 0 && sub == 0 && ctl.active[k]) {
+    if (blk.rb == 0 && wave == 0 && sub == 0 && ctl.active[k]) {
         ctl.kx[k] = 0;
         ctl.ky[k] = 0;
     }
@@ -449,7 +557,8 @@ struct BatchWS {
     HBuf<double> SC_h;
     BatchCtl ctl{};
     double lambda_max = 1.0;
-    int gx = 1, gy = 1, kchunks = 1;
+    int gx = 1, gy = 1;  // row blocks of the n- / m-row launches with partials (the grid is geo.nchunk times that)
+    Geo geo{};
     hipStream_t stream = nullptr;
     std::map<int, hipGraphExec_t> graphs;
     ~BatchWS() {
@@ -481,32 +590,36 @@ void finalize(BatchWS &w, int nblocks, std::initializer_list<int> slots) {
 
 void launch_half_pair(BatchWS &w, bool check) {
     const CsrDev &A = w.shared->A.view, &AT = w.shared->AT.view;
-    HalfArgs xa{w.Y.p, w.X.p, w.Xh.p, w.L.p, w.U.p, w.C.p, w.lastX.p, w.Xb.p, w.Zb.p, w.DX.p, w.ctl, w.lambda_max, w.partials.p, w.order_x.p};
-    HalfArgs ya{w.Xh.p, w.Y.p, nullptr, w.AL.p, w.AU.p, nullptr, w.lastY.p, w.Yb.p, w.Yobj.p, w.DY.p, w.ctl, w.lambda_max, w.partials.p, w.order_y.p};
-    const dim3 gxd(w.gx, w.kchunks), gyd(w.gy, w.kchunks), blk(256);
-    const bool wide = w.Bp >= 64;  // a wave = one row: kb_half64
+    HalfArgs xa{w.Y.p, w.m, w.X.p, w.Xh.p, w.L.p, w.U.p, w.C.p, w.lastX.p, w.Xb.p, w.Zb.p, w.DX.p, w.ctl, w.lambda_max, w.partials.p, w.order_x.p};
+    HalfArgs ya{w.Xh.p, w.n, w.Y.p, nullptr, w.AL.p, w.AU.p, nullptr, w.lastY.p, w.Yb.p, w.Yobj.p, w.DY.p, w.ctl, w.lambda_max, w.partials.p, w.order_y.p};
+    const Geo &g = w.geo;
+    const dim3 gxd(w.gx * g.nchunk), gyd(w.gy * g.nchunk), blk(256);
+    // kernel by chunk width: 64 -> a wave = one row (kb_half64); 8 / 16 / 32 -> lane groups with their own rows (kb_halfN);
+    // below: the plain row loop (kb_half)
+    auto launch = [&](auto xhalf, auto check, dim3 grid, const CsrDev &M, const HalfArgs &ha) {
+        constexpr bool X = decltype(xhalf)::value, C = decltype(check)::value;
+        switch (g.Bw) {
+            case 64: hipLaunchKernelGGL((kb_half64<X, C>), grid, blk, 0, w.stream, M.rows, M.rowptr, M.col, M.val, g, ha); break;
+            case 32: hipLaunchKernelGGL((kb_halfN<X, C, 32>), grid, blk, 0, w.stream, M.rows, M.rowptr, M.col, M.val, g, ha); break;
+            case 16: hipLaunchKernelGGL((kb_halfN<X, C, 16>), grid, blk, 0, w.stream, M.rows, M.rowptr, M.col, M.val, g, ha); break;
+            case 8: hipLaunchKernelGGL((kb_halfN<X, C, 8>), grid, blk, 0, w.stream, M.rows, M.rowptr, M.col, M.val, g, ha); break;
+            default: hipLaunchKernelGGL((kb_half<X, C>), grid, blk, 0, w.stream, M.rows, M.rowptr, M.col, M.val, g, ha); break;
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
     if (check) {
-        if (wide) hipLaunchKernelGGL((kb_half64<true, true>), gxd, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
-        else hipLaunchKernelGGL((kb_half<true, true>), gxd, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
+        launch(T{}, T{}, gxd, AT, xa);
         finalize(w, w.gx, {B_CX, B_XZ, B_DX2});
-        if (wide) hipLaunchKernelGGL((kb_half64<false, true>), gyd, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
-        else hipLaunchKernelGGL((kb_half<false, true>), gyd, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
+        launch(F{}, T{}, gyd, A, ya);
         finalize(w, w.gy, {B_YOBJ_Y, B_DY2});
     } else {
         // no reduction partials in the normal variant: one pass over the rows, as many workgroups as rows need
-        const Geo g = make_geo(w.Bp);
-        const int rpb = wide ? 4 * kRowsPerWave : g.rows_per_block;
+        const int rpb = g.Bw >= 8 ? 4 * kRowsPerWave * (64 / g.Bw) : g.rows_per_block;
         static const int grid_cap = std::getenv("HPRLP_BATCH_GRID") ? std::atoi(std::getenv("HPRLP_BATCH_GRID")) : 0;  // experiment knob
-        auto cap = [&](int g) { return grid_cap > 0 ? std::min(g, grid_cap) : g; };
-        const dim3 fx(cap((AT.rows + rpb - 1) / rpb), w.kchunks);
-        const dim3 fy(cap((A.rows + rpb - 1) / rpb), w.kchunks);
-        if (wide) {
-            hipLaunchKernelGGL((kb_half64<true, false>), fx, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
-            hipLaunchKernelGGL((kb_half64<false, false>), fy, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
-        } else {
-            hipLaunchKernelGGL((kb_half<true, false>), fx, blk, 0, w.stream, AT.rows, AT.rowptr, AT.col, AT.val, w.Bp, xa);
-            hipLaunchKernelGGL((kb_half<false, false>), fy, blk, 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp, ya);
-        }
+        auto cap = [&](int gr) { return grid_cap > 0 ? std::min(gr, grid_cap) : gr; };
+        launch(T{}, F{}, dim3(cap((AT.rows + rpb - 1) / rpb) * g.nchunk), AT, xa);
+        launch(F{}, F{}, dim3(cap((A.rows + rpb - 1) / rpb) * g.nchunk), A, ya);
     }
 }
 
@@ -541,8 +654,8 @@ inline double sc(const BatchWS &w, int slot, int k) { return w.SC_h.p[static_cas
 // unless a movement pass has overwritten DX/DY since (then B_MOVE_* hold the matching norms).
 void weighted_norm(BatchWS &w, bool dxdy_from_movement, std::vector<double> &sigma, std::vector<double> &out) {
     const CsrDev &A = w.shared->A.view;
-    hipLaunchKernelGGL((kb_resid<3>), dim3(w.gy, w.kchunks), dim3(256), 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.Bp,
-                       static_cast<const double *>(nullptr), w.DX.p, static_cast<const double *>(nullptr),
+    hipLaunchKernelGGL((kb_resid<3>), dim3(w.gy * w.geo.nchunk), dim3(256), 0, w.stream, A.rows, A.rowptr, A.col, A.val, w.geo,
+                       w.n, static_cast<const double *>(nullptr), w.DX.p, static_cast<const double *>(nullptr),
                        static_cast<const double *>(nullptr), static_cast<const double *>(nullptr), w.DY.p, w.partials.p);
     finalize(w, w.gy, {B_ADX_DY});
     fetch(w);
@@ -580,11 +693,28 @@ double column_norm_host(const double *X, int n, size_t off) {  // :347-354
     return std::sqrt(static_cast<double>(sum));
 }
 
-// column-major (ABI) n x B -> row-major padded n x Bp
-void to_panel(const std::vector<double> &cm, int rows, int B, int Bp, double pad, std::vector<double> &out) {
-    out.assign(static_cast<size_t>(rows) * Bp, pad);
+// element (row i, problem k) of a device panel with `rows` rows (the host's copy of pidx)
+inline size_t panel_index(const Geo &g, int rows, int i, int k) {
+    return (static_cast<size_t>(k / g.Bw) * rows + i) * g.Bw + k % g.Bw;
+}
+// column-major (ABI) rows x B -> padded device panel
+void to_panel(const std::vector<double> &cm, int rows, int B, const Geo &g, double pad, std::vector<double> &out) {
+    out.assign(static_cast<size_t>(rows) * g.Bp, pad);
     for (int k = 0; k < B; ++k)
-        for (int i = 0; i < rows; ++i) out[static_cast<size_t>(i) * Bp + k] = cm[static_cast<size_t>(k) * rows + i];
+        for (int i = 0; i < rows; ++i) out[panel_index(g, rows, i, k)] = cm[static_cast<size_t>(k) * rows + i];
+}
+
+// Chunk width.  Below 64 problems: one chunk.  From 64 up: 8 problems per chunk when the gathered panels are too large for
+// an XCD's L2 as a whole but an eighth (a sixteenth, ..) of them is not -- every XCD then works on its own chunks and
+// gathers from 1 / nchunk-th of the panel -- else 64 (a wave = one row, scalar CSR loads).  HPRLP_BATCH_CHUNK overrides.
+int choose_chunk(int m, int n, int Bp) {
+    if (Bp < 64) return Bp;
+    if (const char *e = std::getenv("HPRLP_BATCH_CHUNK")) {
+        const int c = std::atoi(e);
+        if (c == 8 || c == 16 || c == 32 || c == 64) return c;
+    }
+    (void)m; (void)n;
+    return 64;
 }
 
 HPRLP_batched_results make_batched_error(const char *status, int m, int n, int B) {  // :356-368
@@ -679,20 +809,33 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
         w.shared = &shared;
         w.stream = shared.stream;
         w.lambda_max = lambda0;
-        const Geo geo = make_geo(w.Bp);
-        w.kchunks = (w.Bp + 63) / 64;
+        w.geo = make_geo(w.Bp, choose_chunk(m, n, w.Bp));
+        const Geo &geo = w.geo;
         w.gx = grid_for(n, geo);
         w.gy = grid_for(m, geo);
-        if (w.Bp >= 64) {
+        if (geo.Bw >= 8) {
             // groups of kRowsPerWave rows with more than kLongGroup nonzeros go first, longest first; the rest keep their order
-            auto build_order = [](const DBuf<int> &rowptr_dev, int rows, DBuf<int> &out) {
+            // a wave's group: 64 / Bw lane groups of kRowsPerWave rows each; its length = the longest lane group's entry count
+            const int subs = 64 / geo.Bw, gr = kRowsPerWave * subs;
+            auto build_order = [gr, subs](const DBuf<int> &rowptr_dev, int rows, DBuf<int> &out) {
                 constexpr int kLongGroup = 32;
                 std::vector<int> rp(static_cast<size_t>(rows) + 1);
                 rowptr_dev.download(rp.data(), rp.size());
-                const int ng = (rows + kRowsPerWave - 1) / kRowsPerWave;
+                const int ng = (rows + gr - 1) / gr;
                 std::vector<int> longg, order;
                 order.reserve(static_cast<size_t>(ng));
-                auto len = [&](int g) { return rp[std::min(rows, (g + 1) * kRowsPerWave)] - rp[g * kRowsPerWave]; };
+                auto len = [&](int g) {
+                    int longest = 0;
+                    for (int sb = 0; sb < subs; ++sb) {  // lane group sb: rows g * gr + i * subs + sb (kb_halfN; kb_half64: subs = 1)
+                        int cnt = 0;
+                        for (int i = 0; i < kRowsPerWave; ++i) {
+                            const int r = g * gr + i * subs + sb;
+                            if (r < rows) cnt += rp[r + 1] - rp[r];
+                        }
+                        longest = std::max(longest, cnt);
+                    }
+                    return longest;
+                };
                 for (int g = 0; g < ng; ++g)
                     if (len(g) > kLongGroup) longg.push_back(g);
                 if (longg.empty()) return;  // identity: no table
@@ -709,11 +852,11 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
         const size_t nB = static_cast<size_t>(n) * w.Bp, mB = static_cast<size_t>(m) * w.Bp;
         {
             std::vector<double> panel;
-            to_panel(hC, n, B, w.Bp, 0.0, panel); w.C.alloc(nB); w.C.upload(panel.data(), nB);
-            to_panel(hL, n, B, w.Bp, 0.0, panel); w.L.alloc(nB); w.L.upload(panel.data(), nB);
-            to_panel(hU, n, B, w.Bp, 0.0, panel); w.U.alloc(nB); w.U.upload(panel.data(), nB);
-            to_panel(hAL, m, B, w.Bp, 0.0, panel); w.AL.alloc(mB); w.AL.upload(panel.data(), mB);
-            to_panel(hAU, m, B, w.Bp, 0.0, panel); w.AU.alloc(mB); w.AU.upload(panel.data(), mB);
+            to_panel(hC, n, B, geo, 0.0, panel); w.C.alloc(nB); w.C.upload(panel.data(), nB);
+            to_panel(hL, n, B, geo, 0.0, panel); w.L.alloc(nB); w.L.upload(panel.data(), nB);
+            to_panel(hU, n, B, geo, 0.0, panel); w.U.alloc(nB); w.U.upload(panel.data(), nB);
+            to_panel(hAL, m, B, geo, 0.0, panel); w.AL.alloc(mB); w.AL.upload(panel.data(), mB);
+            to_panel(hAU, m, B, geo, 0.0, panel); w.AU.alloc(mB); w.AU.upload(panel.data(), mB);
         }
         for (DBuf<double> *p : {&w.X, &w.Xh, &w.Xb, &w.DX, &w.Zb, &w.lastX}) p->alloc_zero(nB);
         for (DBuf<double> *p : {&w.Y, &w.Yb, &w.DY, &w.Yobj, &w.lastY}) p->alloc_zero(mB);
@@ -752,16 +895,16 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
             if (periodic) {
                 if (iter > 0) weighted_norm(w, dxdy_from_movement, sigma, cur_gap);
                 // compute_residuals :578-624
-                hipLaunchKernelGGL((kb_resid<0>), dim3(w.gx, w.kchunks), dim3(256), 0, w.stream, AT.rows, AT.rowptr, AT.col,
-                                   AT.val, w.Bp, w.Yb.p, static_cast<const double *>(nullptr), w.C.p, w.Zb.p,
+                hipLaunchKernelGGL((kb_resid<0>), dim3(w.gx * geo.nchunk), dim3(256), 0, w.stream, AT.rows, AT.rowptr, AT.col,
+                                   AT.val, geo, m, w.Yb.p, static_cast<const double *>(nullptr), w.C.p, w.Zb.p,
                                    shared.col_norm.p, static_cast<const double *>(nullptr), w.partials.p);
                 finalize(w, w.gx, {B_RD2});
-                hipLaunchKernelGGL((kb_resid<1>), dim3(w.gy, w.kchunks), dim3(256), 0, w.stream, A.rows, A.rowptr, A.col,
-                                   A.val, w.Bp, w.Xb.p, static_cast<const double *>(nullptr), w.AL.p, w.AU.p,
+                hipLaunchKernelGGL((kb_resid<1>), dim3(w.gy * geo.nchunk), dim3(256), 0, w.stream, A.rows, A.rowptr, A.col,
+                                   A.val, geo, n, w.Xb.p, static_cast<const double *>(nullptr), w.AL.p, w.AU.p,
                                    shared.row_norm.p, static_cast<const double *>(nullptr), w.partials.p);
                 finalize(w, w.gy, {B_RP2});
                 if (iter == 0) {
-                    hipLaunchKernelGGL(kb_lu, dim3(w.gx, w.kchunks), dim3(256), 0, w.stream, n, w.Bp, w.Xb.p, w.L.p, w.U.p,
+                    hipLaunchKernelGGL(kb_lu, dim3(w.gx * geo.nchunk), dim3(256), 0, w.stream, n, geo, w.Xb.p, w.L.p, w.U.p,
                                        shared.col_norm.p, w.DX.p, w.partials.p);
                     finalize(w, w.gx, {B_LU2});
                 }
@@ -823,7 +966,7 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
             for (int k = 0; k < B; ++k) restarted = restarted || rflag[k] > 0;
             if (restarted) {
                 // update_sigma :702-745 (movement norms for every problem, formula for the flagged ones)
-                hipLaunchKernelGGL(kb_movement, dim3(std::max(w.gx, w.gy), w.kchunks), dim3(256), 0, w.stream, n, m, w.Bp,
+                hipLaunchKernelGGL(kb_movement, dim3(std::max(w.gx, w.gy) * geo.nchunk), dim3(256), 0, w.stream, n, m, geo,
                                    w.Xb.p, w.lastX.p, w.DX.p, w.Yb.p, w.lastY.p, w.DY.p, w.partials.p);
                 finalize(w, std::max(w.gx, w.gy), {B_MOVE_X2, B_MOVE_Y2});
                 fetch(w);
@@ -851,7 +994,7 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
                 // do_restart :747-769
                 for (int k = 0; k < w.Bp; ++k) flags[k] = (k < B && rflag[k] > 0) ? 1 : 0;
                 w.rflag.upload(flags.data(), w.Bp);
-                hipLaunchKernelGGL(kb_restart, dim3(std::max(w.gx, w.gy), w.kchunks), dim3(256), 0, w.stream, n, m, w.Bp,
+                hipLaunchKernelGGL(kb_restart, dim3(std::max(w.gx, w.gy) * geo.nchunk), dim3(256), 0, w.stream, n, m, geo,
                                    w.X.p, w.lastX.p, w.Xb.p, w.Y.p, w.lastY.p, w.Yb.p, w.ctl);
                 for (int k = 0; k < B; ++k)
                     if (active[k] && rflag[k] > 0) {
@@ -910,12 +1053,12 @@ extern "C" HPRLP_batched_results solve_batched(const LP_info_cpu *model, int bat
         }
         for (int k = 0; k < B; ++k) {
             for (int i = 0; i < n; ++i) {
-                const size_t src = static_cast<size_t>(i) * w.Bp + k, dst = static_cast<size_t>(k) * n + i;
+                const size_t src = panel_index(geo, n, i, k), dst = static_cast<size_t>(k) * n + i;
                 out.x[dst] = (hX[src] / cn[i]) * b_scale[k];
                 out.z[dst] = (hZ[src] * cn[i]) * c_scale[k];
             }
             for (int i = 0; i < m; ++i) {
-                const size_t src = static_cast<size_t>(i) * w.Bp + k, dst = static_cast<size_t>(k) * m + i;
+                const size_t src = panel_index(geo, m, i, k), dst = static_cast<size_t>(k) * m + i;
                 out.y[dst] = (hY[src] / rn[i]) * c_scale[k];
             }
             out.primal_obj[k] = r_pobj[k];

@@ -80,6 +80,42 @@ def test_planted_batch_matches_oracle(gpu, B):
     model.free()
 
 
+@pytest.mark.parametrize("B,chunk", [(64, 8), (64, 16), (70, 32), (70, 8), (24, 0)])
+def test_chunk_widths_of_the_panels_give_the_same_solves(gpu, B, chunk):
+    """The device panels are stored chunk-major (hpr-lp-c_amd/csrc/batched.hip: layout); HPRLP_BATCH_CHUNK forces chunks of
+    8 / 16 / 32 problems where the default is 64 (kb_halfN instead of kb_half64; B = 24 -> one chunk of 32 by itself).  Every
+    row sum is added in CSR order by every kernel, so members follow the same trajectory: same status and stopping iteration
+    as the oracle (up to forks at thresholded restart decisions), same optimum."""
+    lp = lpgen.planted_lp(150, 260, 1700, 70 + B)
+    Cm, AL, AU, L, U = make_batch(lp, B, B + 1)
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
+                                 lp["l"], lp["u"], lp["c"])
+    tol = 1e-6
+    prm = hprlp.Parameters(stop_tol=tol, max_iter=60000, use_presolve=False)
+    old = os.environ.get("HPRLP_BATCH_CHUNK")
+    try:
+        if chunk:
+            os.environ["HPRLP_BATCH_CHUNK"] = str(chunk)
+        r = hprlp.solve_batched(model, Cm, AL, AU, L, U, None, prm)
+    finally:
+        os.environ.pop("HPRLP_BATCH_CHUNK", None)
+        if old is not None:
+            os.environ["HPRLP_BATCH_CHUNK"] = old
+    ref = O.solve_batched(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], B, Cm.T.ravel(), AL.T.ravel(),
+                          AU.T.ravel(), L.T.ravel(), U.T.ravel(), None,
+                          params=O.Params.default(stop_tol=tol, max_iter=60000))
+    assert r["status"] == ref["status"]
+    done = [k for k in range(B) if ref["status"][k] == "OPTIMAL"]
+    assert len(done) >= B // 2
+    assert sum(int(r["iter"][k] == ref["iter"][k]) for k in done) >= 0.8 * len(done)
+    for k in done:
+        assert abs(r["primal_obj"][k] - ref["primal_obj"][k]) <= 20 * tol * (1 + abs(ref["primal_obj"][k]))
+        assert r["residuals"][k] <= tol
+        if r["iter"][k] == ref["iter"][k]:
+            np.testing.assert_allclose(r["x"][:, k], ref["x"][k], rtol=1e-7, atol=1e-8)
+    model.free()
+
+
 def test_batched_bad_arguments(gpu, model_mps_arrays):
     a = model_mps_arrays
     model = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"])
