@@ -169,7 +169,11 @@ void launch_lu(int n, const double *x_bar, const double *l, const double *u, con
 void launch_set_ctrl(Ctrl *ctrl, double sigma, double lambda_max, int reset_k, hipStream_t s);
 
 // scaling (reference src/scaling.cu)
-void launch_cr_log_update(const CsrDev &M, const double *other_full, double *result, hipStream_t s);
+// tval_log / fval_log: the log values of M's tiled copy (launch_tiled_refresh_log) -- the pass then runs through the tiled
+// kernel if cr_runs_tiled(M); null: stream kernel
+void launch_cr_log_update(const CsrDev &M, const double *other_full, double *result, hipStream_t s, const double *tval_log = nullptr,
+                          const double *fval_log = nullptr);
+bool cr_runs_tiled(const CsrDev &M);
 void launch_exp_clamp(double *v, int n, hipStream_t s);
 void launch_row_norm(const CsrDev &M, double *result, int norm, hipStream_t s);
 // val = op(op(val, first), second) where first/second are the row vector or the gathered column vector

@@ -80,6 +80,12 @@ template <class Epi>
 __device__ __forceinline__ double term(double a, double g) {
     return TermOf<Epi>::f(a, g);
 }
+// Tiled kernels: an epilogue with kLogTerm sums (stored value - g) over the entries, the stored values being -log|a| and NaN
+// in the padding slots (launch_tiled_refresh_log); everybody else sums stored value * g (padding: 0).
+template <class Epi, class = void>
+struct LogTerm : std::false_type {};
+template <class Epi>
+struct LogTerm<Epi, std::void_t<decltype(Epi::kLogTerm)>> : std::true_type {};
 
 template <class Epi>
 __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
@@ -323,7 +329,7 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 #define HPRLP_DBG_NOBARRIER 0
 #endif
 
-template <int ED, int TD, bool REP, bool STAMP = false>
+template <int ED, int TD, bool REP, bool STAMP = false, bool LOGTERM = false>
 __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, int first, int count, const double *__restrict__ vec,
                                             int ncols, double *acc, double *ytile, int tid, unsigned long long *stamp = nullptr) {
     constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols, K = kTileChunk;  // (R: the codes' row field, whatever the copy's height)
@@ -422,10 +428,12 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
             double a[K];
 #pragma unroll
             for (int k2 = 0; k2 < K; ++k2) a[k2] = acc[rw[k2]];
-            double sk[K];
-            sk[0] = a[0] + v[0] * y[0];
+            double sk[K], pr[K];
 #pragma unroll
-            for (int k2 = 1; k2 < K; ++k2) sk[k2] = ((rw[k2] == rw[k2 - 1]) ? sk[k2 - 1] : a[k2]) + v[k2] * y[k2];
+            for (int k2 = 0; k2 < K; ++k2) pr[k2] = LOGTERM ? (v[k2] != v[k2] ? 0.0 : v[k2] - y[k2]) : v[k2] * y[k2];
+            sk[0] = a[0] + pr[0];
+#pragma unroll
+            for (int k2 = 1; k2 < K; ++k2) sk[k2] = ((rw[k2] == rw[k2 - 1]) ? sk[k2 - 1] : a[k2]) + pr[k2];
 #pragma unroll
             for (int k2 = 0; k2 < K; ++k2)
                 if (k2 == K - 1 || rw[k2] != rw[k2 + 1]) acc[rw[k2]] = sk[k2];
@@ -673,7 +681,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         const int ncols = A.cols;
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
-        if (s0 < smid) tiled_sweep<HPRLP_SWEEP_ED, HPRLP_SWEEP_TD, REP>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
+        if (s0 < smid) tiled_sweep<HPRLP_SWEEP_ED, HPRLP_SWEEP_TD, REP, false, LogTerm<Epi>::value>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
 #if !HPRLP_DBG_NOREM
         tiled_remainder(t, smid, s1, acc, ytile, tid);
 #endif
@@ -826,10 +834,29 @@ void launch_tiled_refresh(const DeviceTiled &t, const double *csr_val, hipStream
                            t.n_rem, t.f_perm.p, csr_val, t.f_val.p);
 }
 
+// the Curtis-Reid passes' values of a tiled copy: -log|a| (as CrEpi::term forms it), NaN in the padding slots
+__global__ void __launch_bounds__(kThreads) k_tiled_refresh_log(long n, const int *perm, const double *csr_val, double *out) {
+    const long i = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < n) {
+        const int p = perm[i];
+        out[i] = p >= 0 ? -log(fmax(fabs(csr_val[p]), 1e-300)) : __builtin_nan("");
+    }
+}
+
+void launch_tiled_refresh_log(const DeviceTiled &t, const double *csr_val, double *tval_log, double *fval_log, hipStream_t s) {
+    if (t.n_tile > 0)
+        hipLaunchKernelGGL(k_tiled_refresh_log, dim3(static_cast<unsigned>((t.n_tile + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           t.n_tile, t.tperm.p, csr_val, tval_log);
+    if (t.n_rem > 0 && t.f_val.p)
+        hipLaunchKernelGGL(k_tiled_refresh_log, dim3(static_cast<unsigned>((t.n_rem + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           t.n_rem, t.f_perm.p, csr_val, fval_log);
+}
+
 // Pre-pass of a tiled launch (tiled.h): one workgroup per group of kFarGroup columns of the gathered vector.  The
 // group's slice is staged in LDS with coalesced loads; the workgroup streams its remainder entries (value, local
 // column, position in P -- ascending, so the stores of one (group, super-block) run are contiguous) and writes the
 // products.  Every gathered element is read from memory once, no 128-byte line is fetched for 8 bytes.
+template <bool LOGTERM = false>
 __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const double *__restrict__ vec, int ncols) {
     __shared__ double v[kFarGroup];
     // workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of groups, so that the runs its
@@ -873,7 +900,7 @@ __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const 
         int ps[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            pr[u] = a[u] * v[lc[u]];
+            pr[u] = LOGTERM ? a[u] - v[lc[u]] : a[u] * v[lc[u]];
             ps[u] = pos[u];
         }
         const int kn = k + U * kFarThreads;
@@ -1236,7 +1263,7 @@ static bool launch_fused(const CsrDev &M, const Epi &e, hipStream_t s, bool far_
 template <class Epi>
 static bool launch_tiled(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready) {
     if (M.tiled.n_groups > 0 && !far_ready)
-        hipLaunchKernelGGL(k_far_products, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
+        hipLaunchKernelGGL(k_far_products<false>, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
     if (M.tiled.n_pieces > 0) {
         const dim3 grid((M.tiled.n_pieces + 7) / 8 * 8);
         if (M.tiled.stamps) hipLaunchKernelGGL((k_tiled_part<false, true>), grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
@@ -1473,11 +1500,13 @@ void launch_set_ctrl(Ctrl *ctrl, double sigma, double lambda_max, int reset_k, h
 // ------------------------------------------------------------------------------------------------
 // Curtis-Reid update (reference scaling.cu:5-38): result[r] = mean over the row's entries of (-log|a| - other[col]).
 // Runs as an epilogue of the stream kernel (coalesced matrix reads; per row the terms are added in CSR order like
-// the thread-per-row loop it replaces, which took 6.4 ms per pass on the 2e8-nnz matrix against 1.4 ms).  Never the
-// tiled kernel: its zero padding is only neutral for products.
+// the thread-per-row loop it replaces, which took 6.4 ms per pass on the 2e8-nnz matrix against 1.4 ms).  Through the
+// tiled kernel when the caller holds the copy's log values (launch_tiled_refresh_log: -log|a| formed once instead of in each
+// of the 20 passes, NaN = padding): the same terms, added in the tiled kernel's order.
 struct CrEpi {
     static constexpr int NV = 1;
     static constexpr int NACC = 0;
+    static constexpr bool kLogTerm = true;
     const double *gv[1];
     const int *rowptr;
     double *result;
@@ -1494,9 +1523,22 @@ struct CrEpi {
     }
 };
 
-void launch_cr_log_update(const CsrDev &M, const double *other_full, double *result, hipStream_t s) {
+bool cr_runs_tiled(const CsrDev &M) { return M.tiled.valid && M.tiled.n_pieces == 0 && M.tiled.side_nblk == 0; }
+
+void launch_cr_log_update(const CsrDev &M, const double *other_full, double *result, hipStream_t s, const double *tval_log,
+                          const double *fval_log) {
     if (M.rows <= 0 || M.nblk <= 0) return;
     CrEpi e{{other_full}, M.rowptr, result, nullptr, 0};
+    if (tval_log && cr_runs_tiled(M)) {
+        CsrDev L = M;
+        L.tiled.tval = tval_log;
+        L.tiled.f_val = fval_log;
+        if (L.tiled.n_groups > 0)
+            hipLaunchKernelGGL(k_far_products<true>, dim3((L.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, L.tiled, other_full, L.cols);
+        if (L.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<CrEpi, true>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);
+        else hipLaunchKernelGGL((k_tiled_fused<CrEpi, false>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);
+        return;
+    }
     hipLaunchKernelGGL(k_spmv_fused<CrEpi>, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, e);
     if (M.nlong > 0)
         hipLaunchKernelGGL(k_long_finish<CrEpi>, dim3(M.finish_grid()), dim3(kThreads), 0, s, M, e, M.csr_grid());

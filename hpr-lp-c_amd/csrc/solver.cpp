@@ -847,12 +847,28 @@ void Solver::scale() {
     if (prm.use_CR_scaling) {  // :40-83
         HIP_CHECK(hipMemsetAsync(gsm.p, 0, sizeof(double) * m_pad, stream));
         HIP_CHECK(hipMemsetAsync(gsn.p, 0, sizeof(double) * n_pad, stream));
+        // Matrices with a tiled copy run the 40 passes through the tiled kernel on a second value array of the copy that
+        // holds -log|a| (formed once; released when the passes are done).  HPRLP_NO_TILED_CR=1: stream kernel (A/B runs).
+        finish_tiling();
+        struct LogValues {
+            DBuf<double> tile, far;
+        } logA, logAT;
+        const bool tiled_cr = std::getenv("HPRLP_NO_TILED_CR") == nullptr;
+        auto log_values = [&](DeviceMatrix &M, LogValues &lv) {
+            if (!tiled_cr || !cr_runs_tiled(M.view)) return;
+            lv.tile.alloc(static_cast<size_t>(std::max<long>(M.tiled.n_tile, 1)));
+            lv.far.alloc(static_cast<size_t>(std::max<long>(M.tiled.n_rem, 1)));
+            launch_tiled_refresh_log(M.tiled, M.val.p, lv.tile.p, lv.far.p, stream);
+        };
+        log_values(A, logA);
+        log_values(AT, logAT);
         for (int it = 0; it < 20; ++it) {
-            launch_cr_log_update(A.view, gsn.p, t1, stream);
+            launch_cr_log_update(A.view, gsn.p, t1, stream, logA.tile.p, logA.far.p);
             gather(gsm.p, true);
-            launch_cr_log_update(AT.view, gsm.p, t2, stream);
+            launch_cr_log_update(AT.view, gsm.p, t2, stream, logAT.tile.p, logAT.far.p);
             gather(gsn.p, false);
         }
+        if (logA.tile.p || logAT.tile.p) HIP_CHECK(hipStreamSynchronize(stream));  // the log values are released below
         launch_exp_clamp(t1, m_loc, stream);
         launch_exp_clamp(t2, n_loc, stream);
         gather(gsm.p, true);

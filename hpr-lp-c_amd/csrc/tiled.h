@@ -188,5 +188,8 @@ struct DeviceTiled {
 
 // tval[e] = csr_val[tperm[e]] (0 for padding), f_val likewise
 void launch_tiled_refresh(const DeviceTiled &t, const double *csr_val, hipStream_t s);
+// tval_log[e] = -log(max(|csr_val[tperm[e]]|, 1e-300)) (NaN for padding), fval_log likewise: what the Curtis-Reid passes sum
+// when they run through the tiled kernel (kernels.hip: CrEpi)
+void launch_tiled_refresh_log(const DeviceTiled &t, const double *csr_val, double *tval_log, double *fval_log, hipStream_t s);
 
 }  // namespace hprlp

@@ -292,3 +292,46 @@ def test_lowered_heights_differ_between_a_and_its_transpose(gpu):
         np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
     assert abs(res["kkt"] - res0["kkt"]) <= 1e-9 * (1 + abs(res0["kkt"]))
     model.free()
+
+
+@pytest.mark.parametrize("rows_sb", [0, 1024])
+def test_curtis_reid_passes_through_the_tiled_kernel_match_the_oracle(gpu, force_tiled, rows_sb):
+    """The 40 Curtis-Reid passes of scale() (reference src/scaling.cu:5-38, 40-83) run through the tiled kernel on the copy's
+    -log|a| values (NaN marks padding, so an explicitly stored zero keeps the reference's -log(1e-300) term): scaled matrix,
+    bounds and norms against the oracle's scaling, and against the stream-kernel passes (HPRLP_NO_TILED_CR=1)."""
+    m, n = 9000, 12000
+    lp, model0 = build(m, n, 8, 400)
+    model0.free()
+    vals = lp["values"].copy()
+    vals[[5, 777, 40001]] = 0.0   # explicitly stored zeros
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], vals, lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    old = {k: os.environ.get(k) for k in ("HPRLP_TILE_ROWS", "HPRLP_TILE_PIECES", "HPRLP_NO_TILED_CR")}
+    if rows_sb:
+        os.environ["HPRLP_TILE_ROWS"] = str(rows_sb)
+    os.environ["HPRLP_TILE_PIECES"] = "0"
+    try:
+        got = {}
+        for mode in ("tiled", "stream"):
+            if mode == "stream":
+                os.environ["HPRLP_NO_TILED_CR"] = "1"
+            s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+            assert s.info()["tiled"] & 3 == 3
+            s.scale()
+            got[mode] = {k: s.get(k) for k in ("A_val", "AT_val", "AL", "AU", "l", "u", "c", "row_norm", "col_norm")}
+            s.close()
+        ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], vals, lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"], O.Params.default())
+        want = {"A_val": ref.Av, "AT_val": ref.ATv, "AL": ref.AL, "AU": ref.AU, "l": ref.l, "u": ref.u, "c": ref.c,
+                "row_norm": ref.row_norm, "col_norm": ref.col_norm}
+        for k, w in want.items():
+            fin = np.isfinite(w)
+            assert np.array_equal(fin, np.isfinite(got["tiled"][k])), k
+            np.testing.assert_allclose(got["tiled"][k][fin], w[fin], rtol=1e-11, atol=1e-300, err_msg=k)
+            np.testing.assert_allclose(got["stream"][k][fin], w[fin], rtol=1e-11, atol=1e-300, err_msg=k)
+        assert not np.array_equal(got["tiled"]["row_norm"], np.ones(m))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        model.free()
