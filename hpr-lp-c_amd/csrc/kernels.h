@@ -186,6 +186,8 @@ void launch_bnorm2(const double *AL, const double *AU, int m, double *partials, 
 void launch_norm2(const double *x, int n, double *partials, int nblocks, hipStream_t s);
 
 // power iteration helpers
+void launch_check_columns(long nnz, int cols, const int *col, int *bad, hipStream_t s);
+void launch_pw_start(int m, unsigned long long seed, long long offset, double *z, hipStream_t s);  // power_start_vector on the device
 void launch_pw_normalize(const double *z, double *q, int m, const double *scalars, hipStream_t s);
 void launch_pw_err(const double *z, const double *q, int m, const double *scalars, double *partials, int nblocks,
                    hipStream_t s);

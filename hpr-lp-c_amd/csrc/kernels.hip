@@ -1798,6 +1798,39 @@ void launch_bound_codes(int n, const double *l, const double *u, unsigned char *
 // ------------------------------------------------------------------------------------------------
 // power iteration helpers (reference src/power_iteration.cu:60-100)
 // ------------------------------------------------------------------------------------------------
+// *bad = 1 if some column index lies outside [0, cols) (DeviceMatrix::upload: the kernels index without bounds checks)
+__global__ void __launch_bounds__(kThreads) k_check_columns(long nnz, int cols, const int *__restrict__ col, int *bad) {
+    const long stride = static_cast<long>(gridDim.x) * kThreads;
+    int b = 0;
+    for (long k = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x; k < nnz; k += stride) b |= (col[k] < 0 || col[k] >= cols);
+    if (b) *bad = 1;
+}
+void launch_check_columns(long nnz, int cols, const int *col, int *bad, hipStream_t s) {
+    if (nnz > 0) hipLaunchKernelGGL(k_check_columns, dim3(static_cast<unsigned>(std::min<long>((nnz + kThreads - 1) / kThreads, 8192))), dim3(kThreads), 0, s, nnz, cols, col, bad);
+}
+
+// The power iteration's start vector formed where it is used (host_model.cpp: power_start_vector, same counter generator and
+// the same formula; log / cos are the device library's, so elements may differ from the host's in the last place).  For
+// vectors of millions of rows: the host fill + copy of config 5's 1e7 rows was 50 ms of a 0.43 s power iteration.
+__global__ void __launch_bounds__(kThreads) k_pw_start(int m, unsigned long long seed, long long offset, double *z) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= m) return;
+    auto mix = [](unsigned long long x) {
+        unsigned long long v = x + 0x9E3779B97F4A7C15ULL;
+        v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        v = (v ^ (v >> 27)) * 0x94D049BB133111EBULL;
+        return v ^ (v >> 31);
+    };
+    const unsigned long long base = seed * 0x100000001B3ULL, g = static_cast<unsigned long long>(offset + i);
+    const unsigned long long h1 = mix(base + 2 * g), h2 = mix(base + 2 * g + 1);
+    const double two53 = 1.0 / 9007199254740992.0, twopi = 6.283185307179586476925286766559;
+    const double u1 = static_cast<double>((h1 >> 11) + 1) * two53, u2 = static_cast<double>(h2 >> 11) * two53;
+    z[i] = sqrt(-2.0 * log(u1)) * cos(twopi * u2) + 1e-8;
+}
+void launch_pw_start(int m, unsigned long long seed, long long offset, double *z, hipStream_t s) {
+    if (m > 0) hipLaunchKernelGGL(k_pw_start, dim3((m + kThreads - 1) / kThreads), dim3(kThreads), 0, s, m, seed, offset, z);
+}
+
 __global__ void __launch_bounds__(kThreads) k_pw_normalize(const double *z, double *q, int m, const double *scalars) {
     const double invn = 1.0 / sqrt(scalars[S_PW_ZZ] + 2.220446049250313e-16);
     const int tid = blockIdx.x * kThreads + threadIdx.x, nth = gridDim.x * kThreads;

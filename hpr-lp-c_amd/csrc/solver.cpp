@@ -21,6 +21,8 @@
 namespace hprlp {
 
 constexpr int kMaxGraphIters = 64;
+constexpr int kDeviceStartRows = 1000000;  // power iteration: start vectors longer than this are generated on the device
+constexpr int kPowerBlockKey = -10;  // Solver::graphs: the power iteration's block of ten iterations (positive keys: normal iterations)
 
 // ------------------------------------------------------------------------------------------------
 std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows) {
@@ -81,27 +83,24 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     // the kernels index without bounds checks: refuse anything that could fault on the device
     for (int i = 0; i < rows; ++i)
         if (rp[i + 1] < rp[i]) throw std::runtime_error("row pointer array is not monotone");
-    {
-        const int T = nnz > 4000000 ? static_cast<int>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()))) : 1;
-        std::vector<char> bad(static_cast<size_t>(T), 0);
-        auto scan = [&](int t) {
-            const long lo = static_cast<long>(nnz) * t / T, hi = static_cast<long>(nnz) * (t + 1) / T;
-            char b = 0;
-            for (long k = lo; k < hi; ++k) b |= (ci[k] < 0 || ci[k] >= cols);
-            bad[t] = b;
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
-        scan(0);
-        for (auto &x : th) x.join();
-        for (char b : bad)
-            if (b) throw std::runtime_error("column index out of range");
+    const bool check_on_device = nnz > 4000000;  // (a pass over the uploaded copy: 0.3 ms instead of 10 ms of 8 host threads at 2e8)
+    if (!check_on_device) {
+        for (long k = 0; k < nnz; ++k)
+            if (ci[k] < 0 || ci[k] >= cols) throw std::runtime_error("column index out of range");
     }
     pt.tick("  validate indices");
     rowptr.alloc(static_cast<size_t>(rows) + 1);
     rowptr.upload(rp, static_cast<size_t>(rows) + 1);
     col.alloc(nnz);
     col.upload(ci, nnz);
+    if (check_on_device) {
+        DBuf<int> bad;
+        bad.alloc_zero(1);
+        launch_check_columns(nnz, cols, col.p, bad.p, nullptr);
+        int b = 0;
+        bad.download(&b, 1);
+        if (b) throw std::runtime_error("column index out of range");
+    }
     val.alloc(nnz);
     val.upload(v, nnz);
     pt.tick("  upload CSR");
@@ -937,7 +936,12 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
     invalidate_far();
     const auto t0 = time_now();
     double *q = gsm.p + row_off, *ATq = gsn.p + col_off, *z = sm1.p;
-    {
+    // large vectors in the caller's numbering are filled on the device (last-place differences from the host's libm are
+    // possible there; below the threshold the start vector is the oracle's bit for bit)
+    const bool host_start = std::getenv("HPRLP_HOST_POWER_START") != nullptr;  // (tests)
+    if (m_loc > kDeviceStartRows && perm_r.empty() && !host_start) {
+        launch_pw_start(m_loc, 1ULL, row_off, z, stream);
+    } else {
         std::vector<double> z0(static_cast<size_t>(std::max(m_loc, 1)));
         power_start_vector(m_loc, 1ULL, row_off, z0.data());
         if (!perm_r.empty()) {  // the start vector is defined in the caller's row numbering
@@ -973,7 +977,7 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
     double lambda = 1.0;
     int done = max_iter;
     const int gridA = A.view.grid();
-    for (int i = 1; i <= max_iter; ++i) {
+    auto one_iteration = [&]() {
         launch_pw_normalize(z, q, m_loc, scal.p, stream);
         gather(gsm.p, true);
         // A^T q: its epilogue writes the products A's remainder needs (hand-off, as between the half-steps): A runs without a pre-pass
@@ -986,13 +990,42 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
         f.item[1] = {part_y.p + stride_y, gridA, S_PW_QZ};
         launch_finalize(f, scal.p, stream);
         allreduce_slots(this, S_PW_ZZ, 2);
+    };
+    auto error_terms = [&]() {
+        launch_pw_err(z, q, m_loc, scal.p, part_v.p, kReduceBlocks, stream);
+        FinalizeArgs fe{};
+        fe.n = 1;
+        fe.item[0] = {part_v.p, kReduceBlocks, S_PW_ERR2};
+        launch_finalize(fe, scal.p, stream);
+        allreduce_slots(this, S_PW_ERR2, 1);
+    };
+    // One rank: the ten iterations between two stopping tests are one graph launch (about 50 kernels; enqueued one by one the
+    // launches of config 5 leave 0.2 ms of every 1.45 ms iteration idle, on config 3 the iteration is launch-bound altogether).
+    hipGraphExec_t block = nullptr;
+    if (use_graph && max_iter >= 10) {
+        auto it = graphs.find(kPowerBlockKey);
+        if (it != graphs.end()) {
+            block = it->second;
+        } else {
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < 10; ++k) one_iteration();
+            error_terms();
+            HIP_CHECK(hipStreamEndCapture(stream, &g));
+            HIP_CHECK(hipGraphInstantiate(&block, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            graphs[kPowerBlockKey] = block;
+        }
+    }
+    for (int i = 1; i <= max_iter; ++i) {
+        if (block && i % 10 == 1 && i + 9 <= max_iter) {
+            HIP_CHECK(hipGraphLaunch(block, stream));
+            i += 9;
+        } else {
+            one_iteration();
+            if (i % 10 == 0) error_terms();
+        }
         if (i % 10 == 0) {
-            launch_pw_err(z, q, m_loc, scal.p, part_v.p, kReduceBlocks, stream);
-            FinalizeArgs fe{};
-            fe.n = 1;
-            fe.item[0] = {part_v.p, kReduceBlocks, S_PW_ERR2};
-            launch_finalize(fe, scal.p, stream);
-            allreduce_slots(this, S_PW_ERR2, 1);
             fetch_scalars();
             lambda = scal_h[S_PW_QZ];
             const double err = std::sqrt(scal_h[S_PW_ERR2]);

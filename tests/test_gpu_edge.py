@@ -227,3 +227,28 @@ def test_duplicate_and_unsorted_entries(gpu):
     r_pre = raw.solve(hprlp.Parameters(stop_tol=1e-6, use_presolve=True, max_iter=200000))
     assert r_pre.status == "OPTIMAL" and abs(r_pre.primal_obj - lp["obj_star"]) <= 1e-5 * (1 + abs(lp["obj_star"]))
     raw.free(); canon.free()
+
+
+@pytest.mark.parametrize("nnz_per_row", [3, 9])
+def test_out_of_range_column_index_is_refused(gpu, nnz_per_row):
+    """The kernels index without bounds checks.  create_model_from_arrays refuses a column index outside [0, n) (NULL model);
+    a caller that fills an LP_info_cpu itself (the C ABI allows it: reference include/structs.h:243-252) gets past that, so the
+    solver checks again before it launches on the matrix: on the host for small matrices, by a pass over the uploaded copy above
+    4e6 entries (hpr-lp-c_amd/csrc/solver.cpp: DeviceMatrix::upload)."""
+    m = 500_000
+    n = m
+    rng = np.random.default_rng(1)
+    nnz = m * nnz_per_row     # 1.5e6: host check; 4.5e6: device check
+    rp = np.arange(0, nnz + 1, nnz_per_row, dtype=np.int32)
+    ci = np.sort(rng.integers(0, n, size=(m, nnz_per_row)), axis=1).astype(np.int32).ravel()
+    v = np.ones(nnz)
+    args = (np.zeros(m), np.ones(m), np.zeros(n), np.ones(n), np.ones(n))
+    bad = ci.copy()
+    bad[nnz // 2] = n + 7
+    with pytest.raises(Exception):
+        hprlp.Model.from_csr(m, n, rp, bad, v, *args)
+    model = hprlp.Model.from_csr(m, n, rp, ci, v, *args)
+    model._ptr.contents.A.contents.colIndex[nnz // 2] = n + 7      # the model's own copy, behind the library's back
+    with pytest.raises(RuntimeError, match="column index out of range"):
+        hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    model.free()

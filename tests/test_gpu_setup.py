@@ -134,3 +134,19 @@ def test_device_tiled_build_equals_host_build(gpu, case):
     assert dev[0] & 3 == 3 and host[0] & 3 == 3
     assert np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2])
     model.free()
+
+
+def test_power_start_vector_formed_on_the_device_for_long_vectors(gpu):
+    """Above 1e6 rows the power iteration's start vector is generated by a kernel (kernels.hip: k_pw_start) instead of on the host
+    (host_model.cpp: power_start_vector, what the oracle uses): same counter generator and formula, log / cos from the device
+    library.  Same iteration count and lambda_max to 1e-10 as with the host-made vector."""
+    m = n = 1_200_000
+    lp = bh.banded_lp(m, n, 4, 5000)
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    s.scale()
+    lam_d, it_d = s.power_iteration()
+    lam_h, it_h = with_env({"HPRLP_HOST_POWER_START": "1"}, lambda: s.power_iteration())
+    assert it_d == it_h and it_d >= 10
+    assert abs(lam_d - lam_h) <= 1e-10 * lam_h
+    s.close(); model.free()
