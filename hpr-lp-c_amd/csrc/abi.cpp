@@ -681,7 +681,7 @@ extern "C" int hprlp_solver_set_vector(hprlp_solver *h, const char *name, const 
             HIP_CHECK(hipMemcpy(v.p, in, sizeof(double) * v.n, hipMemcpyHostToDevice));
         }
     }
-    if (v.p == h->s.l.p || v.p == h->s.u.p) {  // the bound codes follow the arrays
+    if (v.p == h->s.l.p || v.p == h->s.u.p || v.p == h->s.AL.p || v.p == h->s.AU.p) {  // the bound codes follow the arrays
         h->s.refresh_bound_codes();
         HIP_CHECK(hipStreamSynchronize(h->s.stream));
     }
@@ -818,7 +818,7 @@ extern "C" int hprlp_solver_time_iterations(hprlp_solver *h, int warmup, int ste
         for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
         // the solver's own normal pair (with the multi-GPU overlap when it is on): events before / between / after the halves
         HIP_CHECK(hipEventRecord(e0, s.stream));
-        for (int i = 0; i < steps; ++i) s.launch_normal_pair(i + 1 < steps, &ev[3 * static_cast<size_t>(i)]);
+        for (int i = 0; i < steps; ++i) s.launch_normal_pair(i + 1 < steps, &ev[3 * static_cast<size_t>(i)], s.x_mode_of(i, steps));
         HIP_CHECK(hipEventRecord(e1, s.stream));
         HIP_CHECK(hipEventSynchronize(e1));
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));

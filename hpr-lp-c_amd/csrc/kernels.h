@@ -103,7 +103,14 @@ struct XHalfArgs {
     // bound 0 or -inf, upper bound +inf -- are constants of the code and cost no 8-byte load (LPs have l = 0, u = +inf on
     // most columns: 16 of the x-half's 56 bytes per column).  nullptr: always load both.
     const unsigned char *lu_code = nullptr;
+    // Normal x-halves of a matrix with a tiled copy, inside a run of normal iterations (Solver::run_normal): x is
+    // f2' * x_hat + f1' * last_x of values the previous x-half stored and this one reads anyway, so it need not travel through
+    // memory between them.  kXRebuild: this launch forms its x from x_hat and last_x with the previous iteration's Halpern
+    // factors (bit for bit the value the previous launch would have stored); kXNoStore: this launch does not store x (the next
+    // one rebuilds it).  The first launch of a run reads x, the last one stores it: everybody else finds x in memory.
+    int x_mode = 0;
 };
+constexpr int kXRebuild = 1, kXNoStore = 2;
 // bit 0: l[j] must be loaded (neither -inf nor +0.0); bit 1: u[j] must be loaded (not +inf); bit 2: l[j] is +0.0
 constexpr unsigned kLoadL = 1u, kLoadU = 2u, kZeroL = 4u;
 void launch_bound_codes(int n, const double *l, const double *u, unsigned char *code, hipStream_t s);
@@ -118,7 +125,13 @@ struct YHalfArgs {
     int stride;
     FarPush push;            // y's products into the remainder buffer of A^T (consumed by the next x-half)
     bool far_ready = false;  // A's remainder buffer already holds the products of xhat_full
+    // one byte per row saying which of AL[i], AU[i] the update has to READ (launch_row_codes), as lu_code for the x-half: an
+    // infinite side is a constant of the code, an equality row (AL == AU) reads one value for both.  nullptr: load both.
+    const unsigned char *row_code = nullptr;
 };
+// bit 0: AL[i] must be loaded (finite, differs from AU[i]); bit 1: AU[i] must be loaded (finite); bit 2: AL[i] == AU[i] (finite)
+constexpr unsigned kLoadLo = 1u, kLoadHi = 2u, kRowEq = 4u;
+void launch_row_codes(int m, const double *AL, const double *AU, unsigned char *code, hipStream_t s);
 
 struct FinalizeItem {
     const double *partials;

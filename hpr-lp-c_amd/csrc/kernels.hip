@@ -306,9 +306,6 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 #ifndef HPRLP_DBG_NOEPISTORE
 #define HPRLP_DBG_NOEPISTORE 0
 #endif
-#ifndef HPRLP_DBG_NOXSTORE
-#define HPRLP_DBG_NOXSTORE 0
-#endif
 #ifndef HPRLP_DBG_NOPUSHWORK
 #define HPRLP_DBG_NOPUSHWORK 0
 #endif
@@ -933,7 +930,10 @@ struct XEpi {
     double sigma, f1, f2;
     FarPush push;  // hand-off of x_hat's remainder products to the y-half (kernels.h)
     const unsigned char *lu_code;  // which bounds to read (kernels.h: XHalfArgs::lu_code), or nullptr
+    int x_mode;                    // kXRebuild / kXNoStore (kernels.h: XHalfArgs::x_mode); normal streamed variant only
+    double f1p, f2p;               // the previous iteration's Halpern factors (filled by begin(), kXRebuild)
     static constexpr bool kPublishes = true;
+    static constexpr bool kSkipsX = !CHECK && STREAMED;
     struct Row {
         double xi, ci, li, ui, lx;
     };
@@ -942,6 +942,8 @@ struct XEpi {
         sigma = ctrl->sigma;
         f1 = 1.0 / (static_cast<double>(k) + 2.0);
         f2 = 1.0 - f1;
+        f1p = 1.0 / (static_cast<double>(k - 1) + 2.0);  // (as the previous x-half formed its f1, f2)
+        f2p = 1.0 - f1p;
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->ky = k;
     }
     __device__ __forceinline__ Row load_row(int r) const {
@@ -957,7 +959,11 @@ struct XEpi {
             li = ld(l + r);
             ui = ld(u + r);
         }
-        return Row{ld(x + r), ld(c + r), li, ui, ld(last_x + r)};
+        const double lx = ld(last_x + r);
+        if constexpr (kSkipsX) {
+            if (x_mode & kXRebuild) return Row{f2p * ld(x_hat + r) + f1p * lx, ld(c + r), li, ui, lx};  // = the x the previous launch did not store
+        }
+        return Row{ld(x + r), ld(c + r), li, ui, lx};
     }
     // returns the value the half-step publishes for the other half's gather (x_hat)
     __device__ __forceinline__ double apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 3 : 1]) const {
@@ -972,10 +978,7 @@ struct XEpi {
         {
             if constexpr (STREAMED && HPRLP_EPI_NT >= 2) __builtin_nontemporal_store(xh, x_hat + r);
             else x_hat[r] = xh;
-#if HPRLP_DBG_NOXSTORE
-            if (CHECK || xn == 1.2345e-300)  // timing experiment only (results are wrong): normal x-halves do not store x
-#endif
-            {
+            if (!kSkipsX || !(x_mode & kXNoStore)) {
                 if constexpr (STREAMED && HPRLP_EPI_NT >= 1) __builtin_nontemporal_store(xn, x + r);
                 else x[r] = xn;
             }
@@ -1009,6 +1012,7 @@ struct YEpi {
     int stride;
     double fact1, fact2, hf1, hf2;
     FarPush push;  // hand-off of y's remainder products to the next x-half (kernels.h)
+    const unsigned char *row_code;  // which of AL, AU to read (kernels.h: YHalfArgs::row_code), or nullptr
     static constexpr bool kPublishes = true;
     struct Row {
         double yi, lo, hi, ly;
@@ -1022,11 +1026,19 @@ struct YEpi {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->kx = k + 1;
     }
     __device__ __forceinline__ Row load_row(int r) const {
-        if constexpr (STREAMED && HPRLP_EPI_NT >= 1)
-            return Row{__builtin_nontemporal_load(y + r), __builtin_nontemporal_load(AL + r), __builtin_nontemporal_load(AU + r),
-                       __builtin_nontemporal_load(last_y + r)};
-        else
-            return Row{y[r], AL[r], AU[r], last_y[r]};
+        constexpr bool NT = STREAMED && HPRLP_EPI_NT >= 1;
+        auto ld = [](const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+        double lo, hi;
+        if (row_code) {
+            // the same values the arrays hold, without reading the constant ones (codes are derived from the arrays: launch_row_codes)
+            const unsigned cd = NT ? __builtin_nontemporal_load(row_code + r) : row_code[r];
+            hi = (cd & kLoadHi) ? ld(AU + r) : __builtin_huge_val();
+            lo = (cd & kLoadLo) ? ld(AL + r) : ((cd & kRowEq) ? hi : -__builtin_huge_val());
+        } else {
+            lo = ld(AL + r);
+            hi = ld(AU + r);
+        }
+        return Row{ld(y + r), lo, hi, ld(last_y + r)};
     }
     // returns the value the half-step publishes for the other half's gather (y)
     __device__ __forceinline__ double apply(int r, const Row &w, const double (&s)[1], double (&acc)[CHECK ? 2 : 1]) const {
@@ -1302,7 +1314,7 @@ bool launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t
         return launch_fused(AT, e, s, a.far_ready);
     }
     if (AT.tiled.valid) {  // the tiled kernels: the row's own streams bypass the L2s (HPRLP_EPI_NT)
-        XEpi<false, true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push, a.lu_code};
+        XEpi<false, true> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push, a.lu_code, a.x_mode};
         return launch_fused(AT, e, s, a.far_ready);
     }
     XEpi<false> e{{a.y_full}, a.x, a.x_hat, a.l, a.u, a.c, a.last_x, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, a.push, a.lu_code};
@@ -1311,14 +1323,14 @@ bool launch_x_half(const CsrDev &AT, const XHalfArgs &a, bool check, hipStream_t
 
 bool launch_y_half(const CsrDev &A, const YHalfArgs &a, bool check, hipStream_t s) {
     if (check) {
-        YEpi<true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, a.y_bar, a.y_obj, a.y_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, 0, a.push};
+        YEpi<true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, a.y_bar, a.y_obj, a.y_temp, a.ctrl, a.partials, a.stride, 0, 0, 0, 0, a.push, a.row_code};
         return launch_fused(A, e, s, a.far_ready);
     }
     if (A.tiled.valid) {
-        YEpi<false, true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, a.push};
+        YEpi<false, true> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, a.push, a.row_code};
         return launch_fused(A, e, s, a.far_ready);
     }
-    YEpi<false> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, a.push};
+    YEpi<false> e{{a.xhat_full}, a.y, a.AL, a.AU, a.last_y, nullptr, nullptr, nullptr, a.ctrl, nullptr, 0, 0, 0, 0, 0, a.push, a.row_code};
     return launch_fused(A, e, s, a.far_ready);
 }
 
@@ -1793,6 +1805,20 @@ __global__ void __launch_bounds__(kThreads) k_bound_codes(int n, const double *l
 }
 void launch_bound_codes(int n, const double *l, const double *u, unsigned char *code, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_bound_codes, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, s, n, l, u, code);
+}
+
+// which of AL[i], AU[i] the y-half has to read (kernels.h: YHalfArgs::row_code); derived from the arrays as they are on the device
+__global__ void __launch_bounds__(kThreads) k_row_codes(int m, const double *AL, const double *AU, unsigned char *code) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= m) return;
+    const double lo = AL[i], hi = AU[i];
+    const bool lo_minf = lo == -__builtin_huge_val(), hi_pinf = hi == __builtin_huge_val();
+    // (equal as bit patterns: the coded lower bound must be the stored one, -0.0 against +0.0 included)
+    const bool eq = !hi_pinf && __double_as_longlong(lo) == __double_as_longlong(hi);
+    code[i] = static_cast<unsigned char>((lo_minf || eq ? 0u : kLoadLo) | (hi_pinf ? 0u : kLoadHi) | (eq ? kRowEq : 0u));
+}
+void launch_row_codes(int m, const double *AL, const double *AU, unsigned char *code, hipStream_t s) {
+    if (m > 0) hipLaunchKernelGGL(k_row_codes, dim3((m + kThreads - 1) / kThreads), dim3(kThreads), 0, s, m, AL, AU, code);
 }
 
 // ------------------------------------------------------------------------------------------------

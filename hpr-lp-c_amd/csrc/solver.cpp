@@ -1054,9 +1054,15 @@ void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
 
 void Solver::refresh_bound_codes() {
     static const bool off = std::getenv("HPRLP_NO_BOUND_CODES") != nullptr;  // A/B runs: always read l and u
-    if (off || n_loc <= 0) return;
-    if (lu_code.n != static_cast<size_t>(n_loc)) lu_code.alloc(static_cast<size_t>(n_loc));
-    launch_bound_codes(n_loc, l.p, u.p, lu_code.p, stream);
+    if (off) return;
+    if (n_loc > 0) {
+        if (lu_code.n != static_cast<size_t>(n_loc)) lu_code.alloc(static_cast<size_t>(n_loc));
+        launch_bound_codes(n_loc, l.p, u.p, lu_code.p, stream);
+    }
+    if (m_loc > 0) {
+        if (row_code.n != static_cast<size_t>(m_loc)) row_code.alloc(static_cast<size_t>(m_loc));
+        launch_row_codes(m_loc, AL.p, AU.p, row_code.p, stream);
+    }
 }
 
 void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
@@ -1121,10 +1127,18 @@ FarPush Solver::push_into(const DeviceMatrix &consumer, const DeviceMatrix &prod
     return far_push_of(consumer.view);
 }
 
-void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev) {
+int Solver::x_mode_of(int i, int count) const {
+    static const bool off = std::getenv("HPRLP_STORE_X") != nullptr;  // A/B runs: every x-half reads and stores x
+    if (off || overlap_enabled || !AT.view.tiled.valid) return 0;
+    return (i > 0 ? kXRebuild : 0) | (i + 1 < count ? kXNoStore : 0);
+}
+
+void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev, int x_mode) {
     XHalfArgs xa{gy.p, x.p, x_hat, l.p, u.p, c.p, last_x.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};
     xa.lu_code = lu_code.p;
+    xa.x_mode = x_mode;
     YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, nullptr, nullptr, nullptr, ctrl.p, nullptr, 0};  // (push / far_ready set below)
+    ya.row_code = row_code.p;
     if (ev) HIP_CHECK(hipEventRecord(ev[0], stream));
     if (!overlap_enabled) {
         xa.push = push_into(A, AT);
@@ -1188,6 +1202,7 @@ void Solver::step(bool check) {
     far_A_ready = launch_x_half(AT.view, xa, true, stream);
     gather(gxh.p, false);
     YHalfArgs ya{gxh.p, y, AL.p, AU.p, last_y.p, y_bar, y_obj.p, y_temp.p, ctrl.p, part_y.p, stride_y};
+    ya.row_code = row_code.p;
     ya.push = push_into(AT, A);
     ya.far_ready = far_A_ready;
     far_AT_ready = launch_y_half(A.view, ya, true, stream);
@@ -1212,7 +1227,7 @@ hipGraphExec_t Solver::graph_for(int len) {
     // handed over) and ends with both buffers handed over, whatever ran before it
     far_AT_ready = false;
     HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < len; ++i) launch_normal_pair();
+    for (int i = 0; i < len; ++i) launch_normal_pair(false, nullptr, x_mode_of(i, len));
     HIP_CHECK(hipStreamEndCapture(stream, &g));
     graph_end_A = far_A_ready;
     graph_end_AT = far_AT_ready;
@@ -1234,7 +1249,7 @@ void Solver::run_normal(int count) {
         return;
     }
     if (!use_graph) {
-        for (int i = 0; i < count; ++i) launch_normal_pair(i + 1 < count);
+        for (int i = 0; i < count; ++i) launch_normal_pair(i + 1 < count, nullptr, x_mode_of(i, count));
         return;
     }
     while (count > 0) {

@@ -114,6 +114,7 @@ struct Solver {
     FarPush push_into(const DeviceMatrix &consumer, const DeviceMatrix &producer) const;  // called by setup() for a large matrix that failed the tiling test
     HaloPlan halo_m, halo_n;  // exchange of length-m / length-n gathered vectors (multi-GPU only)
     DBuf<double> AL, AU, l, u, c, row_norm, col_norm;
+    DBuf<unsigned char> row_code;  // per row: which of AL, AU the y-half reads (kernels.h); follows AL / AU (refresh_bound_codes)
     DBuf<unsigned char> lu_code;  // per column: which of l, u the x-half reads (kernels.h); follows l / u (refresh_bound_codes)
     void refresh_bound_codes();
     // local work vectors
@@ -193,7 +194,10 @@ struct Solver {
     // One normal iteration.  ev (optional, 3 events): recorded before the x-half, between the halves, after the y-half.
     // more_follow (multi-GPU overlap only): the caller launches another normal pair next, so the exchange of y may stay
     // in flight behind the local part of that pair's x-half; otherwise the gathered y is complete on return.
-    void launch_normal_pair(bool more_follow = false, hipEvent_t *ev = nullptr);
+    void launch_normal_pair(bool more_follow = false, hipEvent_t *ev = nullptr, int x_mode = 0);
+    // kernels.h XHalfArgs::x_mode of iteration `i` of a run of `count` normal iterations enqueued back to back (0 where the
+    // x-half's epilogue has no such mode: no tiled copy, split shards)
+    int x_mode_of(int i, int count) const;
 
    private:
     void alloc_work();
