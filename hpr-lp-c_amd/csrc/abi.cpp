@@ -550,6 +550,14 @@ extern "C" int hprlp_solver_init(hprlp_solver *h, double sigma, double lambda_ma
     GUARD_END(-1)
 }
 
+extern "C" int hprlp_solver_reset_iterates(hprlp_solver *h) {
+    GUARD_BEGIN
+    if (!h) throw std::runtime_error("null solver");
+    h->s.reset_iterates();
+    return 0;
+    GUARD_END(-1)
+}
+
 extern "C" int hprlp_solver_iterate(hprlp_solver *h, int normal, int then_check) {
     GUARD_BEGIN
     h->s.run_normal(normal);

@@ -1065,6 +1065,25 @@ void Solver::refresh_bound_codes() {
     }
 }
 
+// Back to the state of a fresh solver after scale() and power_iteration(): every iterate and work vector zero, nothing handed over.
+// (bench.py: the timed iterations and the solve to tolerance of a multi-GPU run use ONE solver -- a second one would need a
+// second set of communicators.)  Call init_iteration_state() / set_sigma_lambda() afterwards, as after create.
+void Solver::reset_iterates() {
+    if (y_exchange_pending) throw std::runtime_error("reset_iterates: an exchange is still pending");
+    invalidate_far();
+    auto zero = [&](double *p, size_t n) {
+        if (p && n > 0) HIP_CHECK(hipMemsetAsync(p, 0, sizeof(double) * n, stream));
+    };
+    zero(x.p, x.n); zero(last_x.p, last_x.n); zero(z_bar.p, z_bar.n);
+    zero(last_y.p, last_y.n); zero(y_obj.p, y_obj.n); zero(y_temp.p, y_temp.n);
+    zero(gy.p, gy.n); zero(gyb.p, gyb.n); zero(gsm.p, gsm.n);
+    zero(gxh.p, gxh.n); zero(gxb.p, gxb.n); zero(gxt.p, gxt.n); zero(gsn.p, gsn.n);
+    zero(sm1.p, sm1.n); zero(sn1.p, sn1.n);
+    zero(scal.p, scal.n);
+    HIP_CHECK(hipMemsetAsync(ctrl.p, 0, sizeof(Ctrl), stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 void Solver::init_iteration_state() {  // reference src/HPRLP.cu:154-167
     finish_tiling();
     invalidate_far();

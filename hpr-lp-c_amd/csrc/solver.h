@@ -160,6 +160,7 @@ struct Solver {
     double power_iteration(int max_iter, double tol, int *iters);   // src/power_iteration.cu:20-119
     void init_iteration_state();                                    // src/HPRLP.cu:154-167
     void set_sigma_lambda(double sigma_, double lambda_, bool reset_k);
+    void reset_iterates();                                          // all iterates back to zero (as after create + scale + power iteration)
     void step(bool check);                                          // one HPR iteration
     void run_normal(int count);                                     // count normal iterations (graph replay)
     void fetch_scalars();

@@ -491,6 +491,13 @@ class Solver:
     def init(self, sigma=-1.0, lambda_max=1.0):
         self._chk(lib().hprlp_solver_init(self.h, sigma, lambda_max))
 
+    def reset(self):
+        """All iterates back to zero (hprlp_solver_reset_iterates); follow with init()."""
+        L = lib()
+        L.hprlp_solver_reset_iterates.argtypes = [C.c_void_p]
+        L.hprlp_solver_reset_iterates.restype = C.c_int
+        self._chk(L.hprlp_solver_reset_iterates(self.h))
+
     def iterate(self, normal, then_check=False):
         self._chk(lib().hprlp_solver_iterate(self.h, int(normal), int(bool(then_check))))
 

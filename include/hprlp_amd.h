@@ -48,6 +48,9 @@ int hprlp_solver_scale(hprlp_solver *s);
 double hprlp_solver_power_iteration(hprlp_solver *s, int max_iter, double tol, int *iters_out);
 /* sigma_0, Halpern reset (reference src/HPRLP.cu:154-167).  sigma<=0: norm_b/norm_c rule. */
 int hprlp_solver_init(hprlp_solver *s, double sigma, double lambda_max);
+/* All iterates and work vectors back to zero -- the state after create + scale + power iteration (the reference starts every
+ * solve from zero vectors, src/preprocess.cu:41-101 allocate_memory); follow with hprlp_solver_init.  Collective-free. */
+int hprlp_solver_reset_iterates(hprlp_solver *s);
 /* `normal` normal iterations then, if then_check, one check-variant iteration
  * (reference update_zx_*_gpu + update_y_*_gpu, src/main_iterate.cu:422-481) */
 int hprlp_solver_iterate(hprlp_solver *s, int normal, int then_check);

@@ -42,3 +42,35 @@ def test_planted_lp_matches_oracle(gpu, m, n, nnz, seed):
     # same schedule => same iteration count unless a thresholded decision forks (FP64 reduction order)
     assert abs(res.iter - ref["iter"]) <= 0.2 * ref["iter"] + 150
     model.free()
+
+
+def test_reset_iterates_gives_the_run_of_a_fresh_solver(gpu):
+    """hprlp_solver_reset_iterates: after some iterations (normal and check variants) the solver is set back to zero iterates;
+    the run that follows is the run of a fresh solver, bit for bit (bench.py uses this for the solve to tolerance of a
+    multi-GPU run, whose solver also did the timed iterations)."""
+    lp = lpgen.planted_lp(2500, 4000, 30000, 21)
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+
+    def prepared():
+        s = hprlp.Solver(model, prm)
+        s.scale()
+        lam, _ = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        return s, lam
+
+    fresh, lam = prepared()
+    r0 = fresh.run()
+    fresh.close()
+    used, lam2 = prepared()
+    assert lam2 == lam
+    used.iterate(37, True)
+    used.iterate(150, True)
+    used.residuals(189, True)
+    used.reset()
+    used.init(-1.0, lam * 1.01)
+    r1 = used.run()
+    used.close()
+    assert r1.status == r0.status == "OPTIMAL" and r1.iter == r0.iter
+    assert r1.primal_obj == r0.primal_obj and np.array_equal(r1.x, r0.x) and np.array_equal(r1.y, r0.y)
+    model.free()

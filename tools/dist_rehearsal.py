@@ -57,8 +57,11 @@ def main():
             o = dict(rank=rank, create_s=round(t_create, 2), scale_power_s=round(t_prep, 2), power_its=it,
                      ms_per_iteration_all_ranks_on_one_gpu=round(1e3 * t_it / args.steps, 3), info=s.dist_info(), tiled=s.info()["tiled"])
             if args.solve:
+                s.reset()                      # as bench.py does at N > 1: the solver of the timed iterations, back to zero iterates
+                s.init(-1.0, lam * 1.01)
+                t = time.time()
                 r = s.run()
-                o.update(status=r.status, iters=r.iter, obj=r.primal_obj)
+                o.update(status=r.status, iters=r.iter, obj=r.primal_obj, kkt=r.residuals, loop_s=round(time.time() - t, 3))
             out[rank] = o
             s.close()
         except Exception as e:  # noqa: BLE001
