@@ -252,3 +252,49 @@ def test_out_of_range_column_index_is_refused(gpu, nnz_per_row):
     with pytest.raises(RuntimeError, match="column index out of range"):
         hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
     model.free()
+
+
+def _csr_case(m, n, rp, ci, v, AL, AU, l, u, c):
+    f = lambda a: np.asarray(a, float)
+    return (m, n, np.asarray(rp, np.int32), np.asarray(ci, np.int32), f(v), f(AL), f(AU), f(l), f(u), f(c))
+
+
+DEGENERATE = {
+    # one dense row over 5000 columns (a single vector-mode row in A, 5000 one-entry rows in A^T)
+    "one_row": _csr_case(1, 5000, [0, 5000], np.arange(5000), np.ones(5000), [1.0], [1.0], np.zeros(5000), np.ones(5000),
+                         np.arange(1, 5001) / 5000),
+    # zero objective: a feasibility problem
+    "zero_objective": _csr_case(2, 3, [0, 2, 4], [0, 1, 1, 2], [1, 1, 1, 1], [1, 1], [1, 1], [0, 0, 0], [1, 1, 1], [0, 0, 0]),
+    # fixed variables (l == u) and a redundant row
+    "fixed_variables": _csr_case(2, 3, [0, 3, 6], [0, 1, 2, 0, 1, 2], [1, 2, 3, 2, 4, 6], [-INF, -INF], [10, 20], [1, 1, 0], [1, 1, 5],
+                                 [-1, -1, -1]),
+    # infeasible (x >= 2 and x <= 1) and unbounded (min -x, x - y <= 5, both free above): no certificate in HPR-LP, the
+    # iteration limit ends the run -- as in the reference (src/main_iterate.cu:406-420 knows OPTIMAL / ITER_LIMIT / TIME_LIMIT only)
+    "infeasible": _csr_case(2, 1, [0, 1, 2], [0, 0], [1, 1], [2, -INF], [INF, 1], [0], [10], [1]),
+    "unbounded": _csr_case(1, 2, [0, 2], [0, 1], [1, -1], [-INF], [5], [0, 0], [INF, INF], [-1, 0]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(DEGENERATE))
+def test_degenerate_lps_follow_the_oracle(gpu, name):
+    """Shapes and LPs at the edge of what the iteration is meant for: same status, iteration count and objective as the oracle's
+    restatement of the reference loop; with presolve on the answer is the same optimum where there is one."""
+    case = DEGENERATE[name]
+    m, n = case[0], case[1]
+    model = hprlp.Model.from_csr(*case)
+    r = model.solve(hprlp.Parameters(stop_tol=1e-8, max_iter=3000, use_presolve=False))
+    ref = O.solve(*case, params=O.Params.default(stop_tol=1e-8, max_iter=3000))
+    assert r.status == ref["status"] and r.iter == ref["iter"]
+    assert r.primal_obj == pytest.approx(ref["primal_obj"], rel=1e-9, abs=1e-12)
+    assert (r.status == "ITER_LIMIT") == (name in ("infeasible", "unbounded"))
+    if r.status == "OPTIMAL":
+        rp = model.solve(hprlp.Parameters(stop_tol=1e-8, max_iter=3000, use_presolve=True))
+        assert rp.status == "OPTIMAL" and abs(rp.primal_obj - r.primal_obj) <= 1e-6 * (1 + abs(r.primal_obj))
+    model.free()
+
+
+def test_matrix_without_entries_is_refused_like_the_reference(gpu):
+    """create_model_from_arrays with nnz <= 0 returns NULL (reference src/HPRLP.cu:329-332)."""
+    with pytest.raises(Exception):
+        hprlp.Model.from_csr(3, 4, np.zeros(4, np.int32), np.zeros(0, np.int32), np.zeros(0), [-1, 0, -INF], [1, 0, 2], [0, -1, 0, 2],
+                             [1, 1, 5, 3], [1, -2, 0, 3])
