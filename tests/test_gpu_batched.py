@@ -189,3 +189,29 @@ def test_config4_full_size_against_oracle_and_single_solves(gpu):
         assert s.status == "OPTIMAL", (k, s.status)
         assert abs(s.primal_obj - r["primal_obj"][k]) <= 10 * tol * (1 + abs(s.primal_obj)), (k, s.primal_obj, r["primal_obj"][k])
         mk.free()
+
+
+def test_batch_with_an_infeasible_member_and_a_batch_of_one(gpu):
+    """Members are independent: an infeasible one runs into the iteration limit (HPR-LP has no certificate) while its neighbours
+    stop at the tolerance, with the oracle's statuses and stopping iterations; B = 1 is the single member's own batch."""
+    g = json.load(open(os.path.join(HERE, "golden", "known_lps.json")))
+    rp, ci, v = g[0]["rowptr"], g[0]["colind"], [float(t) for t in g[0]["values"]]
+    model = hprlp.Model.from_csr(2, 2, rp, ci, v, [-INF, -INF], [10, 12], [0, 0], [INF, INF], [-3, -5])
+    B = 3
+    Cm = np.array([[-3.0, -5.0]] * B).T
+    AU = np.array([[10.0, 12.0], [10.0, 12.0], [10.0, 12.0]]).T
+    AL = np.full((2, B), -INF)
+    L = np.zeros((2, B)); U = np.full((2, B), INF)
+    AL[0, 1] = 11.0          # member 1: row 0 must be >= 11 ...
+    U[:, 1] = 1.0            # ... with both variables at most 1 (the row reaches 3)
+    prm = hprlp.Parameters(stop_tol=1e-6, max_iter=3000, use_presolve=False)
+    r = hprlp.solve_batched(model, Cm, AL, AU, L, U, [0.0, 0.0, 7.0], prm)
+    ref = O.solve_batched(2, 2, rp, ci, v, B, Cm.T.ravel(), AL.T.ravel(), AU.T.ravel(), L.T.ravel(), U.T.ravel(), [0.0, 0.0, 7.0],
+                          params=O.Params.default(stop_tol=1e-6, max_iter=3000))
+    assert r["status"] == ref["status"] == ["OPTIMAL", "ITER_LIMIT", "OPTIMAL"]
+    assert list(r["iter"]) == list(ref["iter"]) and r["iter"][1] == 3000
+    assert abs(r["primal_obj"][0] + 26.4) < 1e-4 and abs(r["primal_obj"][2] - (7.0 - 26.4)) < 1e-4
+    one = hprlp.solve_batched(model, Cm[:, :1], AL[:, :1], AU[:, :1], L[:, :1], U[:, :1], [0.0], prm)
+    assert one["status"] == ["OPTIMAL"] and one["iter"][0] == r["iter"][0]
+    np.testing.assert_allclose(one["x"][:, 0], r["x"][:, 0], rtol=0, atol=1e-12)
+    model.free()
