@@ -133,13 +133,28 @@ def banded_lp(m, n, per_row, band, seed=5):
 
 
 def banded_lp_shard(m, n, per_row, band, rank, world, dist, seed=5):
-    """This rank's shard of the SAME planted LP, built from its own rows only (hpr-lp-c_amd/shard.py): the rows of A^T
-    arrive through one all-to-all; no rank generates or holds the whole matrix."""
+    """This rank's shard of the SAME planted LP without any rank generating or holding the whole matrix:
+    its rows of A from the generator, its rows of A^T by sweeping the generator over ALL rows and keeping the columns it owns
+    (hpr-lp-c_amd/shard.py: transposed_rows_generated -- the generator is a pure function of (seed, row); round 2's all-to-all of
+    2e8 triples over gloo + argsort is kept in shard.py as the general form and as the test's cross-check).  Phase wall times go
+    to stderr so that a time-limit kill names its phase."""
     from scipy import sparse
+    t0 = time.time()
+    threads = max(1, host_cpu_share() // max(world, 1))
+
+    def phase(what):
+        nonlocal t0
+        import resource
+        log(f"[bench] rank {rank}: shard assembly: {what} {time.time() - t0:.2f}s "
+            f"(peak host RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.2f} GB, {threads} threads)")
+        t0 = time.time()
+
     _, row_off, m_loc = SH.partition(m, world, rank)
     _, col_off, n_loc = SH.partition(n, world, rank)
-    rp, ci, v = gen_banded(m, n, per_row, band, seed, row0=row_off, rows=m_loc)
-    trp, tci, tv = SH.transpose_rows_distributed(m, n, row_off, rp, ci, v, rank, world, dist)
+    rp, ci, v = gen_banded(m, n, per_row, band, seed, row0=row_off, rows=m_loc, threads=threads)
+    phase(f"rows [{row_off}, {row_off + m_loc}) of A generated")
+    trp, tci, tv = SH.transposed_rows_generated(H, m, n, per_row, band, seed, rank, world, threads=threads)
+    phase(f"columns [{col_off}, {col_off + n_loc}) of A (rows of A^T) kept from a sweep over all {m} rows")
     p = planted_vectors(m, n, seed)
     A_loc = sparse.csr_matrix((v, ci, rp), shape=(m_loc, n), copy=False)
     AT_loc = sparse.csr_matrix((tv, tci, trp), shape=(n_loc, m), copy=False)
@@ -148,11 +163,15 @@ def banded_lp_shard(m, n, per_row, band, rank, world, dist, seed=5):
     AL = np.where(p["is_eq"][rs], b, -np.inf)
     AU = np.where(p["is_eq"][rs] | p["active"][rs], b, b + p["slack"][rs])
     c = AT_loc @ p["y"] + p["z"][cs]
-    import torch
-    obj = torch.tensor([float(c @ p["x"][cs])], dtype=torch.float64)
-    dist.all_reduce(obj)
+    obj_loc = float(c @ p["x"][cs])
+    if dist is not None and world > 1:
+        import torch
+        obj = torch.tensor([obj_loc], dtype=torch.float64)
+        dist.all_reduce(obj)
+        obj_loc = float(obj[0])
     shard = SH.ShardArrays(H, m, n, rank, world, rp, ci, v, trp, tci, tv, AL, AU, p["l"][cs], p["u"][cs], c)
-    return shard, float(obj[0]), len(v)
+    phase("planted vectors, b = A x, c = A^T y + z")
+    return shard, obj_loc, len(v)
 
 
 def bytes_per_iteration(m, n, nnz):

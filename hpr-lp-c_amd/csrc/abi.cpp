@@ -137,6 +137,7 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
     HPRLP_parameters dflt;
     const HPRLP_parameters *p = param ? param : &dflt;
     if (!p->use_presolve) return HPRLP_main_solve(model, p);
+    const auto t_entry = time_now();  // (the fallback below charges everything since here against the caller's time limit)
 
     // The presolver indexes its work arrays by the model's column indices and trusts rowPtr: a hand-built
     // LP_info_cpu (create_model_from_arrays validates, a caller-filled struct does not) must be refused here, before
@@ -246,14 +247,20 @@ extern "C" HPRLP_results solve(const LP_info_cpu *model, const HPRLP_parameters 
             if (err > 100.0 * p->stop_tol && err > 1e-3) {
                 std::cout << "Postsolved solution is far from the original model's KKT conditions; solving the original model" << std::endl;
                 std::free(r.x); std::free(r.y); std::free(r.z);
-                // the caller's time limit covers presolve + the reduced solve + this one; so do the reported times and counts
-                const double spent = pre.stats().seconds + r.time;
+                // the caller's time limit and iteration limit cover presolve + the reduced solve (its set-up and scaling
+                // included: wall clock since entry) + this one; so do the reported times and counts
+                const double spent = time_since(t_entry);
                 const int it_first = r.iter;
                 HPRLP_parameters p2 = *p;
                 p2.time_limit = std::max(p->time_limit - spent, 0.0);
+                p2.max_iter = std::max(p->max_iter - it_first, 0);
                 HPRLP_results r2 = HPRLP_main_solve(model, &p2);
-                r2.time += spent; r2.time4 += spent; r2.time6 += spent; r2.time8 += spent;
-                r2.iter += it_first; r2.iter4 += it_first; r2.iter6 += it_first; r2.iter8 += it_first;
+                if (std::strcmp(r2.status, "ERROR") != 0) {
+                    // iter4/6/8 of a tolerance the second solve never reached are back-filled with its final count
+                    // (reference src/HPRLP.cu:248-253): offset like `iter`, so they stay "<= iter"
+                    r2.time += spent; r2.time4 += spent; r2.time6 += spent; r2.time8 += spent;
+                    r2.iter += it_first; r2.iter4 += it_first; r2.iter6 += it_first; r2.iter8 += it_first;
+                }
                 std::cout << "Fallback solve: reported time and iterations include presolve and the reduced solve (" << spent
                           << " s, " << it_first << " iterations)" << std::endl;
                 return r2;
@@ -360,6 +367,10 @@ extern "C" void hprlp_local_group_destroy(hprlp_local_group *h) {
 // stream than the collectives of the check iterations, and one RCCL communicator must not be driven from two streams.
 static void make_exchange_comm(hprlp_solver *h, int rank, int size, const void *unique_id, int id_bytes, int device) {
     if (!unique_id || id_bytes < 256) return;
+    // a launcher that padded ONE id to 256 bytes: bytes 128..255 hold no id -- single communicator (the documented fallback)
+    bool any = false;
+    for (int k = 128; k < 256; ++k) any = any || static_cast<const unsigned char *>(unique_id)[k] != 0;
+    if (!any) return;
     h->xcomm = make_rccl_comm(rank, size, static_cast<const char *>(unique_id) + 128, 128, device);
     h->s.xcomm = h->xcomm;
 }

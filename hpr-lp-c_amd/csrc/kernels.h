@@ -41,6 +41,8 @@ enum Slot : int {
     S_NC2 = 15,    // |c|^2
     S_TMP0 = 16,
     S_TMP1 = 17,
+    S_SMALL_PW_LAMBDA = 18,  // single-launch power iteration (small.hip): lambda ...
+    S_SMALL_PW_ITERS = 19,   // ... and the iteration it stopped at (0: the kernel did not run)
 };
 
 // Row-block descriptor: one per wave.  {first row, number of rows, first nonzero, nonzero count}.

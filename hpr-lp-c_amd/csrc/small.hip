@@ -328,12 +328,14 @@ template <int KMAX, int R>
 void launch_power_kr(const SmallArgs &a, const double *z0, int max_iter, double tol, double *out, hipStream_t s) {
     const int K = (a.nnz + NT - 1) / NT;
     hipLaunchKernelGGL((k_small_power<KMAX, R>), dim3(1), dim3(NT), 0, s, a, K, z0, max_iter, tol, out);
+    HIP_CHECK(hipGetLastError());  // (the <12, 2> instance holds about 135 KB of static LDS: a refused launch must not pass silently)
 }
 
 template <int KMAX, int R>
 void launch_kr(const SmallArgs &a, int count, hipStream_t s) {
     const int K = (a.nnz + NT - 1) / NT;
     hipLaunchKernelGGL((k_small_iterations<KMAX, R>), dim3(1), dim3(NT), 0, s, a, K, count);
+    HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace

@@ -333,6 +333,12 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     if (!As || As->row != m || As->col != n) throw std::runtime_error("model matrix dimensions inconsistent");
     const long nnz = As->numElements;
     PhaseTimer pt;
+    // choose_sb_rows() reads rowPtr / colIndex on the host before upload() has validated them: refuse a malformed row
+    // pointer array here (upload() repeats the monotonicity test and checks the column range)
+    if (!As->rowPtr || !As->colIndex || !As->value) throw std::runtime_error("model matrix arrays missing");
+    if (As->rowPtr[0] != 0 || As->rowPtr[m] != nnz) throw std::runtime_error("row pointer array does not span the nonzeros");
+    for (int i = 0; i < m; ++i)
+        if (As->rowPtr[i + 1] < As->rowPtr[i]) throw std::runtime_error("row pointer array is not monotone");
     choose_sb_rows(model);
     A.upload(m, n, As->rowPtr, As->colIndex, As->value);
     pt.tick("A upload total");
@@ -508,8 +514,11 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
         if (len < 4) continue;
         // an eighth of the entries off either end (at least one: a 16-entry row of config 5's kind carries one far entry),
         // the span of the rest scaled back to the whole row
+        // (rows need not be sorted by column: the span is |difference|, an unsorted row only makes the estimate coarser,
+        // never negative -- a negative span used to pass the `ratio <= most` test below)
         const int cut = std::max(1, len / 8);
-        const long inner = static_cast<long>(As->colIndex[e - 1 - cut]) - As->colIndex[b + cut];
+        const long ia = std::min<long>(std::max<long>(static_cast<long>(e) - 1 - cut, b), nnz - 1), ib = std::min<long>(static_cast<long>(b) + cut, nnz - 1);
+        const long inner = std::labs(static_cast<long>(As->colIndex[ia]) - As->colIndex[ib]);
         span.push_back(inner * (len - 1) / std::max(1, len - 1 - 2 * cut));
     }
     if (span.size() < 16) return;
@@ -608,7 +617,13 @@ bool Solver::try_reorder(const LP_info_cpu *model) {
 }
 
 void Solver::finish_tiling() {
-    if (A.tiling.valid() || AT.tiling.valid()) invalidate_far();
+    if (A.tiling.valid() || AT.tiling.valid()) {
+        invalidate_far();
+        // captured graphs (normal iterations, the power iteration's block of ten) bake in the kernel form of the views:
+        // a view that is about to change from the stream kernel to its tiled copy makes them stale (slower, not wrong)
+        for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+    }
     if (A.tiling.valid()) A.finish_tiling(stream);
     if (AT.tiling.valid()) AT.finish_tiling(stream);
 }
@@ -958,14 +973,21 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
         // the device; the host waits once
         const SmallArgs a{m, n, A.view.nnz, A.view.rowptr, AT.view.rowptr, AT.view.val, small_ij.p, small_posA.p,
                           small_order_x.p, small_order_y.p, x.p, x_hat, y, l.p, u.p, c.p, last_x.p, AL.p, AU.p, last_y.p, ctrl.p};
-        launch_small_power(a, z, max_iter, tol, scal.p + S_TMP1, stream);
+        HIP_CHECK(hipMemsetAsync(scal.p + S_SMALL_PW_LAMBDA, 0, 2 * sizeof(double), stream));
+        launch_small_power(a, z, max_iter, tol, scal.p + S_SMALL_PW_LAMBDA, stream);
         fetch_scalars();
-        const double lambda_dev = scal_h[S_TMP1];
-        const int done_dev = static_cast<int>(scal_h[S_TMP1 + 1]);
-        if (iters) *iters = done_dev;
-        power_iters = done_dev;
-        power_time = time_since(t0);
-        return lambda_dev;
+        const double lambda_dev = scal_h[S_SMALL_PW_LAMBDA];
+        const int done_dev = static_cast<int>(scal_h[S_SMALL_PW_ITERS]);
+        // a kernel that did not run leaves the zeroed slots; a lambda that is not a positive finite number is no eigenvalue
+        // estimate either: the regular kernels below take over (same start vector, still in z)
+        if (done_dev > 0 && std::isfinite(lambda_dev) && lambda_dev > 0.0) {
+            if (iters) *iters = done_dev;
+            power_iters = done_dev;
+            power_time = time_since(t0);
+            return lambda_dev;
+        }
+        if (verbose) std::cerr << "[hprlp] single-launch power iteration returned lambda = " << lambda_dev << " after " << done_dev
+                               << " iterations: falling back to the regular kernels" << std::endl;
     }
     launch_norm2(z, m_loc, part_v.p, kReduceBlocks, stream);
     FinalizeArgs f0{};

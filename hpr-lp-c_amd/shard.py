@@ -50,6 +50,33 @@ def transpose_rows_distributed(m, n, row_off, rp, ci, v, rank, world, dist=None)
     return trp.astype(np.int32), grow[order].astype(np.int32), np.ascontiguousarray(vals[order])
 
 
+def transposed_rows_generated(hprlp, m, n, per_row, band, seed, rank, world, threads=0):
+    """Rows [col_off, col_off + n_loc) of A^T for the banded benchmark generator WITHOUT communication: the generator is a pure
+    function of (seed, row), so the rank sweeps all m rows in C (csrc/gen.cpp: hprlp_gen_banded_csr_transposed) and keeps the
+    entries whose column it owns.  Entry for entry what transpose_rows_distributed delivers (tests/test_dist_cpu.py), at a
+    fraction of its time and memory: no 2e8-triple all-to-all over gloo, no 25 M-key argsort per rank."""
+    _, col_off, n_loc = partition(n, world, rank)
+    L = hprlp.lib()
+    ip, dp = hprlp.c_int_p, hprlp.c_dbl_p
+    L.hprlp_gen_banded_csr_transposed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int, ip,
+                                                  C.POINTER(ip), C.POINTER(dp), C.POINTER(C.c_long), C.c_int]
+    L.hprlp_host_free.argtypes = [C.c_void_p]
+    L.hprlp_host_free.restype = None
+    trp = np.zeros(n_loc + 1, np.int32)
+    pci, pv, nnz = ip(), dp(), C.c_long(0)
+    if L.hprlp_gen_banded_csr_transposed(m, n, per_row, band, seed, col_off, n_loc, trp.ctypes.data_as(ip), C.byref(pci), C.byref(pv),
+                                         C.byref(nnz), threads) != 0:
+        raise RuntimeError(hprlp.last_error())
+    k = int(nnz.value)
+    try:
+        tci = np.ctypeslib.as_array(pci, shape=(max(k, 1),))[:k].copy()
+        tv = np.ctypeslib.as_array(pv, shape=(max(k, 1),))[:k].copy()
+    finally:
+        L.hprlp_host_free(C.cast(pci, C.c_void_p))
+        L.hprlp_host_free(C.cast(pv, C.c_void_p))
+    return trp, tci, tv
+
+
 class ShardArrays:
     """Owns the numpy arrays of one rank's shard and exposes them as a ctypes hprlp_shard."""
 

@@ -100,6 +100,14 @@ int hprlp_solver_time_iterations(hprlp_solver *s, int warmup, int steps, int mod
 int hprlp_gen_banded_csr(int m, int n, int per_row, int band, unsigned long long seed, int row0, int rows,
                          int *rowptr, int *col, double *val, int nthreads);
 
+/* Rows [col_off, col_off + n_loc) of the TRANSPOSE of that matrix (= the columns a rank of a row-partitioned run owns:
+ * hprlp_shard::AT_*), produced by sweeping all m rows of the generator and keeping the owned columns -- no rank holds the whole
+ * matrix and nothing is communicated.  Equal entry for entry to the stable host transpose (reference src/utils.cu:203-232) of the
+ * matrix generated whole.  trp: n_loc + 1 entries; *tci / *tv are malloc'd (release with hprlp_host_free); *nnz = their length. */
+int hprlp_gen_banded_csr_transposed(int m, int n, int per_row, int band, unsigned long long seed, int col_off, int n_loc,
+                                    int *trp, int **tci, double **tv, long *nnz, int nthreads);
+void hprlp_host_free(void *p);
+
 /* Benchmark utility: P A Q on the host (row i of the result = row row_new2old[i] of A, columns renumbered by col_old2new and
  * sorted) -- builds the randomly permuted variant of config 5 that the set-up time locality ordering has to undo. */
 int hprlp_permute_csr_host(int m, int n, const int *rowptr, const int *col, const double *val, const int *row_new2old,

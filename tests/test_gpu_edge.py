@@ -254,6 +254,37 @@ def test_out_of_range_column_index_is_refused(gpu, nnz_per_row):
     model.free()
 
 
+def test_corrupt_row_pointers_of_a_large_hand_built_model_are_refused_before_the_host_reads_them(gpu):
+    """Solver::setup samples rowPtr / colIndex on the host (choose_sb_rows, matrices of 4e6 entries and more) BEFORE
+    DeviceMatrix::upload validates them: a hand-filled LP_info_cpu with a non-monotone row pointer array must be refused, not
+    read out of bounds; rows whose columns are not sorted must not make the span estimate negative (the solver is built and steps)."""
+    m = n = 600_000
+    per = 8
+    nnz = m * per     # 4.8e6: the sampling path
+    rng = np.random.default_rng(3)
+    rp = np.arange(0, nnz + 1, per, dtype=np.int32)
+    ci = ((np.arange(m)[:, None] + rng.integers(-2000, 2000, size=(m, per))) % n).astype(np.int32)   # unsorted within a row
+    v = np.ones(nnz)
+    args = (np.zeros(m), np.ones(m) * per, np.zeros(n), np.ones(n), np.ones(n))
+    model = hprlp.Model.from_csr(m, n, rp, ci.ravel(), v, *args)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    s.scale()
+    s.init(1.0, 4.0 * per)
+    s.iterate(3, True)
+    assert np.isfinite(s.residuals(4)["kkt"])
+    s.close()
+    A = model._ptr.contents.A.contents
+    A.rowPtr[m // 2] = nnz + 12345     # behind the library's back: decreasing afterwards, and past the end of colIndex
+    with pytest.raises(RuntimeError, match="row pointer"):
+        hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    A.rowPtr[m // 2] = (m // 2) * per
+    A.rowPtr[m] = nnz - 1
+    with pytest.raises(RuntimeError, match="row pointer"):
+        hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    A.rowPtr[m] = nnz
+    model.free()
+
+
 def _csr_case(m, n, rp, ci, v, AL, AU, l, u, c):
     f = lambda a: np.asarray(a, float)
     return (m, n, np.asarray(rp, np.int32), np.asarray(ci, np.int32), f(v), f(AL), f(AU), f(l), f(u), f(c))

@@ -59,6 +59,44 @@ def test_config5_full_size_properties(gpu):
     model.free()
 
 
+def test_config5_full_size_iterates_equal_the_oracle(gpu):
+    """BASELINE config 5 AT FULL SIZE (10M x 10M, 2e8 nonzeros), element-wise against the oracle: the exact launch the headline
+    figure times -- k_tiled_fused over 1221 super-blocks on 512 persistent workgroups, hand-off, x-rebuild -- for two normal
+    iterations and a check iteration (reference formulas src/cuda_kernels/HPR_cuda_kernels.cu:203-295).  The oracle adopts the
+    scaled data the GPU holds (its own scaling of 2e8 entries is skipped: every use_* flag off), so the comparison isolates the
+    iteration: all 11 iterate vectors to 1e-11 (rotated tile sweep + remainder last vs. CSR order), then the bare SpMVs of the
+    power iteration's first step through lambda after 10 iterations."""
+    import bench as B
+    from oracle import oracle as O
+    from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
+    H = B.H
+    m, n, per_row, band = B.WORKLOADS["c5"]
+    lp = B.banded_lp(m, n, per_row, band)
+    model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    s = H.Solver(model, H.Parameters(use_presolve=False))
+    assert s.info()["tiled"] == 3
+    d = s.describe()
+    assert "1221 super-blocks" in d and "tiled, fused" in d and "piece form" not in d, d
+    s.scale()
+    O.set_num_threads(B.host_cpu_share())
+    ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                     O.Params.default(use_CR_scaling=0, use_Ruiz_scaling=0, use_Pock_Chambolle_scaling=0, use_bc_scaling=0))
+    for k in ("rowptr", "colind", "values"):
+        lp.pop(k)
+    adopt_gpu_data(s, ref)
+    sc = s.scalars()
+    sigma = sc["norm_b"] / sc["norm_c"]
+    lam = 1.3
+    st = run_steps(s, ref, sigma, lam, [(2, True)])
+    for name in NAMES_N + NAMES_M:
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+    lam_g, it = s.power_iteration(max_iter=10)
+    lam_ref, it_ref = ref.power_iteration(max_iter=10)
+    assert it == it_ref == 10 and abs(lam_g - lam_ref) <= 1e-10 * lam_ref, (lam_g, lam_ref)
+    s.close()
+    model.free()
+
+
 def test_config5_sharded_over_four_thread_ranks(gpu):
     """The same LP row-partitioned over 4 ranks (host threads of this process on the one GPU: device copies and host
     barriers in place of RCCL): neighbour exchange chosen, tiled shards, exchange/compute overlap on, and the solve ends

@@ -192,6 +192,63 @@ def test_tiled_matrix_with_long_rows(gpu, force_tiled):
     s2.close(); model2.free()
 
 
+def test_multi_round_persistent_schedule_matches_oracle(gpu, force_tiled):
+    """The HEADLINE kernel form under the oracle.  Config 5 runs k_tiled_fused with 1221 super-blocks over 512 persistent
+    workgroups: 2.38 rounds per slot (workgroup `slot` takes super-blocks slot, slot + 64, ... of its XCD's range,
+    tiled_build.hip: finish_schedule), XCD cohorts, rotated sweeps, hand-off of the remainder products between the half-steps
+    and the x-rebuild mode inside a run of normal iterations.  Same form on an LP the oracle handles in seconds: 64-row
+    super-blocks on a 100 k x 100 k banded LP = 1563 super-blocks, 3.05 rounds per slot, the last round partial.  All iterate
+    vectors of reference src/cuda_kernels/HPR_cuda_kernels.cu:203-295 against the oracle at 1e-11 (per-row summation order:
+    rotated tile sweep, remainder last), plus one residual evaluation (src/main_iterate.cu:229-309) and lambda_max."""
+    old = {k: os.environ.get(k) for k in ("HPRLP_TILE_ROWS", "HPRLP_TILE_PIECES", "HPRLP_NO_FAR_PUSH", "HPRLP_STORE_X")}
+    os.environ["HPRLP_TILE_ROWS"] = "64"
+    for k in ("HPRLP_TILE_PIECES", "HPRLP_NO_FAR_PUSH", "HPRLP_STORE_X"):
+        os.environ.pop(k, None)
+    try:
+        m = n = 100_000
+        lp, model = build(m, n, 12, 1500)
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+        assert s.info()["tiled"] == 3
+        d = s.describe()
+        nsb = -(-m // 64)
+        assert nsb > 3 * 512 and f"{nsb} super-blocks" in d and "tiled, fused" in d and "piece form" not in d, d
+        ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                         O.Params.default(use_CR_scaling=0))
+        s.scale()
+        adopt_gpu_data(s, ref)
+        sigma, lam = 0.6, 1.4
+        st = run_steps(s, ref, sigma, lam, [(23, True), (5, True), (11, False)])
+        for name in NAMES_N + NAMES_M:
+            np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+        # one residual evaluation on the state of the last CHECK step (x_bar, y_bar, z_bar, y_obj, x_temp, y_temp are untouched
+        # by the 11 normal iterations that followed): oracle formulas in numpy on the oracle's state
+        got = s.residuals(150, True)
+        sc = ref.sc
+        obj_scale = sc.b_scale * sc.c_scale
+        pobj = obj_scale * (ref.c @ st["x_bar"])
+        dobj = obj_scale * (st["y_obj"] @ st["y_bar"] + st["x_bar"] @ st["z_bar"])
+        ATy = O.spmv(ref.n, ref.ATrp, ref.ATci, ref.ATv, st["y_bar"])
+        Ax = O.spmv(ref.m, ref.Arp, ref.Aci, ref.Av, st["x_bar"])
+        rd = np.linalg.norm((ref.c - ATy - st["z_bar"]) * ref.col_norm) * sc.c_scale / sc.norm_c_org
+        rp = np.linalg.norm(np.maximum(np.minimum(ref.AU - Ax, 0.0), ref.AL - Ax) * ref.row_norm) * sc.b_scale / sc.norm_b_org
+        Adx = O.spmv(ref.m, ref.Arp, ref.Aci, ref.Av, st["x_temp"])
+        wn = np.sqrt(sigma * lam * (st["y_temp"] @ st["y_temp"]) + (st["x_temp"] @ st["x_temp"]) / sigma + 2 * (Adx @ st["y_temp"]))
+        assert abs(got["primal_obj"] - pobj) <= 1e-11 * (1 + abs(pobj))
+        assert abs(got["dual_obj"] - dobj) <= 1e-11 * (1 + abs(dobj))
+        assert abs(got["err_Rd"] - rd) <= 1e-10 * rd and abs(got["err_Rp"] - rp) <= 1e-10 * rp
+        assert abs(got["weighted_norm"] - wn) <= 1e-9 * wn
+        lam_g, it = s.power_iteration()
+        lam_ref, it_ref = ref.power_iteration()
+        assert it == it_ref and abs(lam_g - lam_ref) <= 1e-11 * lam_ref
+        s.close(); model.free()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("rows_sb,pieces", [(1984, None), (3008, None), (2048, 5)])
 def test_lowered_super_block_height_matches_oracle(gpu, force_tiled, rows_sb, pieces):
     """Super-blocks of fewer than 8192 rows (tiled.h: one super-block per workgroup slot for mid-size matrices; any multiple of
