@@ -315,41 +315,95 @@ def side_configs():
     return out
 
 
+def uniform_random_lp(m, n, per_row, seed=11):
+    """Planted LP on a matrix WITHOUT hidden structure: `per_row` distinct uniformly random columns in every row (the generator
+    of config 5 with a band as wide as the matrix: the far-column rule for all entries).  What BASELINE.json config 5 literally
+    says ("synthetic random CSR"); the reference's kernels make no structure assumption (HPR_cuda_kernels.cu:297-427)."""
+    return banded_lp(m, n, per_row, max(m, n), seed=seed)
+
+
+def scaled_c3_lp(factor, seed=3):
+    """The config-3 recipe (pds-20-like: ~2.2 entries per column, ~6.8 per row, +-1 values, uniformly random pattern = an
+    expander) at `factor` times the size."""
+    return G.planted_lp(33874 * factor, 105728 * factor, 230200 * factor, seed, values="network", dense_col_frac=0.0005 / factor)
+
+
+# Size-and-structure ladder between config 3 (2.4e5 nnz) and config 5 (2e8): the Mittelmann regime.  Banded points use the
+# config-5 generator; the block-angular point (hpr-lp-c_amd/lpgen.py) carries 200 linking rows and 200 linking columns of 5000
+# entries (the long-row paths); round 4: a uniformly random pattern (no structure to find: the propagation-blocking form) and the
+# config-3 recipe x 30 (an expander with 2-7 entries per row / column).
+LADDER_POINTS = {
+    "band_2e6": lambda: banded_lp(100_000, 100_000, 20, 1_000),
+    "band_2e7": lambda: banded_lp(1_000_000, 1_000_000, 20, 10_000),
+    "band_6e7": lambda: banded_lp(3_000_000, 3_000_000, 20, 30_000),
+    "block_angular_2e7": lambda: G.block_angular_lp(1000, 1000, 2000, 18, 200, 200, 5000, 7),
+    "unstructured_4e7": lambda: uniform_random_lp(2_000_000, 2_000_000, 20),
+    "expander_7e6": lambda: scaled_c3_lp(30),
+}
+
+
+def ladder_traffic(key, kernels):
+    """FETCH / WRITE counters of this ladder point (profiles/pmc_traffic.json, entry "ladder:<key>", collected by
+    tools/profile_ladder.sh in separate rocprofv3 --pmc passes): carried only if they were taken on the kernel forms this run
+    chose (`kernels` = hprlp_solver_describe)."""
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        ent = json.load(open(tf)).get("ladder:" + key)
+    except Exception:  # noqa: BLE001
+        ent = None
+    if not ent:
+        return None
+    src = {"file": "profiles/pmc_traffic.json", "entry": "ladder:" + key, "commit": ent.get("commit"), "date": ent.get("date")}
+    if ent.get("kernels") != kernels:
+        return {"xhalf_hbm_bytes_per_launch": None, "yhalf_hbm_bytes_per_launch": None,
+                "source": dict(src, note="counters were taken on other kernel forms: traffic withheld", counters_kernels=ent.get("kernels"))}
+    return {"xhalf_hbm_bytes_per_launch": ent.get("xhalf_hbm_bytes_per_launch"), "yhalf_hbm_bytes_per_launch": ent.get("yhalf_hbm_bytes_per_launch"),
+            "source": src}
+
+
+def ladder_point(key, steps=100, warmup=20, timed=True):
+    """One ladder point: which kernels the library chose, the half-step times by HIP events around every kernel
+    (hprlp_solver_time_iterations mode 1), the algorithmic-bytes fraction of 8 TB/s and -- from the counter passes -- the HBM
+    bytes a half-step really moves and their ratio to the algorithmic bytes."""
+    lp = LADDER_POINTS[key]()
+    m, n, nnz = lp["m"], lp["n"], len(lp["values"])
+    model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    del lp
+    s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
+    s.scale()
+    lam, _ = s.power_iteration(max_iter=50)
+    s.init(-1.0, lam * 1.01)
+    info = s.info()
+    t = s.time_iterations(warmup, steps, 1)
+    g = s.time_iterations(warmup, steps, 0) if timed else t  # as the product runs it (graph replay where it applies)
+    s.iterate(0, True)
+    res = s.residuals(2 * steps + 41)
+    x_ms, y_ms = t["xhalf_ms"] / steps, t["yhalf_ms"] / steps
+    bx, by = bytes_x_half(m, n, nnz), bytes_y_half(m, n, nnz)
+    kernels = s.describe()
+    out = {"m": m, "n": n, "nnz": nnz, "kernels": kernels, "tiled_flags": info["tiled"], "reordered_at_setup": bool(info.get("reordered")),
+           "iterations_per_s": steps / (g["total_ms"] * 1e-3), "xhalf_ms": x_ms, "yhalf_ms": y_ms,
+           "xhalf_frac_of_8000": bx / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "yhalf_frac_of_8000": by / (y_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "iteration_frac_of_8000": bytes_per_iteration(m, n, nnz) * steps / (g["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "xhalf_algorithmic_bytes": bx, "yhalf_algorithmic_bytes": by,
+           "finite": bool(np.isfinite(res["kkt"]))}
+    tr = ladder_traffic(key, kernels)
+    if tr is not None:
+        out["traffic"] = tr
+        if tr.get("xhalf_hbm_bytes_per_launch"):
+            out["traffic"]["xhalf_ratio_to_algorithmic"] = tr["xhalf_hbm_bytes_per_launch"] / bx
+            out["traffic"]["yhalf_ratio_to_algorithmic"] = tr["yhalf_hbm_bytes_per_launch"] / by
+    s.close()
+    model.free()
+    return out
+
+
 def ladder():
-    """Size-and-structure ladder between config 3 (2.4e5 nnz) and config 5 (2e8): the Mittelmann regime.  Per point: which
-    kernels the library chose, the half-step times by HIP events around every kernel (hprlp_solver_time_iterations mode 1)
-    and the algorithmic-bytes fraction of 8 TB/s.  Banded points use the config-5 generator; the block-angular point
-    (hpr-lp-c_amd/lpgen.py) carries 200 linking rows and 200 linking columns of 5000 entries: the long-row paths."""
-    pts = [("band_2e6", lambda: banded_lp(100_000, 100_000, 20, 1_000)),
-           ("band_2e7", lambda: banded_lp(1_000_000, 1_000_000, 20, 10_000)),
-           ("band_6e7", lambda: banded_lp(3_000_000, 3_000_000, 20, 30_000)),
-           ("block_angular_2e7", lambda: G.block_angular_lp(1000, 1000, 2000, 18, 200, 200, 5000, 7))]
     out = {}
-    for key, make in pts:
+    for key in LADDER_POINTS:
         try:
-            lp = make()
-            m, n, nnz = lp["m"], lp["n"], len(lp["values"])
-            model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
-            del lp
-            s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
-            s.scale()
-            lam, _ = s.power_iteration(max_iter=50)
-            s.init(-1.0, lam * 1.01)
-            info = s.info()
-            steps = 100
-            t = s.time_iterations(20, steps, 1)
-            g = s.time_iterations(20, steps, 0)  # as the product runs it (graph replay where it applies)
-            s.iterate(0, True)
-            res = s.residuals(2 * steps + 41)
-            x_ms, y_ms = t["xhalf_ms"] / steps, t["yhalf_ms"] / steps
-            out[key] = {"m": m, "n": n, "nnz": nnz, "kernels": s.describe(), "tiled_flags": info["tiled"],
-                        "iterations_per_s": steps / (g["total_ms"] * 1e-3), "xhalf_ms": x_ms, "yhalf_ms": y_ms,
-                        "xhalf_frac_of_8000": bytes_x_half(m, n, nnz) / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "yhalf_frac_of_8000": bytes_y_half(m, n, nnz) / (y_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "iteration_frac_of_8000": bytes_per_iteration(m, n, nnz) * steps / (g["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "finite": bool(np.isfinite(res["kkt"]))}
-            s.close()
-            model.free()
+            out[key] = ladder_point(key)
         except Exception as e:  # noqa: BLE001
             out[key] = {"error": str(e)}
     return out
@@ -451,9 +505,19 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the config-2/3 side measurements")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-tolerance solve of the workload")
     ap.add_argument("--no-ladder", action="store_true", help="skip the size-and-structure ladder (2e6 .. 6e7 nnz)")
+    ap.add_argument("--ladder-point", default=None, choices=sorted(LADDER_POINTS),
+                    help="run ONE ladder point and print its record (what tools/profile_ladder.sh puts under rocprofv3)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    if args.ladder_point:
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)  # (the library's banner goes to the C-level stdout)
+        rec = ladder_point(args.ladder_point, steps=args.steps, warmup=args.warmup, timed=False)
+        sys.stdout.flush()
+        os.write(real, (json.dumps({args.ladder_point: rec}) + "\n").encode())
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     # The library prints its banner / "problem information" lines to the C-level stdout like the

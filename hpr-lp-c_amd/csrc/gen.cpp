@@ -2,6 +2,7 @@
 // "Synthetic random CSR 10M x 10M, ~200M nnz").  Benchmark/test utility, not part of the solve path.
 // Every row is a pure function of (seed, row), so any rank can produce any row range on its own.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
@@ -148,15 +149,20 @@ extern "C" int hprlp_gen_banded_csr_transposed(int m, int n, int per_row, int ba
             throw std::runtime_error("hprlp_gen_banded_csr_transposed: bad arguments");
         if (nthreads <= 0) nthreads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
         nthreads = std::min(nthreads, std::max(1, m / 4096));
-        std::vector<Kept> kept(static_cast<size_t>(nthreads));
+        // row chunks claimed from a counter (a column range's near entries sit in a few row chunks: static row ranges would
+        // leave most threads with the 5 % far entries only); chunk order = row order
+        const int chunk = 1 << 16;
+        const int nchunks = (m + chunk - 1) / chunk;
+        std::vector<Kept> kept(static_cast<size_t>(nchunks));
+        std::atomic<int> next_chunk{0};
         {
             std::vector<std::thread> th;
-            const int chunk = (m + nthreads - 1) / nthreads;
-            for (int t = 0; t < nthreads; ++t) {
-                const int b = t * chunk, e = std::min(m, b + chunk);
-                if (b >= e) break;
-                th.emplace_back(gen_rows_keep_columns, m, n, per_row, band, static_cast<uint64_t>(seed), b, e, col_off, col_off + n_loc, &kept[t]);
-            }
+            for (int t = 0; t < nthreads; ++t)
+                th.emplace_back([&]() {
+                    for (int q = next_chunk.fetch_add(1); q < nchunks; q = next_chunk.fetch_add(1))
+                        gen_rows_keep_columns(m, n, per_row, band, static_cast<uint64_t>(seed), q * chunk, std::min(m, (q + 1) * chunk), col_off,
+                                              col_off + n_loc, &kept[q]);
+                });
             for (auto &t : th) t.join();
         }
         long total = 0;
@@ -173,14 +179,25 @@ extern "C" int hprlp_gen_banded_csr_transposed(int m, int n, int per_row, int ba
             std::free(tv);
             throw std::runtime_error("hprlp_gen_banded_csr_transposed: out of host memory");
         }
-        std::vector<int> next(trp, trp + n_loc);
-        for (Kept &k : kept) {  // thread order = row order: rows ascend inside a column
-            for (size_t e = 0; e < k.lc.size(); ++e) {
-                const int q = next[k.lc[e]]++;
-                tci[q] = k.row[e];
-                tv[q] = k.val[e];
+        // stable scatter, threads over disjoint column ranges (each walks all chunks in row order and takes its columns)
+        {
+            std::vector<int> next(trp, trp + n_loc);
+            const int parts = std::max(1, std::min(nthreads, n_loc / 4096));
+            std::vector<std::thread> th;
+            for (int t = 0; t < parts; ++t) {
+                const int lo = static_cast<int>(static_cast<long>(n_loc) * t / parts), hi = static_cast<int>(static_cast<long>(n_loc) * (t + 1) / parts);
+                th.emplace_back([&, lo, hi]() {
+                    for (const Kept &k : kept)
+                        for (size_t e = 0; e < k.lc.size(); ++e) {
+                            const int lc = k.lc[e];
+                            if (lc < lo || lc >= hi) continue;
+                            const int q = next[lc]++;
+                            tci[q] = k.row[e];
+                            tv[q] = k.val[e];
+                        }
+                });
             }
-            Kept().lc.swap(k.lc); Kept().row.swap(k.row); Kept().val.swap(k.val);  // release as we go
+            for (auto &t : th) t.join();
         }
         *tci_out = tci;
         *tv_out = tv;
