@@ -777,6 +777,7 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
         d += t.n_pieces > 0 ? "tiled, piece form (k_tiled_part + k_tiled_finish, " + std::to_string(t.n_pieces) + " pieces)"
                             : "tiled, fused (k_tiled_fused, grid " + std::to_string(t.grid) + ")";
         d += ", " + std::to_string(t.nsb) + " super-blocks, " + std::to_string(M.tiled.n_steps) + " steps";
+        if (t.R != kTileRows || t.T != kTileCols) d += " (" + std::to_string(t.R) + " rows, tiles of " + std::to_string(t.T) + " columns)";
         const double all = static_cast<double>(M.tiled.dense_entries) + static_cast<double>(M.tiled.n_rem);
         if (all > 0) d += ", " + std::to_string(static_cast<int>(100.0 * M.tiled.dense_entries / all + 0.5)) + " % of the entries in staged tiles";
         if (t.side_nblk > 0) d += ", long rows aside (" + std::to_string(t.side_nblk) + " blocks through the stream kernel)";

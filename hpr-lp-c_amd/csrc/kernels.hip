@@ -94,7 +94,14 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
     __shared__ double lds[kWavesPerBlock][NV][kStreamW];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * kWavesPerBlock + wave;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the XCD's share): give every XCD a CONTIGUOUS
+    // range of row blocks, so that neighbouring rows -- whose column windows overlap in a banded or block-structured LP --
+    // gather through ONE 4 MiB L2 instead of pulling the same lines of the vector into up to eight of them (block-angular
+    // ladder point, y-half: 1.65 x the algorithmic bytes left the L2s with the plain blockIdx order).  A bijection of
+    // [0, gridDim.x): share x owns start_x = x * (grid / 8) + min(x, grid % 8) and the next grid / 8 (+ 1) workgroups.
+    const int xcd = blockIdx.x & 7, per_lo = gridDim.x >> 3, rem = gridDim.x & 7;
+    const int wg = xcd * per_lo + min(xcd, rem) + (blockIdx.x >> 3);
+    const int b = wg * kWavesPerBlock + wave;
     double acc[NACC > 0 ? NACC : 1];
 #pragma unroll
     for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) acc[i] = 0.0;
@@ -309,6 +316,9 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 #ifndef HPRLP_DBG_NOPUSHWORK
 #define HPRLP_DBG_NOPUSHWORK 0
 #endif
+#ifndef HPRLP_DBG_PBSTAMP
+#define HPRLP_DBG_PBSTAMP 0  // developer builds: wall-clock time of k_pb_fused's phases per workgroup (TiledDev::wgtimes, HPRLP_WG_TIMES=1 HPRLP_PB_STAMPS=1)
+#endif
 #ifndef HPRLP_SWEEP_ED
 #define HPRLP_SWEEP_ED 2  // fused kernel: entry loads issued this many steps ahead ...
 #define HPRLP_SWEEP_TD 1  // ... and tile loads this many
@@ -326,11 +336,14 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 #define HPRLP_DBG_NOBARRIER 0
 #endif
 
-template <int ED, int TD, bool REP, bool STAMP = false, bool LOGTERM = false>
+template <int ED, int TD, bool REP, bool STAMP = false, bool LOGTERM = false, int TC = kTileCols>
 __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, int first, int count, const double *__restrict__ vec,
                                             int ncols, double *acc, double *ytile, int tid, unsigned long long *stamp = nullptr) {
-    constexpr int NT = kTileThreads, R = kTileRows, T = kTileCols, K = kTileChunk;  // (R: the codes' row field, whatever the copy's height)
-    constexpr int TPT = T / NT;
+    constexpr int NT = kTileThreads, R = kTileRows, K = kTileChunk;  // (R: the codes' row field, whatever the copy's height)
+    // TC: columns per tile of the copy (tiled.h: kTileCols, or kTileColsNarrow -- its own instantiation: a run-time trip count of
+    // the staging loops costs the sweep its counted waits, 0.69 -> 0.87 ms on config 5)
+    constexpr int TPT = TC / NT;
+    static_assert(TC == kTileCols || TC == kTileColsNarrow, "tile width");
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const int lane = tid & 63;
     auto sidx = [&](int i) { i = min(i, count - 1) + first; return s0 + (i < nst ? i : i - nst); };
@@ -544,6 +557,35 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
 #endif
 }
 
+// Sum of the products of entries j0, j0 + 1, ... of a remainder step while they belong to row `rw` and stay below `lim`, added to
+// `sum` in that order (the step's entries are in (row, CSR) order; rq[e + 1] = slot << 16 | row of entry e, prod[slot] its product).
+// One LDS read decides whether the run goes on at all (most rows of a banded matrix hold ONE far entry); a run that does is read
+// eight codes, then eight products at a time -- independent reads, one LDS latency per batch instead of two per entry (a row of
+// 20 remainder entries -- every row of a matrix without column locality -- was a chain of 40 dependent LDS reads).
+__device__ __forceinline__ double rem_run_sum(const double *prod, const uint32_t *rq, int j0, int lim, int cnt, uint32_t rw, double sum) {
+    int j = j0;
+    if (j >= lim || (rq[j + 1] & 0xffffu) != rw) return sum;
+    while (true) {
+        uint32_t q[8];
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = rq[min(j + u, cnt - 1) + 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = prod[q[u] >> 16];
+        // no branch per entry (eight live lane masks were eight scalar register pairs of the kernel's budget): a product
+        // behind the end of the run is replaced by zero -- sum + 0.0 is sum
+        int go = 1, n = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            go &= static_cast<int>((j + u < lim) & ((q[u] & 0xffffu) == rw));
+            sum += go ? p[u] : 0.0;
+            n += go;
+        }
+        j += 8;
+        if (n < 8 || j >= lim) return sum;
+    }
+}
+
 // Remainder steps [smid, s1) of a super-block (propagation blocking, tiled.h): the products were written by
 // k_far_products into this super-block's slice of P; a step streams its range of P into the tile buffer (coalesced)
 // next to the step's entry codes in (row, CSR) order, then one head lane per row segment adds that row's products in order.
@@ -593,15 +635,8 @@ __device__ __forceinline__ void tiled_remainder(const TiledDev &t, int smid, int
                     const uint32_t w = rq[el + 1];
                     const uint32_t rw = w & 0xffffu;
                     if ((rq[el] & 0xffffu) != rw || (el % kTileRemRun) == 0) {
-                        double part = 0.0;
-                        uint32_t q = w;
-                        int j = el;
-                        do {
-                            part += prod[q >> 16];
-                            ++j;
-                            q = rq[j + 1];
-                        } while (j < cnt && (j % kTileRemRun) != 0 && (q & 0xffffu) == rw);
-                        prod[w >> 16] = part;
+                        const int lim = min(cnt, (el / kTileRemRun + 1) * kTileRemRun);
+                        prod[w >> 16] = rem_run_sum(prod, rq, el + 1, lim, cnt, rw, 0.0 + prod[w >> 16]);
                     }
                 }
             }
@@ -634,24 +669,14 @@ __device__ __forceinline__ void tiled_remainder(const TiledDev &t, int smid, int
             if (el < cnt) {
                 const uint32_t w = rq[el + 1];
                 const uint32_t rw = w & 0xffffu;
-                if ((rq[el] & 0xffffu) != rw) {
-                    double sacc = acc[rw];
-                    uint32_t q = w;
-                    int j = el;
-                    do {
-                        sacc += prod[q >> 16];
-                        ++j;
-                        q = rq[j + 1];
-                    } while (j < cnt && (q & 0xffffu) == rw);
-                    acc[rw] = sacc;
-                }
+                if ((rq[el] & 0xffffu) != rw) acc[rw] = rem_run_sum(prod, rq, el + 1, cnt, cnt, rw, acc[rw] + prod[w >> 16]);
             }
         }
         st = nxt;
     }
 }
 
-template <class Epi, bool REP, bool PUSH = false>
+template <class Epi, bool REP, bool PUSH = false, bool NARROW = false>
 __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi epi) {  // 4 waves per SIMD = two workgroups per CU
     static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
     constexpr int NT = kTileThreads, RMAX = kTileRows, T = kTileCols;
@@ -678,7 +703,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         const int ncols = A.cols;
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
-        if (s0 < smid) tiled_sweep<HPRLP_SWEEP_ED, HPRLP_SWEEP_TD, REP, false, LogTerm<Epi>::value>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
+        if (s0 < smid) tiled_sweep<HPRLP_SWEEP_ED, HPRLP_SWEEP_TD, REP, false, LogTerm<Epi>::value, NARROW ? kTileColsNarrow : kTileCols>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
 #if !HPRLP_DBG_NOREM
         tiled_remainder(t, smid, s1, acc, ytile, tid);
 #endif
@@ -749,6 +774,250 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
 }
 
 // ------------------------------------------------------------------------------------------------
+// All-remainder form (round 4; tiled.h: kPbRemCap): the copy of a matrix without column locality stages no tile at all -- every
+// entry's product arrives through P (written by the other half-step's epilogue, or by k_far_products) and a super-block's work is
+// to add its slice of P row by row.  Its own kernel: LDS holds the accumulators of at most kPbRowsMax rows and steps of
+// kPbRemCap = 3072 products with their codes (k_tiled_fused's remainder steps have the 16 KiB tile buffer: 1024), and a step's
+// work is COMPACTED over the lanes.  One head lane per row left most lanes idle behind a few chains of dependent LDS reads (every
+// row of such a matrix holds all its ~20 entries here: 0.28 ms for the 4e7 entries of a 2M x 2M matrix, three times the time its
+// bytes take).  An item = an entry at a row change or at a multiple of kPbRun; the items' positions go to a dense list (wave
+// ballots + the waves' counts through LDS), lane t takes item t.  Level 1: every item adds the products up to the next item
+// (eight independent reads at a time) and leaves the partial sum in its own product slot; level 2: the items at a row change add
+// their row's partials.  Per-row order of the additions: as stored ((source group, CSR) order), in groups of kPbRun -- fixed by the
+// matrix, so results are reproducible run to run.  Same persistent schedule, epilogue and hand-off as k_tiled_fused.
+// ------------------------------------------------------------------------------------------------
+template <class Epi, bool PUSH = false>
+__global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi) {
+    static_assert(Epi::NV == 1, "one gathered vector");
+    constexpr int NT = kTileThreads, K = kPbRemK, CAP = kPbRemCap, NW = kTileThreads / 64;
+    constexpr int NACC = Epi::NACC;
+    __shared__ double acc[kPbRowsMax];
+    __shared__ __attribute__((aligned(16))) double prod[CAP];
+    __shared__ uint32_t bnd_row[NW];
+    __shared__ double bnd_val[NW];
+    const TiledDev &t = A.tiled;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int R = t.R;
+    const int per = t.per, slots = gridDim.x / 8;
+    const int slot = blockIdx.x / 8;
+    double racc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
+    epi.begin();
+#if HPRLP_DBG_PBSTAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64(), tk0 = tq;
+#define PB_STAMP(i) do { const unsigned long long now_ = wall_clock64(); ph[i] += now_ - tq; tq = now_; } while (0)
+#else
+#define PB_STAMP(i) do { } while (0)
+#endif
+    for (int q = slot; q < per; q += slots) {
+        const int sb = (blockIdx.x % 8) * per + q;
+        if (sb >= t.nsb) break;
+        lds_barrier();  // the previous super-block's epilogue is done with acc
+        for (int i = tid; i < R; i += NT) acc[i] = 0.0;
+        const int smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
+        if (smid < s1 && !HPRLP_DBG_NOREM) {
+            // the loads of step s + 1 (P in storage order for the staging, the codes of this lane's own chunk of K consecutive
+            // entries of the (row, CSR) order) are in flight while step s is folded
+            double pv[K];
+            uint32_t cv[K];
+            TileStep st = t.steps[smid];
+            auto issue = [&](const TileStep &z) {
+                const int last = max(z.e_end - z.e_begin - 1, 0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) pv[k] = __builtin_nontemporal_load(t.P + z.e_begin + min(tid + k * NT, last));  // clamped: branch-free
+                // the lane's K = 6 consecutive codes as two 12-byte loads (4-byte aligned; six 4-byte loads with a lane stride of
+                // 24 bytes kept the address unit busy for 2 us per step); behind the step's end the last whole chunk is read
+                // (its values are not used: the lane's entry count says so)
+                static_assert(K == 6, "two three-word loads per lane");
+                typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));
+                const int c0 = min(K * tid, max(last + 1 - K, 0));
+                const u3_t w0 = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.rq + z.e_begin + c0));
+                const u3_t w1 = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.rq + z.e_begin + c0 + 3));
+                cv[0] = w0.x; cv[1] = w0.y; cv[2] = w0.z; cv[3] = w1.x; cv[4] = w1.y; cv[5] = w1.z;
+            };
+            issue(st);
+            constexpr uint32_t NOROW = 0x10000u;  // (codes keep the row in 16 bits)
+            for (int s = smid; s < s1; ++s) {
+                const int cnt = st.e_end - st.e_begin;
+                const TileStep nxt = t.steps[min(s + 1, s1 - 1)];
+                lds_barrier();  // everybody is done with the previous step's products and row sums
+                PB_STAMP(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int el = tid + k * NT;
+                    if (el < cnt) prod[el] = pv[k];
+                }
+                // (a lane whose chunk crosses the step's end loaded the LAST whole chunk instead: move its codes down)
+                uint32_t code[K];
+                {
+                    const int shift = K * tid - min(K * tid, max(cnt - K, 0));  // 0 for every lane but at most one
+#pragma unroll
+                    for (int u = 0; u < K; ++u) code[u] = cv[u];
+                    if (shift > 0 && shift < K) {
+#pragma unroll
+                        for (int u = 0; u < K; ++u) {
+                            uint32_t c = 0;
+#pragma unroll
+                            for (int q = 0; q < K; ++q) c = (q == u + shift) ? cv[q] : c;
+                            code[u] = c;
+                        }
+                    }
+                }
+                if (s + 1 < s1) issue(nxt);
+                lds_barrier();
+                PB_STAMP(1);
+                // this lane's chunk: entries K tid .. K tid + K - 1 of the step, sorted by row.  Entries behind the step's end
+                // continue the last valid row with a zero product; a lane without any entry holds NOROW.
+                const int nv = min(max(cnt - K * tid, 0), K);
+                uint32_t row[K];
+                double pr[K];
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const bool ok = u < nv;
+                    row[u] = ok ? (code[u] & 0xffffu) : (u == 0 ? NOROW : row[u - 1]);
+                    pr[u] = ok ? prod[code[u] >> 16] : 0.0;
+                }
+                // in-lane: the run that starts at entry 0 (head), rows that begin and end inside the chunk (added on the spot:
+                // nobody else holds entries of theirs in this step), the run that ends at entry K - 1 (tail)
+                double run = pr[0], head = 0.0;
+                bool single = true;
+#pragma unroll
+                for (int u = 1; u < K; ++u) {
+                    if (row[u] != row[u - 1]) {
+                        if (single) {
+                            head = run;
+                            single = false;
+                        } else {
+                            acc[row[u - 1]] += run;
+                        }
+                        run = pr[u];
+                    } else {
+                        run += pr[u];
+                    }
+                }
+                const uint32_t rf = row[0], rl = row[K - 1];
+                // across the lanes of the wave: a row's pieces are the tail of one lane, whole lanes, the head of a last one.
+                // Segmented inclusive scan of the lanes' carry-outs (the tail, or everything for a one-row lane); a lane passes the
+                // carry on iff it holds one row and continues its predecessor's.
+                const uint32_t rl_prev = __shfl_up(rl, 1, 64);
+                const bool open_in = lane > 0 && rf == rl_prev && rf != NOROW;
+                double v = run;
+                int f = (single && open_in) ? 0 : 1;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double vu = __shfl_up(v, off, 64);
+                    const int fu = __shfl_up(f, off, 64);
+                    if (lane >= off && !f) {
+                        v += vu;
+                        f |= fu;
+                    }
+                }
+                const double v_prev = __shfl_up(v, 1, 64);
+                const double carry = open_in ? v_prev : 0.0;
+                const int next_open = __shfl_down(static_cast<int>(open_in), 1, 64);
+                if (!single) acc[rf] += carry + head;  // the head's row ends in this lane
+                const double tail = single ? carry + run : run;
+                if (lane == 63) {
+                    // the wave's last run may go on in the next wave (whose first lane takes no carry): added after the barrier, by one lane
+                    bnd_row[wave] = rl;
+                    bnd_val[wave] = tail;
+                } else if (!next_open && rl != NOROW) {
+                    acc[rl] += tail;
+                }
+                lds_barrier();
+                PB_STAMP(2);
+                if (tid < NW) {
+                    // the waves' last runs, one lane each; a row that fills whole waves appears more than once: the lane of its
+                    // last appearance adds them all, in wave order
+                    const uint32_t rw = bnd_row[tid];
+                    bool last_one = rw != NOROW;
+                    double tot = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const bool same = bnd_row[w] == rw;
+                        if (w <= tid && same) tot += bnd_val[w];
+                        if (w > tid && same) last_one = false;
+                    }
+                    if (last_one) acc[rw] += tot;
+                }
+                PB_STAMP(3);
+                st = nxt;
+            }
+        }
+        lds_barrier();
+        PB_STAMP(4);
+        const int r0 = sb * R;
+#if HPRLP_DBG_NOEPI
+        const int nr = min(R, A.rows - r0) > 0 && acc[tid] == 1.2345e-300 ? 1 : 0;  // timing experiment only: no epilogue traffic
+#else
+        const int nr = min(R, A.rows - r0);
+#endif
+        int pb = 0, pe = 0;
+        if constexpr (PUSH) {
+            pb = epi.push.gptr[sb];
+            pe = epi.push.gptr[sb + 1];
+        }
+        for (int i = tid; i < nr; i += NT) {
+            const double sv[1] = {acc[i]};
+            typename Epi::Row rw = epi.load_row(r0 + i);
+            if constexpr (PUSH) acc[i] = epi.apply(r0 + i, rw, sv, racc);  // the published value replaces the row sum
+            else epi.apply(r0 + i, rw, sv, racc);
+        }
+        PB_STAMP(5);
+        if constexpr (PUSH && !HPRLP_DBG_NOEPI && !HPRLP_DBG_NOPUSHWORK) {
+            // hand-off (kernels.h: FarPush), as in k_tiled_fused: this super-block's fresh values are source group `sb` of the
+            // other matrix' lists
+            lds_barrier();
+            const FarPush &f = epi.push;
+            // four entries per lane and batch; the next batch's loads are in flight while this one's products are stored (one
+            // batch at a time left every batch a full trip to memory: 2.9 us each, 110 of the kernel's 250 us)
+            constexpr int U = 4;
+            double a4[U];
+            int p4[U];
+            uint16_t c4[U];
+            auto load_batch = [&](int k0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int z = min(k0 + u * NT, pe - 1);  // clamped: branch-free, surplus lanes are masked at the store
+                    a4[u] = __builtin_nontemporal_load(f.val + z);
+                    p4[u] = __builtin_nontemporal_load(f.pos + z);
+                    c4[u] = __builtin_nontemporal_load(f.lcol + z);
+                }
+            };
+            int k = pb + tid;
+            if (pb < pe) load_batch(k);
+            for (; k < pe; k += U * NT) {
+                double prd[U];
+                int ps[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    prd[u] = a4[u] * acc[c4[u]];
+                    ps[u] = p4[u];
+                }
+                const int kn = k + U * NT;
+                if (kn < pe) load_batch(kn);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (k + u * NT < pe) f.P[ps[u]] = prd[u];
+            }
+        }
+        PB_STAMP(6);
+    }
+#if HPRLP_DBG_PBSTAMP
+    if (t.wgtimes && tid == 0 && PUSH && NACC == 0) {
+        ph[7] = wall_clock64() - tk0;
+        for (int i = 0; i < 8; ++i) t.wgtimes[blockIdx.x * 8 + i] = ph[i];
+    }
+#endif
+#undef PB_STAMP
+    if constexpr (NACC > 0) {
+        __syncthreads();
+        block_store_partials_in<NACC, kTileThreads / kWave>(racc, epi.partials, epi.stride, reinterpret_cast<double(*)[NACC]>(prod));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Piece form, for matrices with fewer super-blocks than the chip has workgroup slots (a 1/8 row shard of config 5 has 153,
 // a 1/4 shard 306; a workgroup's sweep is a chain of dependent steps, so the chip only streams when every slot has one).
 // The tile steps of all super-blocks, laid end to end, are cut into equal pieces (tiled_build.hip, finish_schedule); a
@@ -756,7 +1025,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
 // stores them (the super-block's last segment adds the remainder); k_tiled_finish adds a row's segments in order and
 // runs the epilogue.  Per-row summation order: tiles ascending, remainder last -- fixed by the matrix and the piece count.
 // ------------------------------------------------------------------------------------------------
-template <bool REP, bool STAMP = false>
+template <bool REP, bool STAMP = false, bool NARROW = false>
 __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_part(CsrDev A, const double *__restrict__ vec) {
     constexpr int NT = kTileThreads, RMAX = kTileRows, T = kTileCols;
     __shared__ double acc[RMAX];
@@ -777,7 +1046,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_part(CsrDev A, const 
         unsigned long long *st = STAMP ? t.stamps + static_cast<size_t>(pc) * 16 : nullptr;
         unsigned long long c0 = 0, c1 = 0, c2 = 0;
         if (STAMP) c0 = __builtin_amdgcn_s_memtime();
-        if (d.z > 0) tiled_sweep<3, 2, REP, STAMP>(t, s0, smid - s0, d.y, d.z, vec, A.cols, acc, ytile, tid, st);
+        if (d.z > 0) tiled_sweep<3, 2, REP, STAMP, false, NARROW ? kTileColsNarrow : kTileCols>(t, s0, smid - s0, d.y, d.z, vec, A.cols, acc, ytile, tid, st);
         if (STAMP) c1 = __builtin_amdgcn_s_memtime();
         if (d.w) tiled_remainder(t, smid, s1, acc, ytile, tid);
         lds_barrier();
@@ -1276,9 +1545,23 @@ template <class Epi>
 static bool launch_tiled(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready) {
     if (M.tiled.n_groups > 0 && !far_ready)
         hipLaunchKernelGGL(k_far_products<false>, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
+    // copies with narrow tiles (tiled.h: kTileColsNarrow) run their own instantiation of the sweep, without the repeated-tile
+    // shortcut (re-staging 8 KiB is cheap; REP only saves work, it is not needed for correctness)
+    const bool narrow = M.tiled.T == kTileColsNarrow;
+    if (M.tiled.rem_cap == kPbRemCap) {  // all-remainder form (tiled.h): its own fused kernel
+        if constexpr (Publishes<Epi>::value) {
+            if (e.push.gptr) {
+                hipLaunchKernelGGL((k_pb_fused<Epi, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+                return true;
+            }
+        }
+        hipLaunchKernelGGL((k_pb_fused<Epi, false>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+        return false;
+    }
     if (M.tiled.n_pieces > 0) {
         const dim3 grid((M.tiled.n_pieces + 7) / 8 * 8);
-        if (M.tiled.stamps) hipLaunchKernelGGL((k_tiled_part<false, true>), grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
+        if (narrow) hipLaunchKernelGGL((k_tiled_part<false, false, true>), grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
+        else if (M.tiled.stamps) hipLaunchKernelGGL((k_tiled_part<false, true>), grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
         else if (M.tiled.repeats) hipLaunchKernelGGL(k_tiled_part<true>, grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
         else hipLaunchKernelGGL(k_tiled_part<false>, grid, dim3(kTileThreads), 0, s, M, e.gv[0]);
         hipLaunchKernelGGL(k_tiled_finish<Epi>, dim3(M.tiled_finish_grid()), dim3(kThreads), 0, s, M, e);
@@ -1286,12 +1569,14 @@ static bool launch_tiled(const CsrDev &M, const Epi &e, hipStream_t s, bool far_
     }
     if constexpr (Publishes<Epi>::value) {
         if (e.push.gptr) {
-            if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+            if (narrow) hipLaunchKernelGGL((k_tiled_fused<Epi, false, true, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+            else if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
             else hipLaunchKernelGGL((k_tiled_fused<Epi, false, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
             return true;
         }
     }
-    if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+    if (narrow) hipLaunchKernelGGL((k_tiled_fused<Epi, false, false, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
+    else if (M.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<Epi, true>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
     else hipLaunchKernelGGL((k_tiled_fused<Epi, false>), dim3(M.tiled.grid), dim3(kTileThreads), 0, s, M, e);
     return false;
 }
@@ -1547,7 +1832,9 @@ void launch_cr_log_update(const CsrDev &M, const double *other_full, double *res
         L.tiled.f_val = fval_log;
         if (L.tiled.n_groups > 0)
             hipLaunchKernelGGL(k_far_products<true>, dim3((L.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, L.tiled, other_full, L.cols);
-        if (L.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<CrEpi, true>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);
+        if (L.tiled.rem_cap == kPbRemCap) hipLaunchKernelGGL((k_pb_fused<CrEpi, false>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);  // all-remainder form
+        else if (L.tiled.T == kTileColsNarrow) hipLaunchKernelGGL((k_tiled_fused<CrEpi, false, false, true>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);
+        else if (L.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<CrEpi, true>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);
         else hipLaunchKernelGGL((k_tiled_fused<CrEpi, false>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);
         return;
     }

@@ -63,6 +63,24 @@ std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4
         }
         blk.push_back(make_int4(start, r - start, rowptr[start], nz));
     }
+    // The stream kernel gives every XCD a contiguous eighth of the block list (kernels.hip: k_spmv_fused), and a vector-mode
+    // block -- a long row or a 4096-entry chunk of a split row -- is up to eight times the work of a stream block.  LPs carry
+    // such rows in bunches (linking constraints at the end of a block-angular model: 400 chunk blocks in the last XCD's range
+    // made that XCD's share 1.6 x the others').  Spread the heavy blocks evenly over the list; the others keep their order
+    // (neighbouring rows stay neighbours), the heavy ones theirs (split-row chunk slots ascend).
+    if (blk.size() >= 256) {
+        std::vector<int4> light, heavy;
+        for (const int4 &d : blk) (d.y == 0 || (d.y == 1 && d.w > kLongRow) ? heavy : light).push_back(d);
+        if (!heavy.empty() && !light.empty()) {
+            const size_t N = blk.size(), H = heavy.size();
+            size_t ih = 0, il = 0;
+            for (size_t i = 0; i < N; ++i) {
+                // heavy block ih belongs at position ih * N / H
+                if (ih < H && (il >= light.size() || ih * N / H <= i)) blk[i] = heavy[ih++];
+                else blk[i] = light[il++];
+            }
+        }
+    }
     return blk;
 }
 
@@ -172,7 +190,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         //    consecutive products (two dependent LDS reads each): five rows of 3000 entries took that launch from 31 to 203
         //    us.  Such matrices keep the stream kernel, which spreads a long row over a wave or several.
         const char *mc = std::getenv("HPRLP_TILED_MIN_COLS");
-        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (short_form ? (1 << 19) : (1 << 20)));
+        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (short_form ? (1 << 19) : 800000));  // (800 k: as kPbMinCols, a vector beyond one L2)
         int longest = 0;
         if (rp)
             for (int i = 0; i < rows; ++i) longest = std::max(longest, rp[i + 1] - rp[i]);
@@ -201,7 +219,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
                 DBuf<int> d_rp_c(rp_c.size()), col_c(static_cast<size_t>(std::max<long>(nnz_c, 1))), map_c(static_cast<size_t>(std::max<long>(nnz_c, 1)));
                 d_rp_c.upload(rp_c.data(), rp_c.size());
                 compact_without_rows(nnz, rows, rowptr.p, d_rp_c.p, col.p, col_c.p, map_c.p, nullptr);
-                const bool ok = tiled.build_on_device(rows, cols, nnz_c, d_rp_c.p, col_c.p, min_rows, min_dense, nullptr, rb);
+                const bool ok = tiled.build_on_device(rows, cols, nnz_c, d_rp_c.p, col_c.p, min_rows, min_dense, nullptr, rb, tile_cols, rem_cap);
                 if (pt.on)
                     std::cerr << "[timing]   tiled copy without " << long_rows.size() << " long rows (" << long_nnz << " entries, longest " << longest
                               << "): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, " << tiled.n_steps << " steps" << std::endl;
@@ -223,7 +241,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
             // built on the device from the device CSR arrays (tiled_build.hip); HPRLP_TILING_CHECK=1 also runs the
             // host builder and compares every array
-            const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr, rb);
+            const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr, rb, tile_cols, rem_cap);
             declined_sparse = !ok;  // rows >= min_rows here: what was missing is dense tiles
             if (pt.on)
                 std::cerr << "[timing]   tiled copy (device build): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, "
@@ -232,7 +250,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
             const char *chk = std::getenv("HPRLP_TILING_CHECK");
             if (chk && chk[0] == '1' && ci) {
                 TiledHost th;
-                const bool hok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense, rb);
+                const bool hok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense, rb, tile_cols, rem_cap);
                 if (hok != ok) throw std::runtime_error("tiling check: host and device builders disagree on acceptance");
                 if (ok) tiled.compare_with(th);
             }
@@ -245,10 +263,11 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
             pt.tick("  build tiled copy (device)");
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && ci) {  // the host builder needs the host column indices
             planned_grid = std::max(((rows + rb - 1) / rb + 7) / 8 * 8, (rows + kThreads - 1) / kThreads);  // fused grid or the split form's finish grid
+            const int tc = tile_cols, rc = rem_cap;
             tiling = std::async(std::launch::async, [=]() -> std::shared_ptr<TiledHost> {
                 (void)keep;  // keeps the host arrays alive for the duration of the build
                 auto th = std::make_shared<TiledHost>();
-                return build_tiled(rows, cols, rp, ci, th.get(), min_rows, min_dense, rb) ? th : nullptr;
+                return build_tiled(rows, cols, rp, ci, th.get(), min_rows, min_dense, rb, tc, rc) ? th : nullptr;
             });
         }
     }
@@ -267,7 +286,7 @@ void DeviceMatrix::finish_tiling(hipStream_t s) {
         std::cerr << "[timing]   tiled copy: " << th->sb_mid.size() << " super-blocks, " << th->steps.size() << " steps, "
                   << th->dense_entries << " entries in tiles + " << th->padding << " padding, " << th->n_rem
                   << " in the remainder list" << std::endl;
-    tiled.upload(*th, sb_rows);
+    tiled.upload(*th, sb_rows, tile_cols, rem_cap);
     tiled.build_far(view.cols, s, far_group);
     view.tiled = tiled.view;
     launch_tiled_refresh(tiled, val.p, s);
@@ -363,6 +382,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
                 device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
                 pt.tick("locality ordering + device transpose of the permuted matrix");
             } else if (pb_fallback_wanted(A)) {
+                choose_pb_rows(A, AT, m, n);
                 // no column locality to be had (or the ordering is disabled): every random 8-byte gather of the stream kernel
                 // would cost a 128-byte line from the Infinity Cache / HBM.  Accept the tiled form with NO dense-tile
                 // requirement: whatever is not in dense tiles -- here almost everything -- goes through the propagation-
@@ -382,7 +402,10 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             }
             pt.tick("download A^T indices");
             AT.describe(n, m, trp.data(), need_tci ? tci.data() : nullptr, ht);
-            if (pb_fallback_wanted(AT)) AT.describe(n, m, trp.data(), nullptr, nullptr, 0.0);
+            if (pb_fallback_wanted(AT)) {
+                choose_pb_rows(AT, A, n, m);
+                AT.describe(n, m, trp.data(), nullptr, nullptr, 0.0);
+            }
         } else {
             std::vector<double> tv;
             csr_transpose_host(m, n, nnz, As->rowPtr, As->colIndex, As->value, trp, tci, tv);
@@ -458,7 +481,8 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
 // vs 0.508, 4.2M 0.46 vs 0.75, 6M 0.59 vs 1.13)
 constexpr double kMaxTileShare = 0.6;  // choose_sb_rows: most tile bytes per entry byte a lowered super-block may stage (one round)
 constexpr double kMaxTileShareRounds = 0.9;  // ... when the height only trims a partial last round of a larger matrix
-constexpr long kPbMinCols = 1500000;
+constexpr long kPbMinCols = 800000;  // (round 4, tools/unstructured_ab.py with k_pb_fused, 10 per row: 0.5M columns 0.065 vs 0.041 ms stream, 1.0M 0.080 vs 0.123, 1.5M 0.119 vs 0.214: from where the vector outgrows a 4 MiB L2)
+constexpr double kNarrowTilesFrom = 1.2;  // choose_sb_rows: entries of a row per 2048-column tile from which the copy gets 1024-column tiles
 
 bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
     const char *no = std::getenv("HPRLP_NO_PB_FALLBACK");
@@ -478,8 +502,56 @@ bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
 // source group of one matrix' remainder lists is a super-block of the other (hand-off, kernels.h FarPush): far_group of A is
 // sb_rows of A^T and vice versa.  Same-box A/B (profiles/r03_ab_rows*.txt): 1M x 1M, band 1e4: 3658 it/s stream kernel, 3393
 // pieces, 5287 with 2048-row super-blocks; the 1.25M x 10M shard of config 5 (window of 2e5 columns): a loss, declined here.
+// The height that fills exactly k rounds of the chip's workgroup slots, k = the rounds the FULL height needs (k = 1: one
+// super-block per slot); the full height where its rounds are nearly full already.
+static int whole_rounds_height(int rows, int slots) {
+    const int nsb_full = (rows + kTileRows - 1) / kTileRows;
+    const int k = std::max(1, (nsb_full + slots - 1) / slots);
+    if (k > 1 && static_cast<double>(nsb_full) / (static_cast<double>(k) * slots) >= 0.8) return kTileRows;  // rounds nearly full already
+    const int per = (rows + k * slots - 1) / (k * slots);
+    return std::min(kTileRows, (per + 63) / 64 * 64);
+}
+
+static int workgroup_slots() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus * kTileResidentPerCu;
+}
+
+// Heights for a matrix that runs the tiled form WITHOUT staged tiles (pb_fallback_wanted: every entry through the
+// propagation-blocking remainder).  No tile is staged, so a lower super-block costs nothing in tile traffic: take the height
+// that gives every workgroup slot whole super-blocks -- the half-step is then ONE fused launch whose epilogue hands the
+// products over to the other half (round 3 ran such matrices at full height: 245 super-blocks of a 2M x 2M matrix = the piece
+// form, three launches per half-step, partial sums through memory, no hand-off).  HPRLP_TILE_ROWS still overrides.
+void Solver::choose_pb_rows(DeviceMatrix &M, DeviceMatrix &other, int rows, int other_rows) {
+    M.rem_cap = kTileRemCap;
+    if (comm) return;
+    if (!std::getenv("HPRLP_TILE_ROWS")) {
+        const int slots = workgroup_slots();
+        // at most kPbRowsMax rows (the all-remainder kernel's accumulators, kernels.hip: k_pb_fused): larger matrices take more rounds
+        auto height = [&](int nrows) {
+            int r = std::max(kTileRowsMin, whole_rounds_height(nrows, slots));
+            for (int k = 2; r > kPbRowsMax; ++k) r = std::max(kTileRowsMin, ((nrows + k * slots - 1) / (k * slots) + 63) / 64 * 64);
+            return r;
+        };
+        M.sb_rows = other.far_group = height(rows);
+        // the other matrix has the same graph: if it is not described yet, expect it to take the same form (its source groups are
+        // this matrix' hand-off unit, kernels.h FarPush; a wrong guess only costs the hand-off)
+        if (!other.view.tiled.valid) other.sb_rows = M.far_group = height(other_rows);
+    }
+    // (HPRLP_NO_PB_KERNEL, A/B runs: the all-remainder copy through k_tiled_fused's remainder steps, as in round 3)
+    if (M.sb_rows <= kPbRowsMax && !std::getenv("HPRLP_NO_PB_KERNEL")) M.rem_cap = kPbRemCap;
+    if (std::getenv("HPRLP_TIMING"))
+        std::cerr << "[timing] no column locality: all-remainder form with super-blocks of " << M.sb_rows << " rows, remainder steps of " << M.rem_cap
+                  << " entries" << std::endl;
+}
+
 void Solver::choose_sb_rows(const LP_info_cpu *model) {
     A.sb_rows = A.far_group = AT.sb_rows = AT.far_group = kTileRows;
+    A.tile_cols = AT.tile_cols = kTileCols;
+    if (const char *force = std::getenv("HPRLP_TILE_COLS")) {  // tests / A/B runs: one tile width for both matrices
+        A.tile_cols = AT.tile_cols = std::atoi(force) <= kTileColsNarrow ? kTileColsNarrow : kTileCols;
+    }
     if (const char *force = std::getenv("HPRLP_TILE_ROWS")) {  // tests / A/B runs: one height for both matrices
         const int R = std::max(64, std::min(kTileRows, std::atoi(force) / 64 * 64));
         A.sb_rows = A.far_group = AT.sb_rows = AT.far_group = R;
@@ -488,23 +560,8 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     if (comm) return;  // row shards: all columns of the LP against 1 / P of the rows -- full height
     const sparseMatrix *As = model->A;
     const long nnz = As->numElements;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int slots = cus * kTileResidentPerCu;
-    // Heights considered for a matrix of `rows` rows: with k = the rounds the FULL height needs (ceil of its super-blocks over the
-    // slots), the height that fills exactly k rounds.  k = 1: one super-block per slot (mid-size matrices).  k >= 2: the same
-    // number of rounds as now without the partial last one -- only when the full height wastes more than a fifth of its rounds
-    // (6M x 6M, band 6e4: 733 super-blocks = 1.43 rounds run as 2; 1020 of 5888 rows: 1121 -> 1148 it/s; 5M x 5M: 1264 -> 1321;
-    // profiles/r03_ab_rows7.txt).  Nothing to gain below kTileRowsMin (launch-bound matrices: the stream kernel).
-    auto height = [&](int rows) {
-        const int nsb_full = (rows + kTileRows - 1) / kTileRows;
-        const int k = std::max(1, (nsb_full + slots - 1) / slots);
-        if (k > 1 && static_cast<double>(nsb_full) / (static_cast<double>(k) * slots) >= 0.8) return kTileRows;  // rounds nearly full already
-        const int per = (rows + k * slots - 1) / (k * slots);
-        return std::min(kTileRows, (per + 63) / 64 * 64);
-    };
-    const int ra = height(m), rat = height(n);
-    if (nnz < 4000000 || (ra >= kTileRows && rat >= kTileRows) || ra < kTileRowsMin || rat < kTileRowsMin) return;
+    if (nnz < 4000000) return;
+    const int slots = workgroup_slots();
     // median column span of a row without its outermost entries
     std::vector<long> span;
     const int samples = 2048;
@@ -523,8 +580,29 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     }
     if (span.size() < 16) return;
     std::nth_element(span.begin(), span.begin() + span.size() / 2, span.end());
-    const double w_a = static_cast<double>(span[span.size() / 2]);
+    const double w_a = static_cast<double>(std::max<long>(span[span.size() / 2], 1));
     const double slope = static_cast<double>(n) / m;  // columns per row along the "diagonal"
+    // Tile width (round 4).  A row segment of more than kTileChunk entries in one tile goes to the remainder lists WHOLE (34
+    // bytes of traffic per entry against 11 in a tile).  With d entries per row spread over a window of w columns a tile of T
+    // columns holds d T / w of them on average; from about 1.2 on, segments of five and more are common (1M x 1M, band 1e4,
+    // d = 19: 1.95 per 2048-column tile, 10.5 % of the entries in such segments; 1024 columns: 1.2 %).  Narrow tiles halve
+    // the staged bytes per step and leave the number of steps about the same (the wide tiles of such a matrix take two).
+    if (!std::getenv("HPRLP_TILE_COLS")) {
+        const double per_tile_a = static_cast<double>(nnz) / m * kTileCols / w_a;
+        const double per_tile_at = static_cast<double>(nnz) / n * kTileCols / std::max(w_a / slope, 1.0);
+        if (per_tile_a > kNarrowTilesFrom) A.tile_cols = kTileColsNarrow;
+        if (per_tile_at > kNarrowTilesFrom) AT.tile_cols = kTileColsNarrow;
+        if (std::getenv("HPRLP_TIMING"))
+            std::cerr << "[timing] entries of a row per 2048-column tile: " << per_tile_a << " (A), " << per_tile_at << " (A^T) -> tiles of "
+                      << A.tile_cols << " / " << AT.tile_cols << " columns" << std::endl;
+    }
+    // Heights considered for a matrix of `rows` rows: with k = the rounds the FULL height needs (ceil of its super-blocks over the
+    // slots), the height that fills exactly k rounds.  k = 1: one super-block per slot (mid-size matrices).  k >= 2: the same
+    // number of rounds as now without the partial last one -- only when the full height wastes more than a fifth of its rounds
+    // (6M x 6M, band 6e4: 733 super-blocks = 1.43 rounds run as 2; 1020 of 5888 rows: 1121 -> 1148 it/s; 5M x 5M: 1264 -> 1321;
+    // profiles/r03_ab_rows7.txt).  Nothing to gain below kTileRowsMin (launch-bound matrices: the stream kernel).
+    const int ra = whole_rounds_height(m, slots), rat = whole_rounds_height(n, slots);
+    if ((ra >= kTileRows && rat >= kTileRows) || ra < kTileRowsMin || rat < kTileRowsMin) return;
     // bytes of the vector tiles a super-block stages against the bytes of its entries; a height that only trims a partial round
     // may stage a little more (it saves a fifth of the rounds or more)
     const double ratio_a = (w_a + ra * slope) * 8.0 / (static_cast<double>(nnz) / m * ra * 11.0);

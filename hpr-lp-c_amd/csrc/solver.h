@@ -44,6 +44,8 @@ struct DeviceMatrix {
     // shape of the tiled copy, set by the solver before upload() / describe(): rows per super-block (tiled.h: 8192 unless
     // lowered for a mid-size matrix) and columns per source group of the remainder lists (= sb_rows of the OTHER matrix)
     int sb_rows = kTileRows, far_group = kTileRows;
+    int rem_cap = kTileRemCap;  // entries per remainder step (tiled.h: kPbRemCap for the all-remainder form)
+    int tile_cols = kTileCols;  // columns per tile of the copy (tiled.h: kTileCols, or kTileColsNarrow for narrow bands)
     CsrDev view;
     // The tiled copy is built on the host (about a second per 2e8 nonzeros) by a background job started in
     // upload(); until finish_tiling() has run every launch on this matrix uses the stream kernel.  `keep` is held
@@ -104,6 +106,7 @@ struct Solver {
     bool allow_reorder = true;
     bool try_reorder(const LP_info_cpu *model);
     void choose_sb_rows(const LP_info_cpu *model);  // super-block heights of this LP's tiled copies (tiled.h), before the matrices are described
+    void choose_pb_rows(DeviceMatrix &M, DeviceMatrix &other, int rows, int other_rows);  // ... of a matrix without column locality (all-remainder form, tiled.h)
     bool pb_fallback_wanted(const DeviceMatrix &M) const;  // unstructured large matrix: tiled form without dense-tile requirement
     // Hand-off of the remainder products between the two kernels of an iteration (kernels.h: FarPush).  far_A_ready: A's
     // remainder buffer holds the products of the current x_hat (written by the x-half's epilogue); far_AT_ready likewise

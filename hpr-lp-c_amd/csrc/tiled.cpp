@@ -22,8 +22,8 @@ struct Local {  // what one builder thread produces for a contiguous range of su
     long dense = 0, pad = 0;
 };
 
-void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int sb1, Local *L, int R) {
-    const int T = kTileCols, K = kTileChunk;
+void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int sb1, Local *L, int R, int T, int rem_cap) {
+    const int K = kTileChunk;
     const int ntile = (cols + T - 1) / T;
     std::vector<int> cnt(static_cast<size_t>(ntile), 0), slot(static_cast<size_t>(ntile), -1);
     std::vector<int> touched;
@@ -54,7 +54,7 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
         b_begin.clear();
         int dense_total = 0;
         for (int tl : touched) {
-            if (cnt[tl] >= kTileDenseMin) {
+            if (rem_cap != kPbRemCap && cnt[tl] >= kTileDenseMin) {  // (the all-remainder form stages no tile at all)
                 slot[tl] = nd++;
                 b_begin.push_back(dense_total);
                 dense_total += cnt[tl];
@@ -136,7 +136,7 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
         }
         const size_t end = L->rcol.size();
         while (p < end) {
-            const size_t c = std::min<size_t>(end - p, kTileRemCap);
+            const size_t c = std::min<size_t>(end - p, static_cast<size_t>(rem_cap));
             L->steps.push_back(TileStep{0, static_cast<int>(p), static_cast<int>(p + c), 0});
             L->step_is_rem.push_back(1);
             p += c;
@@ -152,12 +152,15 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
 }  // namespace
 
 bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
-                 double min_dense_fraction, int R) {
+                 double min_dense_fraction, int R, int T, int rem_cap) {
     *out = TiledHost();
     if (rows < min_rows || rows <= 0 || cols <= 0) return false;
     const long nnz = rowptr[rows];
     if (nnz <= 0) return false;
     if (R < 64 || R > kTileRows || R % 64 != 0) throw std::runtime_error("tiled build: unsupported super-block height");
+    if (T != kTileCols && T != kTileColsNarrow) throw std::runtime_error("tiled build: unsupported tile width");
+    if (rem_cap != kTileRemCap && rem_cap != kPbRemCap) throw std::runtime_error("tiled build: unsupported remainder step size");
+    if (rem_cap == kPbRemCap && R > kPbRowsMax) throw std::runtime_error("tiled build: the all-remainder form takes super-blocks of at most 4096 rows");
     const int nsb = (rows + R - 1) / R;
     // 16: a GPU's usual share of the host's cores (measured on the 16-CPU quota of the test box: 8 threads 1.01 s
     // of set-up, 16 0.69 s, 32 0.73 s, 64 0.70 s)
@@ -170,7 +173,7 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
     for (int t = 0; t < nt; ++t) {
         const int a = t * per, b = std::min(nsb, a + per);
         if (a >= b) break;
-        th.emplace_back(build_range, rows, cols, rowptr, col, a, b, &loc[t], R);
+        th.emplace_back(build_range, rows, cols, rowptr, col, a, b, &loc[t], R, T, rem_cap);
     }
     for (auto &t : th) t.join();
     long dense = 0, pad = 0;
@@ -221,7 +224,7 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
     return true;
 }
 
-void DeviceTiled::upload(const TiledHost &h, int R) {
+void DeviceTiled::upload(const TiledHost &h, int R, int T, int rem_cap) {
     n_tile = static_cast<long>(h.n_tile);
     n_rem = static_cast<long>(h.n_rem);
     n_steps = static_cast<int>(h.steps.size());
@@ -253,6 +256,8 @@ void DeviceTiled::upload(const TiledHost &h, int R) {
     }
     view.valid = true;
     view.R = R;
+    view.T = T;
+    view.rem_cap = rem_cap;
     view.nsb = nsb;
     view.sb_ptr = sb_ptr.p;
     view.sb_mid = sb_mid.p;

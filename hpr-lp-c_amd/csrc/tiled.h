@@ -29,11 +29,22 @@ namespace hprlp {
 constexpr int kTileThreads = 512;  // workgroup of the tiled kernel (8 waves)
 constexpr int kTileRows = 8192;    // rows per super-block of the tall form: 64 KiB of accumulators in LDS
 constexpr int kTileCols = 2048;    // columns per tile: 16 KiB of the gathered vector in LDS
+constexpr int kTileColsNarrow = 1024;  // round 4: tile width of a copy whose rows would put more than ~1.2 entries into a 2048-column tile
+                                   // (narrow bands: 1M x 1M, band 1e4 -- 10 % of the entries sat in row segments longer than a chunk and
+                                   // went to the 34-bytes-per-entry remainder); TiledDev::T, chosen by Solver::choose_sb_rows
 constexpr int kTileChunk = 4;      // entries per lane per step
 constexpr int kTileStepCap = kTileThreads * kTileChunk;                       // entries per tile step
 constexpr int kTileRemK = (kTileCols * 8 - 8) / (12 * kTileThreads);          // remainder entries per lane per step (8 B product + 4 B code of LDS each)
 constexpr int kTileRemCap = kTileThreads * kTileRemK;                         // (scratch aliases the tile buffer)
 constexpr int kTileRemRun = 16;    // remainder steps in which a row holds more consecutive entries than this are added in two levels (8 / 16 / 32 measured)
+// All-remainder form (round 4; a matrix without column locality: no tile is staged, every entry goes through the
+// propagation-blocking lists): the copy has its own fused kernel (kernels.hip: k_pb_fused) whose LDS holds the accumulators of
+// at most kPbRowsMax rows and remainder steps of kPbRemCap entries -- three times the kTileRemCap of a copy that also stages
+// tiles (16 KiB of scratch there) -- with the step's work compacted over the lanes (kPbRun: entries per work item).
+constexpr int kPbRemK = 6;                        // remainder entries per lane per step
+constexpr int kPbRemCap = kTileThreads * kPbRemK;  // 3072
+constexpr int kPbRowsMax = 4096;
+constexpr int kPbRun = 32;
 constexpr int kTileMaxRow = 1024;  // matrices with a longer row are not tiled: a long row's remainder entries all go through ONE workgroup
                                    // (2M x 2M, five rows of L entries, per launch: L = 1000 192 us, 3000 265-327 us, 8000 433-470 us; stream kernel 262 us)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
@@ -66,6 +77,8 @@ struct TileStep {
 struct TiledDev {
     bool valid = false;
     int R = kTileRows;         // rows per super-block (kTileRowsMin .. kTileRows, multiple of 64)
+    int rem_cap = kTileRemCap; // most entries of a remainder step (kTileRemCap; kPbRemCap for the all-remainder form, which k_pb_fused runs)
+    int T = kTileCols;         // columns per tile of this copy (kTileCols or kTileColsNarrow; the codes keep 11 bits for the local column)
     int G = kTileRows;         // columns per source group of the remainder lists (= R of the matrix whose half-step produces
                                // the gathered vector, so that its epilogue can hand the products over: kernels.h FarPush)
     int nsb = 0;               // super-blocks
@@ -135,7 +148,7 @@ struct TiledHost {
 // Builds the tiled structure of a CSR pattern (rows x cols).  Returns false (and leaves `out` empty)
 // when the matrix is too small or too scattered for the tiled kernel to pay off.
 bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
-                 double min_dense_fraction, int R = kTileRows);
+                 double min_dense_fraction, int R = kTileRows, int T = kTileCols, int rem_cap = kTileRemCap);
 
 // col_c / map_c (device, compact nnz entries): the CSR pattern without the rows whose compact length is zero (tiled_build.hip)
 void compact_without_rows(long nnz, int rows, const int *rp_dev, const int *rp_c_dev, const int *col_dev, int *col_c, int *map_c, hipStream_t s);
@@ -156,7 +169,7 @@ struct DeviceTiled {
     long n_tile = 0, n_rem = 0;
     long dense_entries = 0, padding = 0;
     int n_steps = 0;
-    void upload(const TiledHost &h, int R = kTileRows);
+    void upload(const TiledHost &h, int R = kTileRows, int T = kTileCols, int rem_cap = kTileRemCap);
     void pack_indices(hipStream_t s);  // tidx -> tidx3
     // remainder lists (rcol, rrow, rperm) -> the propagation-blocking lists with source groups of G columns
     void build_far(int cols, hipStream_t s, int G = kTileRows);
@@ -181,7 +194,7 @@ struct DeviceTiled {
     // Builds the same structure from the DEVICE CSR index arrays (tiled_build.hip); false: declined (too small,
     // too scattered, or too large for 32-bit entry offsets) and nothing is valid.
     bool build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
-                         double min_dense_fraction, hipStream_t s, int R = kTileRows);
+                         double min_dense_fraction, hipStream_t s, int R = kTileRows, int T = kTileCols, int rem_cap = kTileRemCap);
     // throws std::runtime_error naming the first difference between this (device-built) copy and the host builder's
     void compare_with(const TiledHost &h) const;
 };

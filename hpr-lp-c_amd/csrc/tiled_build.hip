@@ -25,7 +25,7 @@ namespace hprlp {
 
 namespace {
 
-constexpr int T = kTileCols, K = kTileChunk;
+constexpr int K = kTileChunk;  // (the tile width T is a property of the copy: kTileCols or kTileColsNarrow)
 constexpr int kRowBits = kTileRowBits;  // the key and the entry codes pack the local row in 13 bits whatever the height R (<= 8192)
 
 __device__ __forceinline__ int row_of_entry(const int *__restrict__ rowptr, int rows, int k) {
@@ -38,7 +38,7 @@ __device__ __forceinline__ int row_of_entry(const int *__restrict__ rowptr, int 
     return lo;
 }
 
-__global__ void __launch_bounds__(kThreads) k_make_keys(long nnz, int rows, int tile_bits, int R, const int *__restrict__ rowptr,
+__global__ void __launch_bounds__(kThreads) k_make_keys(long nnz, int rows, int tile_bits, int R, int T, const int *__restrict__ rowptr,
                                                        const int *__restrict__ col, unsigned long long *__restrict__ key,
                                                        int *__restrict__ idx) {
     const long k = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
@@ -155,7 +155,7 @@ __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long 
     return len_out;
 }
 
-__global__ void __launch_bounds__(kWalkThreads) k_run_pass1(int nruns, const int *__restrict__ run_start,
+__global__ void __launch_bounds__(kWalkThreads) k_run_pass1(int nruns, bool all_rem, const int *__restrict__ run_start,
                                                            const unsigned long long *__restrict__ skey, char *__restrict__ flag_sorted,
                                                            int *__restrict__ padded_len, int *__restrict__ nsteps,
                                                            unsigned long long *__restrict__ totals) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_run_pass1(int nruns, const int
     const int r = blockIdx.x * kWalkThreads + threadIdx.x;
     if (r >= nruns) return;
     const int begin = run_start[r], end = run_start[r + 1];
-    if (end - begin < kTileDenseMin) {
+    if (all_rem || end - begin < kTileDenseMin) {  // (all_rem: the all-remainder form stages no tile at all, tiled.h)
         for (int q = begin; q < end; ++q) flag_sorted[q] = 1;
         padded_len[r] = 0;
         nsteps[r] = 0;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(kThreads) k_first_run_of_sb(int nsb, int nruns
     first_run[sb] = lo;
 }
 
-__global__ void __launch_bounds__(kWalkThreads) k_run_pass2(int nruns, int tile_bits, const int *__restrict__ run_start,
+__global__ void __launch_bounds__(kWalkThreads) k_run_pass2(int nruns, int tile_bits, int T, const int *__restrict__ run_start,
                                                        const unsigned long long *__restrict__ skey, const int *__restrict__ sperm,
                                                        const int *__restrict__ padded_len, const int *__restrict__ run_off,
                                                        const int *__restrict__ run_step_off, const int *__restrict__ first_run,
@@ -247,12 +247,12 @@ __global__ void __launch_bounds__(kThreads) k_fill_remainder(int n_rem, int rows
     rrow[e] = static_cast<uint16_t>(row_of_entry(rowptr, rows, k) % R);
 }
 
-__global__ void __launch_bounds__(kThreads) k_rem_steps(int nsb, const int *__restrict__ sb_mid, const int *__restrict__ rem_before,
+__global__ void __launch_bounds__(kThreads) k_rem_steps(int nsb, int rem_cap, const int *__restrict__ sb_mid, const int *__restrict__ rem_before,
                                                        TileStep *__restrict__ steps) {
     const int sb = blockIdx.x * kThreads + threadIdx.x;
     if (sb >= nsb) return;
     const int b = rem_before[sb], e = rem_before[sb + 1];
-    for (int p = b, j = 0; p < e; p += kTileRemCap, ++j) steps[sb_mid[sb] + j] = TileStep{0, p, min(e, p + kTileRemCap), 0};
+    for (int p = b, j = 0; p < e; p += rem_cap, ++j) steps[sb_mid[sb] + j] = TileStep{0, p, min(e, p + rem_cap), 0};
 }
 
 inline unsigned grid_for(long n) { return static_cast<unsigned>((n + kThreads - 1) / kThreads); }
@@ -289,7 +289,7 @@ void DeviceTiled::pack_indices(hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-__global__ void __launch_bounds__(kThreads) k_window_widths(int nsb, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
+__global__ void __launch_bounds__(kThreads) k_window_widths(int nsb, int T, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
                                                            const TileStep *__restrict__ steps, unsigned long long *__restrict__ out) {
     const int sb = blockIdx.x * kThreads + threadIdx.x;
     if (sb >= nsb) return;
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(kThreads) k_window_widths(int nsb, const int *
     if (rep) atomicAdd(out + 2, static_cast<unsigned long long>(rep));
 }
 
-__global__ void __launch_bounds__(kThreads) k_rotation(int nsb, int period, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
+__global__ void __launch_bounds__(kThreads) k_rotation(int nsb, int period, int T, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
                                                       TileStep *__restrict__ steps) {
     const int sb = blockIdx.x * kThreads + threadIdx.x;
     if (sb >= nsb) return;
@@ -338,6 +338,7 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
     int want = (nsb > 0 && nsb <= resident * 8) ? resident * 8 : 0;
     // a lowered super-block height (tiled.h) was chosen so that the slots get whole super-blocks: pieces only below one per CU
     if (view.R < kTileRows && nsb >= cus) want = 0;
+    if (view.rem_cap != kTileRemCap) want = 0;  // (k_tiled_part adds remainder steps of kTileRemCap entries; the all-remainder form has its own fused kernel)
     if (const char *e = std::getenv("HPRLP_TILE_PIECES")) want = std::max(0, std::atoi(e));
     if (want > 0 && nsb > 0) {
         std::vector<int> h_ptr(static_cast<size_t>(nsb) + 1), h_mid(static_cast<size_t>(nsb));
@@ -413,7 +414,7 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
     {
         DBuf<unsigned long long> acc(3);
         HIP_CHECK(hipMemsetAsync(acc.p, 0, 3 * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(k_window_widths, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, acc.p);
+        hipLaunchKernelGGL(k_window_widths, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, view.T, sb_ptr.p, sb_mid.p, steps.p, acc.p);
         unsigned long long h[3] = {0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -421,14 +422,17 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
         view.repeats = h[2] > 0;
     }
     if (const char *e = std::getenv("HPRLP_TILE_ROT")) rot_period = std::atoi(e);
-    if (rot_period > 0) hipLaunchKernelGGL(k_rotation, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, rot_period, sb_ptr.p, sb_mid.p, steps.p);
+    if (rot_period > 0) hipLaunchKernelGGL(k_rotation, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, rot_period, view.T, sb_ptr.p, sb_mid.p, steps.p);
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
 bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowptr, const int *col, int min_rows,
-                                  double min_dense_fraction, hipStream_t s, int R) {
+                                  double min_dense_fraction, hipStream_t s, int R, int T, int rem_cap) {
+    if (rem_cap != kTileRemCap && rem_cap != kPbRemCap) throw std::runtime_error("tiled build: unsupported remainder step size");
+    if (rem_cap == kPbRemCap && R > kPbRowsMax) throw std::runtime_error("tiled build: the all-remainder form takes super-blocks of at most 4096 rows");
     if (rows < min_rows || rows <= 0 || cols <= 0 || nnz <= 0 || nnz >= 2000000000L) return false;
     if (R < 64 || R > kTileRows || R % 64 != 0) throw std::runtime_error("tiled build: unsupported super-block height");
+    if (T != kTileCols && T != kTileColsNarrow) throw std::runtime_error("tiled build: unsupported tile width");
     const int nsb = (rows + R - 1) / R;
     const int ntile = (cols + T - 1) / T;
     int tile_bits = 1;
@@ -439,7 +443,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
 
     DBuf<unsigned long long> key_in(static_cast<size_t>(nnz)), skey(static_cast<size_t>(nnz));
     DBuf<int> idx_in(static_cast<size_t>(nnz)), sperm(static_cast<size_t>(nnz));
-    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, rows, tile_bits, R, rowptr, col, key_in.p, idx_in.p);
+    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, rows, tile_bits, R, T, rowptr, col, key_in.p, idx_in.p);
     size_t tmp_bytes = 0;
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), 0,
                                                  key_bits, s));
@@ -481,7 +485,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     totals.alloc_zero(2);
     HIP_CHECK(hipMemsetAsync(padded_len.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
     HIP_CHECK(hipMemsetAsync(nsteps.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
-    hipLaunchKernelGGL(k_run_pass1, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, run_start.p, skey.p, flag_sorted.p, padded_len.p,
+    hipLaunchKernelGGL(k_run_pass1, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, rem_cap == kPbRemCap, run_start.p, skey.p, flag_sorted.p, padded_len.p,
                        nsteps.p, totals.p);
     unsigned long long tot[2] = {0, 0};
     HIP_CHECK(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, s));
@@ -529,7 +533,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
         h_sb_ptr[sb] = h_dsteps[sb] + rsteps_before;
         if (sb < nsb) {
             h_sb_mid[sb] = h_sb_ptr[sb] + (h_dsteps[sb + 1] - h_dsteps[sb]);
-            rsteps_before += (h_rem[sb + 1] - h_rem[sb] + kTileRemCap - 1) / kTileRemCap;
+            rsteps_before += (h_rem[sb + 1] - h_rem[sb] + rem_cap - 1) / rem_cap;
         }
     }
     const int total_steps = h_sb_ptr[nsb];
@@ -543,7 +547,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     tidx.alloc_zero(static_cast<size_t>(n_tile) + 8);
     tperm.alloc(static_cast<size_t>(n_tile) + 8);
     tval.alloc_zero(static_cast<size_t>(n_tile) + 8);
-    hipLaunchKernelGGL(k_run_pass2, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, tile_bits, run_start.p, skey.p, sperm.p, padded_len.p,
+    hipLaunchKernelGGL(k_run_pass2, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, tile_bits, T, run_start.p, skey.p, sperm.p, padded_len.p,
                        run_off.p, run_step_off.p, first_run.p, sb_ptr.p, col, tidx.p, tperm.p, steps.p);
     rcol.alloc_zero(static_cast<size_t>(n_rem) + 8);
     rperm.alloc(static_cast<size_t>(n_rem) + 8);
@@ -559,7 +563,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
                            rperm.p, rcol.p, rrow.p);
         HIP_CHECK(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(k_rem_steps, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, sb_mid.p, rem_before.p, steps.p);
+    hipLaunchKernelGGL(k_rem_steps, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, rem_cap, sb_mid.p, rem_before.p, steps.p);
     HIP_CHECK(hipStreamSynchronize(s));
 
     dense_entries = static_cast<long>(tot[0]);
@@ -568,6 +572,8 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     view = TiledDev();
     view.valid = true;
     view.R = R;
+    view.T = T;
+    view.rem_cap = rem_cap;
     view.nsb = nsb;
     view.sb_ptr = sb_ptr.p;
     view.sb_mid = sb_mid.p;
@@ -839,6 +845,24 @@ void DeviceTiled::dump_wgtimes() const {
         if (h[w * 8] == 0) continue;
         t0 = std::min(t0, h[w * 8]);
         t1 = std::max(t1, h[w * 8 + 7]);
+    }
+    if (std::getenv("HPRLP_PB_STAMPS")) {  // developer build -DHPRLP_DBG_PBSTAMP=1: the slots hold phase durations of k_pb_fused (100 MHz ticks)
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+        for (int w = 0; w < view.grid; ++w) {
+            if (h[w * 8 + 7] == 0) continue;
+            ++cnt;
+            for (int i = 0; i < 8; ++i) {
+                sum[i] += h[w * 8 + i] / 100.0;
+                mx[i] = std::max(mx[i], h[w * 8 + i] / 100.0);
+            }
+        }
+        if (cnt)
+            std::fprintf(stderr, "[pb stamps] %d workgroups, mean (max) us: wait+barrier %.1f (%.1f) | stage %.1f (%.1f) | flags+scan %.1f (%.1f) | level 1 %.1f (%.1f) | "
+                                 "level 2 %.1f (%.1f) | epilogue %.1f (%.1f) | push %.1f (%.1f) | total %.1f (%.1f)\n",
+                         cnt, sum[0] / cnt, mx[0], sum[1] / cnt, mx[1], sum[2] / cnt, mx[2], sum[3] / cnt, mx[3], sum[4] / cnt, mx[4], sum[5] / cnt, mx[5],
+                         sum[6] / cnt, mx[6], sum[7] / cnt, mx[7]);
+        return;
     }
     if (t1 == 0) return;
     if (const char *f = std::getenv("HPRLP_WG_TIMES_DUMP")) {

@@ -134,6 +134,69 @@ def test_unstructured_large_matrix_runs_propagation_blocking(gpu):
     model.free()
 
 
+def test_all_remainder_kernel_matches_oracle(gpu):
+    """k_pb_fused (kernels.hip, round 4) under the oracle.  A 900 k x 1.1 M LP with 12 uniformly random columns per row plus a
+    few rows and columns of several hundred entries: no ordering helps, both matrices take the all-remainder form -- every
+    entry's product travels through P, a super-block's rows are summed by the lane-chunk segmented reduction (rows of 12
+    span two or three lanes, the long ones whole waves and wave boundaries), the half-steps hand the products over to each
+    other.  All iterate vectors of reference src/cuda_kernels/HPR_cuda_kernels.cu:203-295 against the oracle at 1e-11 over
+    normal and check iterations, one residual evaluation (src/main_iterate.cu:229-309), lambda_max, and the Curtis-Reid
+    scaling through the same kernel."""
+    rng = np.random.default_rng(77)
+    m, n, per_row = 900_000, 1_100_000, 12
+    cols = np.sort(rng.integers(0, n, size=(m, per_row)), axis=1)
+    keep = np.ones((m, per_row), bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    r_idx = np.repeat(np.arange(m), keep.sum(axis=1))
+    c_idx = cols[keep]
+    extra_r, extra_c = [], []
+    for i, L in zip(rng.choice(m, 6, replace=False), (70, 130, 400, 700, 900, 1000)):      # long rows of A (<= kTileMaxRow)
+        extra_r.append(np.full(L, i)); extra_c.append(rng.choice(n, L, replace=False))
+    for j, L in zip(rng.choice(n, 5, replace=False), (90, 300, 650, 800, 990)):             # long columns (= rows of A^T)
+        extra_r.append(rng.choice(m, L, replace=False)); extra_c.append(np.full(L, j))
+    r_idx = np.concatenate([r_idx] + extra_r); c_idx = np.concatenate([c_idx] + extra_c)
+    A = sparse.csr_matrix((np.ones(len(r_idx)), (r_idx, c_idx)), shape=(m, n))
+    A.sum_duplicates()
+    A.data = rng.normal(size=A.nnz) * 10.0 ** rng.uniform(-1, 1, size=A.nnz)
+    A.sort_indices()
+    assert np.diff(A.indptr).max() <= 1024 and np.bincount(A.indices, minlength=n).max() <= 1024
+    x0 = rng.uniform(0, 1, size=n)
+    b = A @ x0
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    AL, AU = np.where(rng.random(m) < 0.5, b, -np.inf), b + np.where(rng.random(m) < 0.5, 0.0, 1.0)
+    l, u, c = np.zeros(n), np.where(rng.random(n) < 0.3, 2.0, np.inf), rng.normal(size=n)
+    model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, c)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    d = s.describe()
+    assert s.info()["tiled"] == 3 and not s.info()["reordered"], d
+    assert d.count("0 % of the entries in staged tiles") == 2 and "piece form" not in d, d
+    ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, c, O.Params.default())
+    s.scale()
+    # the Curtis-Reid passes ran through k_pb_fused<CrEpi> on -log|a|: same scaled matrix as the oracle's (device exp / log)
+    for name, want in (("A_val", ref.Av), ("AT_val", ref.ATv), ("row_norm", ref.row_norm), ("col_norm", ref.col_norm), ("c", ref.c)):
+        np.testing.assert_allclose(s.get(name), want, rtol=1e-11, atol=1e-300, err_msg=name)
+    from test_gpu_kernels import adopt_gpu_data
+    adopt_gpu_data(s, ref)
+    sigma, lam = 0.6, 1.4
+    st = run_steps(s, ref, sigma, lam, [(17, True), (3, True), (6, False)])
+    for name in NAMES_N + NAMES_M:
+        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+    got = s.residuals(150, True)
+    sc = ref.sc
+    obj_scale = sc.b_scale * sc.c_scale
+    pobj = obj_scale * (ref.c @ st["x_bar"])
+    ATy = O.spmv(ref.n, ref.ATrp, ref.ATci, ref.ATv, st["y_bar"])
+    Ax = O.spmv(ref.m, ref.Arp, ref.Aci, ref.Av, st["x_bar"])
+    rd = np.linalg.norm((ref.c - ATy - st["z_bar"]) * ref.col_norm) * sc.c_scale / sc.norm_c_org
+    rp_ = np.linalg.norm(np.maximum(np.minimum(ref.AU - Ax, 0.0), ref.AL - Ax) * ref.row_norm) * sc.b_scale / sc.norm_b_org
+    assert abs(got["primal_obj"] - pobj) <= 1e-11 * (1 + abs(pobj))
+    assert abs(got["err_Rd"] - rd) <= 1e-10 * rd and abs(got["err_Rp"] - rp_) <= 1e-10 * rp_
+    lam_g, it = s.power_iteration(max_iter=40)
+    lam_ref, it_ref = ref.power_iteration(max_iter=40)
+    assert it == it_ref and abs(lam_g - lam_ref) <= 1e-11 * lam_ref
+    s.close(); model.free()
+
+
 def test_permuted_grid_is_reordered_on_the_device(gpu):
     """A five-point grid (large diameter: BFS balls grow polynomially, the Voronoi clustering needs ~100 levels) in random
     numbering: the device clustering + ordering must make it tileable, and the iterates must match the oracle."""

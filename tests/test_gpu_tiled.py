@@ -249,12 +249,14 @@ def test_multi_round_persistent_schedule_matches_oracle(gpu, force_tiled):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("rows_sb,pieces", [(1984, None), (3008, None), (2048, 5)])
-def test_lowered_super_block_height_matches_oracle(gpu, force_tiled, rows_sb, pieces):
+@pytest.mark.parametrize("rows_sb,pieces,tile_cols", [(1984, None, 2048), (3008, None, 2048), (2048, 5, 2048), (1984, None, 1024), (8192, 7, 1024)])
+def test_lowered_super_block_height_matches_oracle(gpu, force_tiled, rows_sb, pieces, tile_cols):
     """Super-blocks of fewer than 8192 rows (tiled.h: one super-block per workgroup slot for mid-size matrices; any multiple of
     64): fused form, hand-off between the half-steps (a source group of one matrix' remainder = a super-block of the other)
-    and the piece form on top of it -- same iterates as the oracle, device and host builders equal array for array."""
-    old = {k: os.environ.get(k) for k in ("HPRLP_TILE_ROWS", "HPRLP_TILE_PIECES", "HPRLP_TILING_CHECK")}
+    and the piece form on top of it -- same iterates as the oracle, device and host builders equal array for array.  Round 4:
+    the same with tiles of 1024 columns (tiled.h: kTileColsNarrow, what a narrow band gets from Solver::choose_sb_rows)."""
+    old = {k: os.environ.get(k) for k in ("HPRLP_TILE_ROWS", "HPRLP_TILE_PIECES", "HPRLP_TILING_CHECK", "HPRLP_TILE_COLS")}
+    os.environ["HPRLP_TILE_COLS"] = str(tile_cols)
     os.environ["HPRLP_TILE_ROWS"] = str(rows_sb)
     os.environ["HPRLP_TILING_CHECK"] = "1"  # (the host builder needs host column indices: both matrices have them below 4 M entries)
     os.environ["HPRLP_TILE_PIECES"] = str(pieces or 0)  # (0: the fused form although the test matrix has few super-blocks)
@@ -266,6 +268,7 @@ def test_lowered_super_block_height_matches_oracle(gpu, force_tiled, rows_sb, pi
         d = s.describe()
         assert f"{-(-m // rows_sb)} super-blocks" in d and f"{-(-n // rows_sb)} super-blocks" in d, d
         assert ("piece form" in d) == bool(pieces), d
+        assert ("tiles of 1024 columns" in d) == (tile_cols == 1024), d
         ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
                          O.Params.default(use_CR_scaling=0))
         s.scale()
@@ -297,6 +300,7 @@ def test_mid_size_banded_lp_gets_one_super_block_per_slot(gpu):
     d = s.describe()
     s.close()
     assert "tiled, fused" in d and "piece form" not in d and "stream kernel" not in d, d
+    assert d.count("tiles of 1024 columns") == 2, d   # ~2 entries of a row per 2048-column tile: narrow tiles (choose_sb_rows)
     import re
     nsb = [int(x) for x in re.findall(r"(\d+) super-blocks", d)]
     assert len(nsb) == 2 and all(384 <= k <= 512 for k in nsb), d

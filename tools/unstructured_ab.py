@@ -39,8 +39,8 @@ print("RESULT tiled=%%d reordered=%%d  x %%.4f ms  y %%.4f ms" %% (info["tiled"]
 
 sizes = [float(a) for a in sys.argv[1:]] or [0.5, 1.0, 2.0, 3.0, 4.2]
 for sz in sizes:
-    for name, env in (("stream", {"HPRLP_NO_PB_FALLBACK": "1"}), ("all-remainder tiled", {"HPRLP_PB_MIN_COLS": "1"})):
+    for name, env in (("stream", {"HPRLP_NO_PB_FALLBACK": "1"}), ("all-remainder tiled", {"HPRLP_PB_MIN_COLS": "1", "HPRLP_TILED_MIN_COLS": "1"})):
         e = dict(os.environ, **env)
-        r = subprocess.run([sys.executable, "-c", CHILD, str(sz), "10"], env=e, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", CHILD, str(sz), os.environ.get("AB_PER_ROW", "10")], env=e, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stderr.splitlines() if l.startswith("RESULT")]
-        print("%4.1fM x %4.1fM, 10/row  %-20s %s" % (sz, sz, name, line[0] if line else "FAILED " + r.stderr[-300:]), flush=True)
+        print("%4.2fM x %4.2fM, %s/row  %-20s %s" % (sz, sz, os.environ.get("AB_PER_ROW", "10"), name, line[0] if line else "FAILED " + r.stderr[-300:]), flush=True)
