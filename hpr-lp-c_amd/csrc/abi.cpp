@@ -775,7 +775,8 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
             return d;
         }
         d += t.n_pieces > 0 ? "tiled, piece form (k_tiled_part + k_tiled_finish, " + std::to_string(t.n_pieces) + " pieces)"
-                            : "tiled, fused (k_tiled_fused, grid " + std::to_string(t.grid) + ")";
+             : t.rem_cap == kPbRemCap ? "tiled, all-remainder form (k_pb_fused, grid " + std::to_string(t.grid) + ")"
+                                      : "tiled, fused (k_tiled_fused, grid " + std::to_string(t.grid) + ")";
         d += ", " + std::to_string(t.nsb) + " super-blocks, " + std::to_string(M.tiled.n_steps) + " steps";
         if (t.R != kTileRows || t.T != kTileCols) d += " (" + std::to_string(t.R) + " rows, tiles of " + std::to_string(t.T) + " columns)";
         const double all = static_cast<double>(M.tiled.dense_entries) + static_cast<double>(M.tiled.n_rem);

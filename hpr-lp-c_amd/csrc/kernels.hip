@@ -557,122 +557,213 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
 #endif
 }
 
-// Sum of the products of entries j0, j0 + 1, ... of a remainder step while they belong to row `rw` and stay below `lim`, added to
-// `sum` in that order (the step's entries are in (row, CSR) order; rq[e + 1] = slot << 16 | row of entry e, prod[slot] its product).
-// One LDS read decides whether the run goes on at all (most rows of a banded matrix hold ONE far entry); a run that does is read
-// eight codes, then eight products at a time -- independent reads, one LDS latency per batch instead of two per entry (a row of
-// 20 remainder entries -- every row of a matrix without column locality -- was a chain of 40 dependent LDS reads).
-__device__ __forceinline__ double rem_run_sum(const double *prod, const uint32_t *rq, int j0, int lim, int cnt, uint32_t rw, double sum) {
-    int j = j0;
-    if (j >= lim || (rq[j + 1] & 0xffffu) != rw) return sum;
-    while (true) {
-        uint32_t q[8];
-        double p[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = rq[min(j + u, cnt - 1) + 1];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = prod[q[u] >> 16];
-        // no branch per entry (eight live lane masks were eight scalar register pairs of the kernel's budget): a product
-        // behind the end of the run is replaced by zero -- sum + 0.0 is sum
-        int go = 1, n = 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            go &= static_cast<int>((j + u < lim) & ((q[u] & 0xffffu) == rw));
-            sum += go ? p[u] : 0.0;
-            n += go;
-        }
-        j += 8;
-        if (n < 8 || j >= lim) return sum;
-    }
-}
-
-// Remainder steps [smid, s1) of a super-block (propagation blocking, tiled.h): the products were written by
-// k_far_products into this super-block's slice of P; a step streams its range of P into the tile buffer (coalesced)
-// next to the step's entry codes in (row, CSR) order, then one head lane per row segment adds that row's products in order.
-__device__ __forceinline__ void tiled_remainder(const TiledDev &t, int smid, int s1, double *acc, double *ytile, int tid) {
-    constexpr int NT = kTileThreads;
+// Remainder steps [smid, s1) of a super-block (propagation blocking, tiled.h): the products were written into this
+// super-block's slice of P -- by k_far_products, or by the other half-step's epilogue (hand-off) -- in (source group) order; the
+// step's codes (slot in the step << 16 | local row) are in (row, CSR) order.  A step: the products go to LDS (`prod`, K per
+// lane, coalesced); lane l takes entries K l .. K l + K - 1 of the (row, CSR) order -- its codes come straight from memory into
+// registers -- gathers their products from LDS and adds them up per row: rows that begin and end inside the chunk on the
+// spot, the run at the chunk's start and the run at its end through a segmented scan over the lanes of the wave (a row's
+// pieces are the tail of one lane, whole lanes, the head of a last one), a wave's last run through LDS after the barrier
+// (`bnd`: its first lane takes no carry from the wave before).  All lanes work, three LDS barriers per step, a row of any
+// length costs the same per entry.  (Until round 4 ONE head lane per row read code and product alternately -- two dependent LDS
+// reads per entry: a matrix without column locality, 20 entries per row all in here, spent 0.28 ms on 4e7 entries.)
+// Per-row order of the additions: fixed by the matrix (chunks in order, the scan's tree inside a wave).
+// bnd: kTileThreads / 64 doubles of LDS for the values, then as many 32-bit words for the rows.
+template <int K>
+__device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int s1, double *acc, double *prod, double *bnd, int tid) {
+    constexpr int NT = kTileThreads, NW = kTileThreads / 64;
+    static_assert(K == 4 || K == 6, "code loads: one 16-byte or two 12-byte loads per lane");
     if (smid >= s1) return;
-    double *prod = ytile;
-    uint32_t *rq = reinterpret_cast<uint32_t *>(ytile + kTileRemCap);
-    // the loads of step s + 1 (P and the entry codes: two HBM round trips without it) are in flight while step s is folded
-    double pv[kTileRemK];
-    uint32_t qv[kTileRemK];
+    const int wave = tid >> 6, lane = tid & 63;
+    double *bnd_val = bnd;
+    uint32_t *bnd_row = reinterpret_cast<uint32_t *>(bnd + NW);
+    constexpr uint32_t NOROW = 0x10000u;  // (codes keep the row in 16 bits)
+    // the loads of step s + 1 are in flight while step s is folded
+    double pv[K];
+    uint32_t cv[K];
     TileStep st = t.steps[smid];
-    auto issue = [&](const TileStep &q) {
+    auto issue = [&](const TileStep &z) {
+        const int last = max(z.e_end - z.e_begin - 1, 0);
 #pragma unroll
-        for (int k = 0; k < kTileRemK; ++k) {
-            const int el = min(tid + k * NT, max(q.e_end - q.e_begin - 1, 0));  // clamped: branch-free, the surplus lanes' values are not stored
-            pv[k] = __builtin_nontemporal_load(t.P + q.e_begin + el);
-            qv[k] = __builtin_nontemporal_load(t.rq + q.e_begin + el);
+        for (int k = 0; k < K; ++k) pv[k] = __builtin_nontemporal_load(t.P + z.e_begin + min(tid + k * NT, last));  // clamped: branch-free
+        // the lane's K consecutive codes in wide loads (4-byte aligned); behind the step's end the last whole chunk is read
+        const int c0 = min(K * tid, max(last + 1 - K, 0));
+        if constexpr (K == 6) {
+            typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));
+            const u3_t w0 = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.rq + z.e_begin + c0));
+            const u3_t w1 = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.rq + z.e_begin + c0 + 3));
+            cv[0] = w0.x; cv[1] = w0.y; cv[2] = w0.z; cv[3] = w1.x; cv[4] = w1.y; cv[5] = w1.z;
+        } else {
+            typedef uint32_t u4_t __attribute__((ext_vector_type(4), aligned(4)));
+            const u4_t w0 = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(t.rq + z.e_begin + c0));
+            cv[0] = w0.x; cv[1] = w0.y; cv[2] = w0.z; cv[3] = w0.w;
         }
     };
     issue(st);
     for (int s = smid; s < s1; ++s) {
         const int cnt = st.e_end - st.e_begin;
         const TileStep nxt = t.steps[min(s + 1, s1 - 1)];
-        lds_barrier();
+        lds_barrier();  // everybody is done with the previous step's products and row sums
 #pragma unroll
-        for (int k = 0; k < kTileRemK; ++k) {
+        for (int k = 0; k < K; ++k) {
             const int el = tid + k * NT;
-            if (el < cnt) {
-                prod[el] = pv[k];
-                rq[el + 1] = qv[k];
+            if (el < cnt) prod[el] = pv[k];
+        }
+        // (a lane whose chunk crosses the step's end loaded the LAST whole chunk instead: move its codes down)
+        uint32_t code[K];
+        {
+            const int shift = K * tid - min(K * tid, max(cnt - K, 0));  // 0 for every lane but at most one
+#pragma unroll
+            for (int u = 0; u < K; ++u) code[u] = cv[u];
+            if (shift > 0 && shift < K) {
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int q = 0; q < K; ++q) c = (q == u + shift) ? cv[q] : c;
+                    code[u] = c;
+                }
             }
         }
-        if (tid == 0) rq[0] = 0xffffu;
         if (s + 1 < s1) issue(nxt);
         lds_barrier();
-        if (st.col0 != 0) {
-            // A row with a long run in this step (marked by the builder; uniform): two levels.  Level 1: every entry at a
-            // row change or at a multiple of kTileRemRun adds the products up to the next such entry and leaves the partial
-            // sum in its own product slot (nobody else reads that slot); level 2: the entry at the row change adds the
-            // partials.  (One lane adding a 1000-entry run -- two dependent LDS reads per product -- was 55 us; a tree of
-            // fan-in 4 with a barrier per level measured slower than these two levels.)
+        // this lane's chunk, sorted by row.  Entries behind the step's end continue the last valid row with a zero product; a
+        // lane without any entry holds NOROW.
+        const int nv = min(max(cnt - K * tid, 0), K);
+        uint32_t row[K];
+        double pr[K];
 #pragma unroll
-            for (int k = 0; k < kTileRemK; ++k) {
-                const int el = tid + k * NT;
-                if (el < cnt) {
-                    const uint32_t w = rq[el + 1];
-                    const uint32_t rw = w & 0xffffu;
-                    if ((rq[el] & 0xffffu) != rw || (el % kTileRemRun) == 0) {
-                        const int lim = min(cnt, (el / kTileRemRun + 1) * kTileRemRun);
-                        prod[w >> 16] = rem_run_sum(prod, rq, el + 1, lim, cnt, rw, 0.0 + prod[w >> 16]);
-                    }
-                }
-            }
-            lds_barrier();
-#pragma unroll
-            for (int k = 0; k < kTileRemK; ++k) {
-                const int el = tid + k * NT;
-                if (el < cnt) {
-                    const uint32_t w = rq[el + 1];
-                    const uint32_t rw = w & 0xffffu;
-                    if ((rq[el] & 0xffffu) != rw) {
-                        double sacc = acc[rw];
-                        int j = el;
-                        uint32_t q = w;
-                        do {
-                            sacc += prod[q >> 16];
-                            j = (j / kTileRemRun + 1) * kTileRemRun;
-                            q = rq[min(j, cnt - 1) + 1];
-                        } while (j < cnt && (q & 0xffffu) == rw);
-                        acc[rw] = sacc;
-                    }
-                }
-            }
-            st = nxt;
-            continue;
+        for (int u = 0; u < K; ++u) {
+            const bool ok = u < nv;
+            row[u] = ok ? (code[u] & 0xffffu) : (u == 0 ? NOROW : row[u - 1]);
+            pr[u] = ok ? prod[code[u] >> 16] : 0.0;
         }
+        // in-lane: the run that starts at entry 0 (head), rows that begin and end inside the chunk (added on the spot: nobody
+        // else holds entries of theirs in this step), the run that ends at entry K - 1 (tail)
+        double run = pr[0], head = 0.0;
+        bool single = true;
 #pragma unroll
-        for (int k = 0; k < kTileRemK; ++k) {
-            const int el = tid + k * NT;
-            if (el < cnt) {
-                const uint32_t w = rq[el + 1];
-                const uint32_t rw = w & 0xffffu;
-                if ((rq[el] & 0xffffu) != rw) acc[rw] = rem_run_sum(prod, rq, el + 1, cnt, cnt, rw, acc[rw] + prod[w >> 16]);
+        for (int u = 1; u < K; ++u) {
+            if (row[u] != row[u - 1]) {
+                if (single) {
+                    head = run;
+                    single = false;
+                } else {
+                    acc[row[u - 1]] += run;
+                }
+                run = pr[u];
+            } else {
+                run += pr[u];
             }
+        }
+        const uint32_t rf = row[0], rl = row[K - 1];
+        // segmented inclusive scan of the lanes' carry-outs (the tail, or everything for a one-row lane); a lane passes the
+        // carry on iff it holds one row and continues its predecessor's
+        const uint32_t rl_prev = __shfl_up(rl, 1, 64);
+        const bool open_in = lane > 0 && rf == rl_prev && rf != NOROW;
+        double v = run;
+        int f = (single && open_in) ? 0 : 1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double vu = __shfl_up(v, off, 64);
+            const int fu = __shfl_up(f, off, 64);
+            if (lane >= off && !f) {
+                v += vu;
+                f |= fu;
+            }
+        }
+        const double v_prev = __shfl_up(v, 1, 64);
+        const double carry = open_in ? v_prev : 0.0;
+        const int next_open = __shfl_down(static_cast<int>(open_in), 1, 64);
+        if (!single) acc[rf] += carry + head;  // the head's row ends in this lane
+        const double tail = single ? carry + run : run;
+        if (lane == 63) {
+            // the wave's last run may go on in the next wave (whose first lane takes no carry): added after the barrier
+            bnd_row[wave] = rl;
+            bnd_val[wave] = tail;
+        } else if (!next_open && rl != NOROW) {
+            acc[rl] += tail;
+        }
+        lds_barrier();
+        if (tid < NW) {
+            // the waves' last runs, one lane each; a row that fills whole waves appears more than once: the lane of its last
+            // appearance adds them all, in wave order
+            const uint32_t rw = bnd_row[tid];
+            bool last_one = rw != NOROW;
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const bool same = bnd_row[w] == rw;
+                if (w <= tid && same) tot += bnd_val[w];
+                if (w > tid && same) last_one = false;
+            }
+            if (last_one) acc[rw] += tot;
         }
         st = nxt;
+    }
+}
+
+// Epilogue of a super-block (k_tiled_fused, k_pb_fused): row i of the block has its sum in acc[i]; the half-step / residual /
+// dot epilogue runs on it, and with PUSH the value the half-step publishes replaces the sum (the hand-off reads it from there).
+// Four rows per lane at a time, all their loads before the first update: one trip to memory per four rows instead of one
+// per row (the update's stores may alias the next row's loads as far as the compiler knows, so it kept them in order:
+// a 1984-row super-block of a mid-size matrix spent 8 us of its 96 in four such trips).
+template <class Epi, bool PUSH>
+__device__ __forceinline__ void epilogue_rows(const Epi &epi, double *acc, double (&racc)[Epi::NACC > 0 ? Epi::NACC : 1], int r0, int nr, int tid) {
+    constexpr int NT = kTileThreads, B = 4;
+    for (int i0 = tid; i0 < nr; i0 += B * NT) {
+        typename Epi::Row rw[B];
+        double sv[B][1];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int i = min(i0 + u * NT, nr - 1);  // clamped: branch-free loads, surplus lanes skip the update
+            rw[u] = epi.load_row(r0 + i);
+            sv[u][0] = acc[i];
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int i = i0 + u * NT;
+            if (i < nr) {
+                if constexpr (PUSH) acc[i] = epi.apply(r0 + i, rw[u], sv[u], racc);  // the published value replaces the row sum
+                else epi.apply(r0 + i, rw[u], sv[u], racc);
+            }
+        }
+    }
+}
+
+// Hand-off of one source group's remainder products (kernels.h: FarPush): entries [pb, pe) of the consumer's source-side lists,
+// the group's fresh vector values in `vals` (LDS).  Four entries per lane and batch; the next batch's loads are in flight while
+// this one's products are stored (one batch at a time left every batch a full trip to memory).
+__device__ __forceinline__ void push_products(const FarPush &f, const double *vals, int pb, int pe, int tid) {
+    constexpr int NT = kTileThreads, U = 4;
+    if (pb >= pe) return;
+    double a4[U];
+    int p4[U];
+    uint16_t c4[U];
+    auto load_batch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = min(k0 + u * NT, pe - 1);  // clamped: branch-free, surplus lanes are masked at the store
+            a4[u] = __builtin_nontemporal_load(f.val + z);
+            p4[u] = __builtin_nontemporal_load(f.pos + z);
+            c4[u] = __builtin_nontemporal_load(f.lcol + z);
+        }
+    };
+    int k = pb + tid;
+    load_batch(k);
+    for (; k < pe; k += U * NT) {
+        double prd[U];
+        int ps[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            prd[u] = a4[u] * vals[c4[u]];
+            ps[u] = p4[u];
+        }
+        const int kn = k + U * NT;
+        if (kn < pe) load_batch(kn);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + u * NT < pe) f.P[ps[u]] = prd[u];
     }
 }
 
@@ -705,7 +796,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
         if (s0 < smid) tiled_sweep<HPRLP_SWEEP_ED, HPRLP_SWEEP_TD, REP, false, LogTerm<Epi>::value, NARROW ? kTileColsNarrow : kTileCols>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
 #if !HPRLP_DBG_NOREM
-        tiled_remainder(t, smid, s1, acc, ytile, tid);
+        remainder_steps<kTileRemK>(t, smid, s1, acc, ytile, ytile + kTileRemCap, tid);
 #endif
         lds_barrier();
         const int r0 = sb * R;
@@ -721,41 +812,14 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
             pb = epi.push.gptr[sb];
             pe = epi.push.gptr[sb + 1];
         }
-        for (int i = tid; i < nr; i += NT) {
-            const double sv[1] = {acc[i]};
-            typename Epi::Row rw = epi.load_row(r0 + i);
-            if constexpr (PUSH) acc[i] = epi.apply(r0 + i, rw, sv, racc);  // the published value replaces the row sum
-            else epi.apply(r0 + i, rw, sv, racc);
-        }
+        epilogue_rows<Epi, PUSH>(epi, acc, racc, r0, nr, tid);
         if constexpr (PUSH && !HPRLP_DBG_NOEPI && !HPRLP_DBG_NOPUSHWORK) {
             // Hand-off (kernels.h: FarPush): this super-block's fresh values are the source group `sb` of the OTHER matrix'
             // remainder; write its products straight into that matrix' P -- what k_far_products would do in a launch of
             // its own after re-reading the vector from memory.  Same products bit for bit, same slots.
             // (a source group of the consumer's remainder = the rows of one super-block here: push_into() checks G == R)
             lds_barrier();
-            const FarPush &f = epi.push;
-            const int b = pb, e = pe;
-            int k = b + tid;
-            for (; k + 3 * NT < e; k += 4 * NT) {
-                double a4[4];
-                int p4[4];
-                uint16_t c4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a4[u] = __builtin_nontemporal_load(f.val + k + u * NT);
-                    p4[u] = __builtin_nontemporal_load(f.pos + k + u * NT);
-                    c4[u] = __builtin_nontemporal_load(f.lcol + k + u * NT);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-#if HPRLP_EPI_NT >= 3
-                    __builtin_nontemporal_store(a4[u] * acc[c4[u]], f.P + p4[u]);
-#else
-                    f.P[p4[u]] = a4[u] * acc[c4[u]];
-#endif
-                }
-            }
-            for (; k < e; k += NT) f.P[f.pos[k]] = f.val[k] * acc[f.lcol[k]];
+            push_products(epi.push, acc, pb, pe, tid);
         }
         if (wg_stamp && ++wg_round <= 5) t.wgtimes[blockIdx.x * 8 + wg_round] = wall_clock64();
     }
@@ -793,10 +857,9 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
     constexpr int NACC = Epi::NACC;
     __shared__ double acc[kPbRowsMax];
     __shared__ __attribute__((aligned(16))) double prod[CAP];
-    __shared__ uint32_t bnd_row[NW];
-    __shared__ double bnd_val[NW];
+    __shared__ double bnd[3 * NW];
     const TiledDev &t = A.tiled;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int R = t.R;
     const int per = t.per, slots = gridDim.x / 8;
     const int slot = blockIdx.x / 8;
@@ -816,135 +879,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
         lds_barrier();  // the previous super-block's epilogue is done with acc
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
-        if (smid < s1 && !HPRLP_DBG_NOREM) {
-            // the loads of step s + 1 (P in storage order for the staging, the codes of this lane's own chunk of K consecutive
-            // entries of the (row, CSR) order) are in flight while step s is folded
-            double pv[K];
-            uint32_t cv[K];
-            TileStep st = t.steps[smid];
-            auto issue = [&](const TileStep &z) {
-                const int last = max(z.e_end - z.e_begin - 1, 0);
-#pragma unroll
-                for (int k = 0; k < K; ++k) pv[k] = __builtin_nontemporal_load(t.P + z.e_begin + min(tid + k * NT, last));  // clamped: branch-free
-                // the lane's K = 6 consecutive codes as two 12-byte loads (4-byte aligned; six 4-byte loads with a lane stride of
-                // 24 bytes kept the address unit busy for 2 us per step); behind the step's end the last whole chunk is read
-                // (its values are not used: the lane's entry count says so)
-                static_assert(K == 6, "two three-word loads per lane");
-                typedef uint32_t u3_t __attribute__((ext_vector_type(3), aligned(4)));
-                const int c0 = min(K * tid, max(last + 1 - K, 0));
-                const u3_t w0 = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.rq + z.e_begin + c0));
-                const u3_t w1 = __builtin_nontemporal_load(reinterpret_cast<const u3_t *>(t.rq + z.e_begin + c0 + 3));
-                cv[0] = w0.x; cv[1] = w0.y; cv[2] = w0.z; cv[3] = w1.x; cv[4] = w1.y; cv[5] = w1.z;
-            };
-            issue(st);
-            constexpr uint32_t NOROW = 0x10000u;  // (codes keep the row in 16 bits)
-            for (int s = smid; s < s1; ++s) {
-                const int cnt = st.e_end - st.e_begin;
-                const TileStep nxt = t.steps[min(s + 1, s1 - 1)];
-                lds_barrier();  // everybody is done with the previous step's products and row sums
-                PB_STAMP(0);
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int el = tid + k * NT;
-                    if (el < cnt) prod[el] = pv[k];
-                }
-                // (a lane whose chunk crosses the step's end loaded the LAST whole chunk instead: move its codes down)
-                uint32_t code[K];
-                {
-                    const int shift = K * tid - min(K * tid, max(cnt - K, 0));  // 0 for every lane but at most one
-#pragma unroll
-                    for (int u = 0; u < K; ++u) code[u] = cv[u];
-                    if (shift > 0 && shift < K) {
-#pragma unroll
-                        for (int u = 0; u < K; ++u) {
-                            uint32_t c = 0;
-#pragma unroll
-                            for (int q = 0; q < K; ++q) c = (q == u + shift) ? cv[q] : c;
-                            code[u] = c;
-                        }
-                    }
-                }
-                if (s + 1 < s1) issue(nxt);
-                lds_barrier();
-                PB_STAMP(1);
-                // this lane's chunk: entries K tid .. K tid + K - 1 of the step, sorted by row.  Entries behind the step's end
-                // continue the last valid row with a zero product; a lane without any entry holds NOROW.
-                const int nv = min(max(cnt - K * tid, 0), K);
-                uint32_t row[K];
-                double pr[K];
-#pragma unroll
-                for (int u = 0; u < K; ++u) {
-                    const bool ok = u < nv;
-                    row[u] = ok ? (code[u] & 0xffffu) : (u == 0 ? NOROW : row[u - 1]);
-                    pr[u] = ok ? prod[code[u] >> 16] : 0.0;
-                }
-                // in-lane: the run that starts at entry 0 (head), rows that begin and end inside the chunk (added on the spot:
-                // nobody else holds entries of theirs in this step), the run that ends at entry K - 1 (tail)
-                double run = pr[0], head = 0.0;
-                bool single = true;
-#pragma unroll
-                for (int u = 1; u < K; ++u) {
-                    if (row[u] != row[u - 1]) {
-                        if (single) {
-                            head = run;
-                            single = false;
-                        } else {
-                            acc[row[u - 1]] += run;
-                        }
-                        run = pr[u];
-                    } else {
-                        run += pr[u];
-                    }
-                }
-                const uint32_t rf = row[0], rl = row[K - 1];
-                // across the lanes of the wave: a row's pieces are the tail of one lane, whole lanes, the head of a last one.
-                // Segmented inclusive scan of the lanes' carry-outs (the tail, or everything for a one-row lane); a lane passes the
-                // carry on iff it holds one row and continues its predecessor's.
-                const uint32_t rl_prev = __shfl_up(rl, 1, 64);
-                const bool open_in = lane > 0 && rf == rl_prev && rf != NOROW;
-                double v = run;
-                int f = (single && open_in) ? 0 : 1;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const double vu = __shfl_up(v, off, 64);
-                    const int fu = __shfl_up(f, off, 64);
-                    if (lane >= off && !f) {
-                        v += vu;
-                        f |= fu;
-                    }
-                }
-                const double v_prev = __shfl_up(v, 1, 64);
-                const double carry = open_in ? v_prev : 0.0;
-                const int next_open = __shfl_down(static_cast<int>(open_in), 1, 64);
-                if (!single) acc[rf] += carry + head;  // the head's row ends in this lane
-                const double tail = single ? carry + run : run;
-                if (lane == 63) {
-                    // the wave's last run may go on in the next wave (whose first lane takes no carry): added after the barrier, by one lane
-                    bnd_row[wave] = rl;
-                    bnd_val[wave] = tail;
-                } else if (!next_open && rl != NOROW) {
-                    acc[rl] += tail;
-                }
-                lds_barrier();
-                PB_STAMP(2);
-                if (tid < NW) {
-                    // the waves' last runs, one lane each; a row that fills whole waves appears more than once: the lane of its
-                    // last appearance adds them all, in wave order
-                    const uint32_t rw = bnd_row[tid];
-                    bool last_one = rw != NOROW;
-                    double tot = 0.0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const bool same = bnd_row[w] == rw;
-                        if (w <= tid && same) tot += bnd_val[w];
-                        if (w > tid && same) last_one = false;
-                    }
-                    if (last_one) acc[rw] += tot;
-                }
-                PB_STAMP(3);
-                st = nxt;
-            }
-        }
+        if (!HPRLP_DBG_NOREM) remainder_steps<K>(t, smid, s1, acc, prod, bnd, tid);
         lds_barrier();
         PB_STAMP(4);
         const int r0 = sb * R;
@@ -958,49 +893,13 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
             pb = epi.push.gptr[sb];
             pe = epi.push.gptr[sb + 1];
         }
-        for (int i = tid; i < nr; i += NT) {
-            const double sv[1] = {acc[i]};
-            typename Epi::Row rw = epi.load_row(r0 + i);
-            if constexpr (PUSH) acc[i] = epi.apply(r0 + i, rw, sv, racc);  // the published value replaces the row sum
-            else epi.apply(r0 + i, rw, sv, racc);
-        }
+        epilogue_rows<Epi, PUSH>(epi, acc, racc, r0, nr, tid);
         PB_STAMP(5);
         if constexpr (PUSH && !HPRLP_DBG_NOEPI && !HPRLP_DBG_NOPUSHWORK) {
             // hand-off (kernels.h: FarPush), as in k_tiled_fused: this super-block's fresh values are source group `sb` of the
             // other matrix' lists
             lds_barrier();
-            const FarPush &f = epi.push;
-            // four entries per lane and batch; the next batch's loads are in flight while this one's products are stored (one
-            // batch at a time left every batch a full trip to memory: 2.9 us each, 110 of the kernel's 250 us)
-            constexpr int U = 4;
-            double a4[U];
-            int p4[U];
-            uint16_t c4[U];
-            auto load_batch = [&](int k0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int z = min(k0 + u * NT, pe - 1);  // clamped: branch-free, surplus lanes are masked at the store
-                    a4[u] = __builtin_nontemporal_load(f.val + z);
-                    p4[u] = __builtin_nontemporal_load(f.pos + z);
-                    c4[u] = __builtin_nontemporal_load(f.lcol + z);
-                }
-            };
-            int k = pb + tid;
-            if (pb < pe) load_batch(k);
-            for (; k < pe; k += U * NT) {
-                double prd[U];
-                int ps[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    prd[u] = a4[u] * acc[c4[u]];
-                    ps[u] = p4[u];
-                }
-                const int kn = k + U * NT;
-                if (kn < pe) load_batch(kn);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (k + u * NT < pe) f.P[ps[u]] = prd[u];
-            }
+            push_products(epi.push, acc, pb, pe, tid);
         }
         PB_STAMP(6);
     }
@@ -1048,7 +947,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_part(CsrDev A, const 
         if (STAMP) c0 = __builtin_amdgcn_s_memtime();
         if (d.z > 0) tiled_sweep<3, 2, REP, STAMP, false, NARROW ? kTileColsNarrow : kTileCols>(t, s0, smid - s0, d.y, d.z, vec, A.cols, acc, ytile, tid, st);
         if (STAMP) c1 = __builtin_amdgcn_s_memtime();
-        if (d.w) tiled_remainder(t, smid, s1, acc, ytile, tid);
+        if (d.w) remainder_steps<kTileRemK>(t, smid, s1, acc, ytile, ytile + kTileRemCap, tid);
         lds_barrier();
         if (STAMP) c2 = __builtin_amdgcn_s_memtime();
         double *out = t.parts + static_cast<size_t>(sg) * R;

@@ -34,9 +34,10 @@ constexpr int kTileColsNarrow = 1024;  // round 4: tile width of a copy whose ro
                                    // went to the 34-bytes-per-entry remainder); TiledDev::T, chosen by Solver::choose_sb_rows
 constexpr int kTileChunk = 4;      // entries per lane per step
 constexpr int kTileStepCap = kTileThreads * kTileChunk;                       // entries per tile step
-constexpr int kTileRemK = (kTileCols * 8 - 8) / (12 * kTileThreads);          // remainder entries per lane per step (8 B product + 4 B code of LDS each)
-constexpr int kTileRemCap = kTileThreads * kTileRemK;                         // (scratch aliases the tile buffer)
-constexpr int kTileRemRun = 16;    // remainder steps in which a row holds more consecutive entries than this are added in two levels (8 / 16 / 32 measured)
+constexpr int kTileRemK = 4;                                                  // remainder entries per lane per step (kernels.hip: remainder_steps)
+constexpr int kTileRemCap = (kTileThreads - 4) * kTileRemK;                   // 2032: the step's products fill the tile buffer but for 16 doubles of scratch
+constexpr int kTileRemRun = 16;    // (the builder still marks remainder steps in which a row holds more consecutive entries than this -- TileStep::col0 --
+                                   // for the statistics line; since round 4 the kernels add rows of any length the same way)
 // All-remainder form (round 4; a matrix without column locality: no tile is staged, every entry goes through the
 // propagation-blocking lists): the copy has its own fused kernel (kernels.hip: k_pb_fused) whose LDS holds the accumulators of
 // at most kPbRowsMax rows and remainder steps of kPbRemCap entries -- three times the kTileRemCap of a copy that also stages
@@ -48,7 +49,7 @@ constexpr int kPbRun = 32;
 constexpr int kTileMaxRow = 1024;  // matrices with a longer row are not tiled: a long row's remainder entries all go through ONE workgroup
                                    // (2M x 2M, five rows of L entries, per launch: L = 1000 192 us, 3000 265-327 us, 8000 433-470 us; stream kernel 262 us)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
-static_assert(kTileRemK >= 1, "tile buffer too small for the remainder scratch");
+static_assert(kTileRemCap % kTileRemK == 0 && kTileRemCap + (kTileThreads / 64) * 3 / 2 <= kTileCols, "tile buffer too small for the remainder scratch");
 constexpr int kTileRowBits = 13;  // local row in an entry code of the tall form
 // Super-block height (round 3).  The accumulators of a super-block take 8 bytes of LDS per row, so 8192 rows is the most;
 // a copy may use fewer (TiledDev::R, any multiple of 64 from kTileRowsMin up; the codes keep 13 bits for the local row).

@@ -601,8 +601,8 @@ __global__ void __launch_bounds__(kThreads) k_far_step_of(int nsb, const int *__
                                                          TileStep *__restrict__ steps, const uint16_t *__restrict__ rrow,
                                                          int *__restrict__ step_of, int *__restrict__ sb_of, bool mark) {
     // one workgroup per super-block: every remainder entry learns its step and its super-block; a step in which some row
-    // holds more than kTileRemRun consecutive entries is marked (col0 = 1, unused by remainder steps otherwise): the
-    // kernel adds such a step's rows in two levels (kernels.hip, tiled_remainder)
+    // holds more than kTileRemRun consecutive entries is marked (col0 = 1, unused by remainder steps otherwise; read by the
+    // HPRLP_TIMING statistics only since round 4: kernels.hip, remainder_steps adds rows of any length the same way)
     const int sb = blockIdx.x;
     if (sb >= nsb) return;
     for (int s = sb_mid[sb]; s < sb_ptr[sb + 1]; ++s) {
