@@ -240,6 +240,29 @@ def cpu_baseline(name, steps_budget_s=12.0):
     return out
 
 
+def fresh_process_solves(which):
+    """Cold start: tools/cold_start.py in a FRESH process (this one has long been warm): four whole solve() calls of the
+    config; the first pays for the HIP runtime, the device context and the code objects.  Returns {cold, warm} with the
+    whole-call wall, the reference's instrument (HPRLP_results.time = power iteration + loop) and the library's phase
+    table each; warm = the median call of the other three."""
+    import subprocess
+    out = {}
+    for label, extra in (("first_solve_of_a_process", []), ("after_hprlp_warmup", ["warm"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_start.py"), which] + extra, env=dict(os.environ, HPRLP_COLD_START_JSON="1"),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+        rec = None
+        for ln in r.stderr.decode(errors="replace").splitlines():
+            if ln.startswith("COLDJSON "):
+                rec = json.loads(ln[len("COLDJSON "):])
+        if rec is None:
+            out[label] = {"error": r.stderr.decode(errors="replace")[-300:]}
+            continue
+        sv = rec["solves"]
+        later = sorted(sv[1:], key=lambda q: q["whole_call_wall_s"])[len(sv[1:]) // 2]
+        out[label] = {"cold": sv[0], "warm": later, "warmup_call_s": rec["warmup_s"], "library_load_s": rec["library_load_s"]}
+    return out
+
+
 def side_configs():
     """BASELINE configs 2 and 3 (shape-matched stand-ins) on one GPU: it/s by graph replay and time-to-1e-4."""
     out = {}
@@ -279,6 +302,10 @@ def side_configs():
                     "time_to_1e-4_parts_s": best, "time_to_1e-4_all_runs_s": [q["total"] for q in runs],
                     "rel_obj_err": abs(r.primal_obj - lp["obj_star"]) / (1 + abs(lp["obj_star"]))}
         s.close()
+        try:  # what a caller's FIRST solve() of a process costs, and the following ones (a fresh process each; round 4)
+            out[key]["solve_call_in_a_fresh_process"] = fresh_process_solves("c2" if key.startswith("c2") else "c3")
+        except Exception as e:  # noqa: BLE001
+            out[key]["solve_call_in_a_fresh_process"] = {"error": str(e)}
         if key == "c3_pds20_like":
             # BASELINE config 4: solve_batched, shared A = config-3 matrix, B = 64 perturbed c / AU columns.  Members are
             # kept bounded (infinite upper bounds -> 50: with the recipe's perturbed c an unbounded-above column makes the

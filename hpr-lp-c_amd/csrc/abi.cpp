@@ -51,6 +51,71 @@ static void print_banner_and_parameters(const HPRLP_parameters *p) {
 extern "C" const char *hprlp_last_error(void) { return last_error_cstr(); }
 extern "C" const char *hprlp_backend(void) { return HPRLP_BACKEND_STRING; }
 
+// ---- warm-up -------------------------------------------------------------------------------------------------------
+// The first solve of a process pays for the HIP runtime's start-up, the device context, the first stream and the library's code
+// objects (loaded as their first kernels are launched): 0.10 s on a Netlib-scale LP whose solve takes 0.04 s
+// (profiles/r04_cold_start.txt).  None of it depends on the LP.  hprlp_warmup() does it on request -- a serving process calls
+// it once at start-up, the first solve() then costs what the later ones do plus the first stream (0.03 s).  Measured and NOT
+// done: starting it implicitly from the model constructors on a background thread -- a context first touched by another
+// thread cost the solving thread MORE set-up time (0.18 instead of 0.09 s), and loading all six code objects up front is
+// 0.05 s of which a small solve needs 0.01.
+namespace hprlp {
+void warm_kernels_tu();
+void warm_small_tu();
+void warm_batched_tu();
+void warm_transpose_tu();
+void warm_tiled_build_tu();
+void warm_reorder_tu();
+}  // namespace hprlp
+
+static double g_warm_seconds[4] = {0, 0, 0, 0};
+
+extern "C" int hprlp_warmup(int device) {
+    const auto t0 = time_now();
+    int count = 0;
+    if (hipInit(0) != hipSuccess || hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        set_last_error("hprlp_warmup: no usable GPU");
+        return -1;
+    }
+    if (device < 0 || device >= count) device = 0;
+    const auto t1 = time_now();
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess || hipStreamCreate(&s) != hipSuccess) {
+        (void)hipGetLastError();
+        set_last_error("hprlp_warmup: the device context could not be created");
+        return -1;
+    }
+    (void)hipStreamDestroy(s);
+    const auto t2 = time_now();
+    // one attribute query per translation unit loads that unit's code object (deferred loading: otherwise at its first launch)
+    try {
+        warm_kernels_tu();
+        warm_small_tu();
+        warm_batched_tu();
+        warm_transpose_tu();
+        warm_tiled_build_tu();
+        warm_reorder_tu();
+    } catch (...) {
+    }
+    (void)hipGetLastError();
+    const auto t3 = time_now();
+    g_warm_seconds[0] = std::chrono::duration<double>(t1 - t0).count();
+    g_warm_seconds[1] = std::chrono::duration<double>(t2 - t1).count();
+    g_warm_seconds[2] = std::chrono::duration<double>(t3 - t2).count();
+    g_warm_seconds[3] = std::chrono::duration<double>(t3 - t0).count();
+    if (std::getenv("HPRLP_TIMING"))
+        std::cerr << "[timing] warm-up: runtime start-up " << g_warm_seconds[0] << " s, device context + first stream " << g_warm_seconds[1]
+                  << " s, code objects " << g_warm_seconds[2] << " s" << std::endl;
+    return 0;
+}
+
+extern "C" int hprlp_warmup_seconds(double out[4]) {
+    if (!out) return -1;
+    for (int i = 0; i < 4; ++i) out[i] = g_warm_seconds[i];
+    return 0;
+}
+
 // phases of the calling thread's last HPRLP_main_solve (hprlp_last_solve_phases): device set-up (upload, transpose, tiled
 // copies, ordering), scaling, power iteration, loop, solution's way back, teardown of the device state, whole call
 static thread_local double g_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -731,6 +731,13 @@ HPRLP_batched_results make_batched_error(const char *status, int m, int n, int B
 }
 
 }  // namespace
+// warm-up (abi.cpp: hprlp_warmup): an attribute query makes the runtime load this translation unit's code object now instead
+// of at the first launch of one of its kernels
+void warm_batched_tu() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&kb_finalize));
+}
+
 }  // namespace hprlp
 
 using namespace hprlp;

@@ -369,4 +369,11 @@ void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s) {
     else launch_kr<12, 2>(a, count, s);
 }
 
+// warm-up (abi.cpp: hprlp_warmup): an attribute query makes the runtime load this translation unit's code object now instead
+// of at the first launch of one of its kernels
+void warm_small_tu() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>((&k_small_iterations<4, 1>)));
+}
+
 }  // namespace hprlp

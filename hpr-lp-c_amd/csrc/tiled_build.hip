@@ -927,4 +927,11 @@ void DeviceTiled::dump_stamps() const {
                  sum[9] / view.n_pieces, sum[10] / view.n_pieces);
 }
 
+// warm-up (abi.cpp: hprlp_warmup): an attribute query makes the runtime load this translation unit's code object now instead
+// of at the first launch of one of its kernels
+void warm_tiled_build_tu() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_run_heads));
+}
+
 }  // namespace hprlp

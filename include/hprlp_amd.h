@@ -28,6 +28,13 @@ typedef struct hprlp_trace_row {
 
 const char *hprlp_last_error(void);
 const char *hprlp_backend(void); /* "hip-gfx950" */
+/* Warm-up: start the HIP runtime, create the device context and a first stream and load the library's code objects NOW instead
+ * of inside the first solve of the process (0.10 s there against a 0.04 s solve of a Netlib-scale LP, profiles/r04_cold_start.txt).
+ * For callers that serve many solves: call once at start-up.  Returns 0, or -1 without a usable GPU.
+ * hprlp_warmup_seconds: {runtime start-up, device context + first stream, code objects, total} of the last call. */
+int hprlp_warmup(int device);
+int hprlp_warmup_seconds(double out[4]);
+
 /* The library keeps freed device blocks of 1 MiB and more for its next solver (a hipMalloc of a multi-GB set-up temporary right
  * behind a large hipFree stalls for up to a second on this platform); this returns them all to the driver.  HPRLP_NO_ALLOC_CACHE=1
  * disables the cache. */
