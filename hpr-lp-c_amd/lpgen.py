@@ -167,3 +167,236 @@ def block_angular_lp(K, mb, nb, per_row, link_rows, link_cols, link_len, seed):
     out = _plant(np.random.default_rng(seed + 1), A)
     out.update(m=m, n=n, A=A, rowptr=rp, colind=ci, values=v)
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Families of the Mittelmann LP set (round 4).  The named instances (pds-xx, nug-xx, cont-xx, staircase multi-stage models)
+# are not available offline; these are deterministic generators of the same CONSTRUCTIONS at any size -- real LPs with the
+# families' structure and degeneracy (no planted optimum: the tests take the optimum from HiGHS at small sizes and from
+# the oracle / the KKT conditions beyond).  Every generator returns the usual dict (m, n, rowptr, colind, values, AL, AU, l,
+# u, c) plus `family`.
+# --------------------------------------------------------------------------------------------------------------------
+def _finish(A, AL, AU, l, u, c, family):
+    A = sparse.csr_matrix(A)
+    A.sum_duplicates()
+    A.sort_indices()
+    m, n = A.shape
+    return dict(m=m, n=n, A=A, rowptr=A.indptr.astype(np.int32), colind=A.indices.astype(np.int32), values=A.data.astype(np.float64),
+                AL=np.asarray(AL, float), AU=np.asarray(AU, float), l=np.asarray(l, float), u=np.asarray(u, float), c=np.asarray(c, float),
+                family=family)
+
+
+def multicommodity_flow_lp(grid, commodities, seed, cap_tightness=0.7):
+    """pds-like (Patient Distribution System: multicommodity minimum-cost flow).  A grid x grid torus of nodes, arcs to the four
+    neighbours plus 20 % random long arcs; K commodities, each ships one unit-scaled demand from a random source to a random
+    sink.  Variables: flow x[k, a] >= 0 and one artificial arc per commodity (source -> sink, expensive, uncapacitated: the LP is
+    always feasible).  Rows: flow conservation per (commodity, node) -- K node-arc incidence blocks, +-1 entries, equalities --
+    and one joint capacity row per arc, sum_k x[k, a] <= cap_a.  Capacities are `cap_tightness` x the load of the
+    shortest-path routing on the busiest arcs (so they bind) and generous elsewhere.  Block-angular, +-1 matrix, degenerate."""
+    rng = np.random.default_rng(seed)
+    V = grid * grid
+    idx = np.arange(V).reshape(grid, grid)
+    tails = np.concatenate([idx.ravel()] * 4)
+    heads = np.concatenate([np.roll(idx, -1, 0).ravel(), np.roll(idx, 1, 0).ravel(), np.roll(idx, -1, 1).ravel(), np.roll(idx, 1, 1).ravel()])
+    extra = V // 5 * 4 // 4
+    et, eh = rng.integers(0, V, extra), rng.integers(0, V, extra)
+    keep = et != eh
+    tails, heads = np.concatenate([tails, et[keep]]), np.concatenate([heads, eh[keep]])
+    Aarcs = len(tails)
+    cost = rng.uniform(1.0, 3.0, Aarcs)
+    K = commodities
+    src, dst = rng.integers(0, V, K), rng.integers(0, V, K)
+    dst = np.where(dst == src, (dst + 1) % V, dst)
+    dem = rng.uniform(1.0, 4.0, K)
+    # shortest-path routing (by arc cost) of every commodity: the load that sizes the capacities
+    from scipy.sparse.csgraph import dijkstra
+    Gm = sparse.csr_matrix((cost, (tails, heads)), shape=(V, V))
+    Gm.sum_duplicates()
+    load = np.zeros(Aarcs)
+    arc_of = {}
+    for a in range(Aarcs):
+        key = (int(tails[a]), int(heads[a]))
+        if key not in arc_of or cost[a] < cost[arc_of[key]]:
+            arc_of[key] = a
+    _, pred = dijkstra(Gm, indices=src, return_predecessors=True)
+    for k in range(K):
+        v = int(dst[k])
+        while v != int(src[k]) and pred[k, v] >= 0:
+            p = int(pred[k, v])
+            load[arc_of[(p, v)]] += dem[k]
+            v = p
+    cap = np.where(load > 0, np.maximum(cap_tightness * load, 0.5), rng.uniform(2.0, 6.0, Aarcs))
+    nvar_k = Aarcs + 1   # + the artificial arc
+    n = K * nvar_k
+    m = K * V + Aarcs
+    rows, cols, vals = [], [], []
+    for k in range(K):
+        c0, r0 = k * nvar_k, k * V
+        a = np.arange(Aarcs)
+        rows += [r0 + tails, r0 + heads, K * V + a]
+        cols += [c0 + a, c0 + a, c0 + a]
+        vals += [np.ones(Aarcs), -np.ones(Aarcs), np.ones(Aarcs)]
+        rows += [np.array([r0 + src[k], r0 + dst[k]])]
+        cols += [np.array([c0 + Aarcs, c0 + Aarcs])]
+        vals += [np.array([1.0, -1.0])]
+    A = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m, n))
+    b = np.zeros(K * V)
+    for k in range(K):
+        b[k * V + src[k]] += dem[k]
+        b[k * V + dst[k]] -= dem[k]
+    AL = np.concatenate([b, np.full(Aarcs, -np.inf)])
+    AU = np.concatenate([b, cap])
+    c = np.tile(np.concatenate([cost, [60.0]]), K) * np.repeat(rng.uniform(0.8, 1.2, K), nvar_k)
+    return _finish(A, AL, AU, np.zeros(n), np.full(n, np.inf), c, "multicommodity flow (pds-like)")
+
+
+def qap_lp_relaxation(nfac, seed):
+    """nug-like: the Adams-Johnson linearisation of a quadratic assignment problem with the symmetry y[i,j,k,l] = y[k,l,i,j]
+    substituted out (the form of the nugXX LPs: nfac = 8 gives their 912 x 1632).  Variables x[i,j] (facility i at location j) and
+    y[i,j,k,l] for i < k, j != l; rows: the 2 nfac assignment equalities and, for every (i, j), one equality per other location
+    l and one per other facility k tying the y's to x[i,j].  Flows and distances are random integers (Nugent-style grid
+    distances); all equalities, every vertex massively degenerate -- the hard end of the set for first-order methods."""
+    rng = np.random.default_rng(seed)
+    nf = nfac
+    side = int(np.ceil(np.sqrt(nf)))
+    loc = np.array([(q // side, q % side) for q in range(nf)])
+    D = np.abs(loc[:, None, :] - loc[None, :, :]).sum(axis=2).astype(float)
+    F = np.triu(rng.integers(0, 7, size=(nf, nf)), 1).astype(float)
+    F = F + F.T
+    nx = nf * nf
+    pairs = [(i, k) for i in range(nf) for k in range(i + 1, nf)]
+    pidx = {p: q for q, p in enumerate(pairs)}
+    jl = [(j, l) for j in range(nf) for l in range(nf) if j != l]
+    jlidx = {p: q for q, p in enumerate(jl)}
+    ny = len(pairs) * len(jl)
+    n = nx + ny
+
+    def yv(i, j, k, l):   # variable of y[i,j,k,l], any order of the two (facility, location) pairs
+        if i > k:
+            i, j, k, l = k, l, i, j
+        return nx + pidx[(i, k)] * len(jl) + jlidx[(j, l)]
+
+    rows, cols, vals = [], [], []
+    r = 0
+    for j in range(nf):
+        for i in range(nf):
+            rows.append(r); cols.append(i * nf + j); vals.append(1.0)
+        r += 1
+    for i in range(nf):
+        for j in range(nf):
+            rows.append(r); cols.append(i * nf + j); vals.append(1.0)
+        r += 1
+    for i in range(nf):
+        for j in range(nf):
+            for l in range(nf):
+                if l == j:
+                    continue
+                for k in range(nf):
+                    if k != i:
+                        rows.append(r); cols.append(yv(i, j, k, l)); vals.append(1.0)
+                rows.append(r); cols.append(i * nf + j); vals.append(-1.0)
+                r += 1
+            for k in range(nf):
+                if k == i:
+                    continue
+                for l in range(nf):
+                    if l != j:
+                        rows.append(r); cols.append(yv(i, j, k, l)); vals.append(1.0)
+                rows.append(r); cols.append(i * nf + j); vals.append(-1.0)
+                r += 1
+    m = r
+    A = sparse.csr_matrix((vals, (rows, cols)), shape=(m, n))
+    b = np.concatenate([np.ones(2 * nf), np.zeros(m - 2 * nf)])
+    c = np.zeros(n)
+    for (i, k) in pairs:
+        for (j, l) in jl:
+            c[yv(i, j, k, l)] = 2.0 * F[i, k] * D[j, l]   # both orders of the pair
+    return _finish(A, b, b, np.zeros(n), np.full(n, np.inf), c, "QAP relaxation (nug-like)")
+
+
+def pde_control_lp(N, seed, alpha=0.01):
+    """cont-like: boundary control of the Poisson equation on an N x N grid with an L1 tracking objective and a state
+    constraint (the construction of Mittelmann's cont-xx LPs).  Variables: states y (N^2), controls u on the boundary cells
+    (4 N - 4, -1 <= u <= 1), and t >= |y - y_d| (N^2).  Rows: the five-point stencil 4 y_ij - sum of neighbours = h^2 f + boundary
+    control (equalities, one per cell), t - y >= -y_d and t + y >= y_d.  Bounds y <= psi.  min h^2 sum t + alpha h sum |u| is
+    taken with u split by its sign bound instead: cost alpha h on u^+ and u^-.  Grid stencil: banded, 5 entries per row."""
+    rng = np.random.default_rng(seed)
+    h = 1.0 / (N + 1)
+    ny = N * N
+    bcells = [(i, j) for i in range(N) for j in range(N) if i in (0, N - 1) or j in (0, N - 1)]
+    nb = len(bcells)
+    n = ny + 2 * nb + ny          # y, u+, u-, t
+    oy, oup, oum, ot = 0, ny, ny + nb, ny + 2 * nb
+    xs = (np.arange(N) + 1) * h
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    yd = (np.sin(2 * np.pi * X) * np.sin(np.pi * Y) + 0.3 * rng.normal(size=(N, N)) * 0.1).ravel()
+    f = (5.0 * np.exp(-20 * ((X - 0.3) ** 2 + (Y - 0.6) ** 2))).ravel()
+    rows, cols, vals = [], [], []
+    cell = lambda i, j: i * N + j
+    for i in range(N):
+        for j in range(N):
+            r = cell(i, j)
+            rows.append(r); cols.append(oy + r); vals.append(4.0)
+            for (a, b2) in ((i - 1, j), (i + 1, j), (i, j - 1), (i, j + 1)):
+                if 0 <= a < N and 0 <= b2 < N:
+                    rows.append(r); cols.append(oy + cell(a, b2)); vals.append(-1.0)
+    for q, (i, j) in enumerate(bcells):   # the control enters the boundary cells' equations
+        r = cell(i, j)
+        rows += [r, r]; cols += [oup + q, oum + q]; vals += [-1.0, 1.0]
+    r0 = ny
+    for k in range(ny):
+        rows += [r0 + k, r0 + k]; cols += [ot + k, oy + k]; vals += [1.0, -1.0]
+    r1 = 2 * ny
+    for k in range(ny):
+        rows += [r1 + k, r1 + k]; cols += [ot + k, oy + k]; vals += [1.0, 1.0]
+    m = 3 * ny
+    A = sparse.csr_matrix((vals, (rows, cols)), shape=(m, n))
+    AL = np.concatenate([h * h * f, -yd, yd])
+    AU = np.concatenate([h * h * f, np.full(2 * ny, np.inf)])
+    psi = 0.6
+    l = np.concatenate([np.full(ny, -np.inf), np.zeros(2 * nb), np.zeros(ny)])
+    u = np.concatenate([np.full(ny, psi), np.ones(2 * nb), np.full(ny, np.inf)])
+    c = np.concatenate([np.zeros(ny), np.full(2 * nb, alpha * h), np.full(ny, h * h)])
+    return _finish(A, AL, AU, l, u, c, "PDE boundary control (cont-like)")
+
+
+def staircase_lp(stages, rows_per_stage, cols_per_stage, per_row, seed):
+    """Staircase (multi-stage / dynamic) LP: stage t has its own variables x_t >= 0 and rows B_t x_{t-1} + A_t x_t = b_t -- the
+    matrix is a staircase of (rows_per_stage x cols_per_stage) blocks on the diagonal and the sub-diagonal, `per_row` entries
+    per row and block.  b_t comes from a nonnegative point (feasible), costs are nonnegative (bounded), a fifth of the
+    variables carry upper bounds."""
+    rng = np.random.default_rng(seed)
+    T, ms, ns = stages, rows_per_stage, cols_per_stage
+    m, n = T * ms, T * ns
+    rows, cols, vals = [], [], []
+    for t in range(T):
+        r = np.repeat(np.arange(t * ms, (t + 1) * ms), per_row)
+        cA = t * ns + rng.integers(0, ns, size=len(r))
+        rows.append(r); cols.append(cA); vals.append(rng.uniform(0.2, 1.5, len(r)) * rng.choice([-1.0, 1.0], len(r), p=[0.3, 0.7]))
+        if t > 0:
+            k = max(1, per_row // 2)
+            r2 = np.repeat(np.arange(t * ms, (t + 1) * ms), k)
+            cB = (t - 1) * ns + rng.integers(0, ns, size=len(r2))
+            rows.append(r2); cols.append(cB); vals.append(-rng.uniform(0.2, 1.0, len(r2)))
+    A = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m, n))
+    A.sum_duplicates()
+    x0 = np.where(rng.random(n) < 0.6, rng.uniform(0.0, 2.0, n), 0.0)
+    b = A @ x0
+    u = np.where(rng.random(n) < 0.2, x0 + rng.uniform(0.5, 2.0, n), np.inf)
+    c = rng.uniform(0.1, 2.0, n)
+    return _finish(A, b, b, np.zeros(n), u, c, "staircase (multi-stage)")
+
+
+# the four families at test size (<= 1e5 nonzeros) and at table size (1e6 - 1e7)
+FAMILIES_SMALL = {
+    "pds_like": lambda: multicommodity_flow_lp(12, 8, 41),
+    "nug_like": lambda: qap_lp_relaxation(6, 42),
+    "cont_like": lambda: pde_control_lp(40, 43),
+    "staircase": lambda: staircase_lp(12, 300, 450, 6, 44),
+}
+FAMILIES_LARGE = {
+    "pds_like": lambda: multicommodity_flow_lp(110, 40, 41),
+    "nug_like": lambda: qap_lp_relaxation(30, 42),     # 52 260 x 379 350, 1.57e6 nonzeros: the size of nug30
+    "cont_like": lambda: pde_control_lp(700, 43),
+    "staircase": lambda: staircase_lp(200, 3000, 4500, 8, 44),
+}

@@ -20,4 +20,6 @@ write_mps(os.path.join(out, "c2_25fv47_like.mps"), lpgen.c2_25fv47_like())
 write_mps(os.path.join(out, "c3_pds20_like.mps.gz"), lpgen.c3_pds20_like())
 write_mps(os.path.join(out, "banded_100k_2e6nnz.mps.gz"), lpgen.banded_lp(100_000, 100_000, 20, 1_000, 5))
 write_mps(os.path.join(out, "block_angular_100x500x1000.mps.gz"), lpgen.block_angular_lp(100, 500, 1000, 12, 20, 20, 600, 9))
+for name, make in lpgen.FAMILIES_SMALL.items():   # the four Mittelmann-family constructions at test size (round 4)
+    write_mps(os.path.join(out, f"family_{name}.mps"), make())
 print("wrote", sorted(os.listdir(out)))

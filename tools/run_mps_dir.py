@@ -28,7 +28,10 @@ _spec.loader.exec_module(H)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("dir")
+    ap.add_argument("dir", nargs="?", default=None)
+    ap.add_argument("--generated", default=None, choices=["families_small", "families_large"],
+                    help="instead of a directory: the four Mittelmann-family generators of hpr-lp-c_amd/lpgen.py (pds-, nug-, cont-like, "
+                         "staircase) at test size (<= 1e5 nonzeros) or table size (1e6 - 1e7), handed over through create_model_from_arrays")
     ap.add_argument("--tol", type=float, default=1e-4)
     ap.add_argument("--time-limit", type=float, default=3600.0)
     ap.add_argument("--max-iter", type=int, default=2**31 - 1)
@@ -36,20 +39,33 @@ def main():
     ap.add_argument("--out", default=None, help="markdown table (default: stdout)")
     ap.add_argument("--json", default=None, help="rows as JSON")
     args = ap.parse_args()
-    files = sorted(glob.glob(os.path.join(args.dir, "*.mps")) + glob.glob(os.path.join(args.dir, "*.mps.gz")) +
-                   glob.glob(os.path.join(args.dir, "*.MPS")), key=os.path.getsize)
-    if not files:
-        raise SystemExit(f"no .mps / .mps.gz files in {args.dir}")
+    if args.generated:
+        _s2 = importlib.util.spec_from_file_location("hprlp_lpgen", os.path.join(ROOT, "hpr-lp-c_amd", "lpgen.py"))
+        G = importlib.util.module_from_spec(_s2)
+        _s2.loader.exec_module(G)
+        fam = G.FAMILIES_SMALL if args.generated == "families_small" else G.FAMILIES_LARGE
+
+        def from_generator(make):
+            lp = make()
+            return H.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        files = [(f"{k} ({args.generated})", (lambda mk=mk: from_generator(mk))) for k, mk in fam.items()]
+    else:
+        if not args.dir:
+            raise SystemExit("give a directory of .mps files or --generated")
+        paths = sorted(glob.glob(os.path.join(args.dir, "*.mps")) + glob.glob(os.path.join(args.dir, "*.mps.gz")) +
+                       glob.glob(os.path.join(args.dir, "*.MPS")), key=os.path.getsize)
+        if not paths:
+            raise SystemExit(f"no .mps / .mps.gz files in {args.dir}")
+        files = [(os.path.basename(f), (lambda f=f: H.Model.from_mps(f))) for f in paths]
     presolve = args.presolve.lower() in ("true", "1", "yes")
     real_stdout = os.dup(1)
     os.dup2(2, 1)  # the library prints its banner and iteration log to the C-level stdout
     rows = []
-    for f in files:
-        name = os.path.basename(f)
+    for name, load in files:
         row = {"instance": name}
         try:
             t0 = time.time()
-            model = H.Model.from_mps(f)
+            model = load()
             row.update(m=model.m, n=model.n, nnz=model.nnz, read_s=time.time() - t0)
             prm = H.Parameters(stop_tol=args.tol, time_limit=args.time_limit, max_iter=args.max_iter, use_presolve=presolve)
             t1 = time.time()
