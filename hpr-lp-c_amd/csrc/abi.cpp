@@ -636,8 +636,8 @@ extern "C" int hprlp_solver_reset_iterates(hprlp_solver *h) {
 
 extern "C" int hprlp_solver_iterate(hprlp_solver *h, int normal, int then_check) {
     GUARD_BEGIN
-    h->s.run_normal(normal);
-    if (then_check) h->s.step(true);
+    if (then_check) h->s.run_normal_then_check(normal);
+    else h->s.run_normal(normal);
     HIP_CHECK(hipStreamSynchronize(h->s.stream));
     return 0;
     GUARD_END(-1)
@@ -751,6 +751,7 @@ extern "C" long hprlp_solver_get_vector(hprlp_solver *h, const char *name, doubl
 
 extern "C" int hprlp_solver_set_vector(hprlp_solver *h, const char *name, const double *in, long len) {
     GUARD_BEGIN
+    if (h) h->s.small_resid_ready = false;
     VecRef v = find_vector(h->s, name ? name : "");
     if (v.n < 0) throw std::runtime_error(std::string("unknown vector name: ") + (name ? name : "(null)"));
     if (len != v.n) throw std::runtime_error("length mismatch");

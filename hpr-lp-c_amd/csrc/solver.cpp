@@ -925,6 +925,7 @@ static double bnorm_sq(Solver *s) {
 // that the column-side scaling of each stored matrix can index the full vector.
 // ------------------------------------------------------------------------------------------------
 void Solver::scale() {
+    small_resid_ready = false;
     invalidate_far();
     const auto t0 = time_now();
     overlap_ready = false;  // the split copies of the shards carry matrix values
@@ -1169,6 +1170,7 @@ void Solver::refresh_bound_codes() {
 // (bench.py: the timed iterations and the solve to tolerance of a multi-GPU run use ONE solver -- a second one would need a
 // second set of communicators.)  Call init_iteration_state() / set_sigma_lambda() afterwards, as after create.
 void Solver::reset_iterates() {
+    small_resid_ready = false;
     if (y_exchange_pending) throw std::runtime_error("reset_iterates: an exchange is still pending");
     invalidate_far();
     auto zero = [&](double *p, size_t n) {
@@ -1309,6 +1311,7 @@ void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev, int x_mode) {
 }
 
 void Solver::step(bool check) {
+    small_resid_ready = false;
     finish_tiling();
     if (!check) {
         launch_normal_pair();
@@ -1359,6 +1362,7 @@ hipGraphExec_t Solver::graph_for(int len) {
 
 void Solver::run_normal(int count) {
     if (count <= 0) return;
+    small_resid_ready = false;
     finish_tiling();
     if (use_small && !comm) {
         // Netlib-scale LP: all `count` iterations in one single-workgroup launch, matrices in registers (small.hip)
@@ -1378,6 +1382,29 @@ void Solver::run_normal(int count) {
         far_AT_ready = graph_end_AT;
         count -= len;
     }
+}
+
+void Solver::run_normal_then_check(int count) {
+    // Built and measured in round 4, NOT the default: the check step + the residual sums as one single-workgroup launch are bit
+    // for bit the regular kernels' vectors (tests/test_gpu_small.py), but one CU walking five SpMV passes in a row is no
+    // faster than the eight small launches it replaces, which overlap on the chip (config 2: loop 0.0300 s with it, 0.0290 s
+    // without, profiles/r04_small_check.txt).  HPRLP_SMALL_CHECK=1 switches it on.
+    const char *on = std::getenv("HPRLP_SMALL_CHECK");
+    if (!(use_small && !comm) || !(on && on[0] == '1')) {
+        run_normal(count);
+        step(true);
+        return;
+    }
+    finish_tiling();
+    run_normal(count);
+    // (a launch of its own: fused into the iterations' kernel the tail cost that kernel's 12-entries-per-thread instance a
+    // scratch reload per iteration)
+    const SmallArgs a{m, n, A.view.nnz, A.view.rowptr, AT.view.rowptr, AT.view.val, small_ij.p, small_posA.p,
+                      small_order_x.p, small_order_y.p, x.p, x_hat, y, l.p, u.p, c.p, last_x.p, AL.p, AU.p, last_y.p, ctrl.p};
+    const SmallTail tl{x_bar, z_bar.p, x_temp, y_bar, y_obj.p, y_temp.p, col_norm.p, row_norm.p, scal.p};
+    launch_small_iterations_check(a, 0, tl, stream);
+    invalidate_far();
+    small_resid_ready = true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1401,6 +1428,21 @@ static double weighted_norm_from(Solver *s, double dot_adx_dy, double dy2, doubl
 }
 
 void Solver::compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs) {
+    if (small_resid_ready && iter != 0) {
+        // the check step's launch has left the eight sums of this state in scal[S_CX .. S_DX2] (run_normal_then_check)
+        small_resid_ready = false;
+        fetch_scalars();
+        const double obj_scale = b_scale * c_scale;
+        r->primal_obj = obj_scale * scal_h[S_CX] + obj_constant;
+        r->dual_obj = obj_scale * (scal_h[S_YOBJ_Y] + scal_h[S_XZ]) + obj_constant;
+        r->rel_gap = std::abs(r->primal_obj - r->dual_obj) / (1.0 + std::abs(r->primal_obj) + std::abs(r->dual_obj));
+        r->err_Rd = c_scale * std::sqrt(scal_h[S_RD2]) / norm_c_org;
+        r->err_Rp = b_scale * std::sqrt(scal_h[S_RP2]) / norm_b_org;
+        r->kkt = std::max(std::max(r->err_Rd, r->err_Rp), r->rel_gap);
+        if (compute_gap && rs) rs->current_gap = weighted_norm_from(this, scal_h[S_ADX_DY], scal_h[S_DY2], scal_h[S_DX2]);
+        return;
+    }
+    small_resid_ready = false;
     invalidate_far();  // the residual SpMVs refill the remainder buffers for x_bar / y_bar
     finish_tiling();
     const int gx = AT.view.grid(), gyy = A.view.grid();
@@ -1471,6 +1513,7 @@ static void check_restart(RestartState *rs, int iter, int check_iter, double sig
 
 void Solver::update_sigma_and_restart(RestartState *rs, const Residuals &r) {
     if (rs->flag <= 0) return;
+    small_resid_ready = false;
     // movement x_bar - last_x, y_bar - last_y and their norms (update_sigma, main_iterate.cu:367-404)
     launch_movement(n_loc, m_loc, x_bar, last_x.p, x_temp, y_bar, last_y.p, y_temp.p, part_v.p, kReduceBlocks,
                     kReduceBlocks, stream);
@@ -1589,10 +1632,7 @@ void Solver::solve_loop(HPRLP_results *out) {
             rs.last_gap = weighted_norm_after_restart();
             ++it;
         }
-        if (it < next) {
-            run_normal(next - 1 - it);
-            step(true);
-        }
+        if (it < next) run_normal_then_check(next - 1 - it);
         rs.inner += next - iter;
         iter = next;
     }

@@ -166,6 +166,11 @@ struct Solver {
     void reset_iterates();                                          // all iterates back to zero (as after create + scale + power iteration)
     void step(bool check);                                          // one HPR iteration
     void run_normal(int count);                                     // count normal iterations (graph replay)
+    // count normal iterations, then one check-variant iteration.  Netlib-scale LPs on one GPU: the check iteration AND the
+    // residual evaluation of the state it leaves in ONE launch of the single-workgroup kernel (small.hip: SmallTail) -- the
+    // next compute_residuals() only fetches the sums (small_resid_ready).  Everything else: run_normal + step(true).
+    void run_normal_then_check(int count);
+    bool small_resid_ready = false;
     void fetch_scalars();
     void compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs);  // main_iterate.cu:229-309
     double weighted_norm_after_restart();                           // main_iterate.cu:486-515

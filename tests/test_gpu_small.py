@@ -14,6 +14,7 @@ from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
 pytestmark = pytest.mark.gpu
 
 VECS = ("x", "x_hat", "y", "last_x", "last_y")
+CHECK_VECS = ("x_bar", "z_bar", "x_temp", "y_bar", "y_obj", "y_temp")  # what a check-variant step leaves besides
 
 
 def make(lp):
@@ -27,6 +28,7 @@ def iterate_states(model, prm, plan, no_small):
     # (what is compared bit for bit are the ITERATION kernels: lambda_max comes from the regular power iteration in both runs;
     # the single-launch one adds its dot products in another order -- test_small_power_iteration_matches_... below)
     os.environ["HPRLP_NO_SMALL_POWER"] = "1"
+    os.environ["HPRLP_SMALL_CHECK"] = "1"   # the fused check + residual launch (off by default: measured no faster)
     try:
         s = hprlp.Solver(model, prm)
         assert bool(s.info()["tiled"] & 4) == (not no_small)
@@ -34,15 +36,23 @@ def iterate_states(model, prm, plan, no_small):
         lam, _ = s.power_iteration()
         s.init(-1.0, lam * 1.01)
         out = []
+        done = 0
+        res_after_check = []
         for normal, check in plan:
             s.iterate(normal, check)
-            out.append({k: s.get(k) for k in VECS})
+            done += normal + (1 if check else 0)
+            out.append({k: s.get(k) for k in VECS + (CHECK_VECS if check else ())})
             out[-1]["k"] = (s.scalars()["kx"], s.scalars()["ky"])
-        res = s.residuals(sum(a + (1 if b else 0) for a, b in plan), True)
+            if check:
+                # right behind a check step: on the small path the step's own launch has formed the sums (small.hip: SmallTail),
+                # the call only fetches them; otherwise the regular residual kernels run
+                res_after_check.append(s.residuals(done, True))
+        res = s.residuals(done, True)
         s.close()
-        return out, res
+        return out, res, res_after_check
     finally:
         os.environ.pop("HPRLP_NO_SMALL_POWER", None)
+        os.environ.pop("HPRLP_SMALL_CHECK", None)
         if old is None:
             os.environ.pop("HPRLP_NO_SMALL", None)
         else:
@@ -58,8 +68,8 @@ def test_small_kernel_equals_regular_kernels_bit_for_bit(gpu, shape):
     model = make(lp)
     prm = hprlp.Parameters(use_presolve=False)
     plan = [(1, False), (7, True), (64, False), (149, True), (3, False)]
-    small, res_s = iterate_states(model, prm, plan, no_small=False)
-    regular, res_r = iterate_states(model, prm, plan, no_small=True)
+    small, res_s, chk_s = iterate_states(model, prm, plan, no_small=False)
+    regular, res_r, chk_r = iterate_states(model, prm, plan, no_small=True)
     # The single-workgroup kernel adds every row in CSR order; the regular kernels do so for rows of up to 64 entries
     # (kernels.h: kLongRow) and hand longer rows to a whole wave (strided partial sums + a wave sum).  Shapes without such
     # rows must agree bit for bit, the others to rounding.
@@ -68,23 +78,31 @@ def test_small_kernel_equals_regular_kernels_bit_for_bit(gpu, shape):
     longest = max(np.diff(A.indptr).max(), np.diff(A.tocsc().indptr).max())
     for a, b in zip(small, regular):
         assert a["k"] == b["k"]
-        for k in VECS:
+        for k in [q for q in a if q != "k"]:
             if longest <= 64:
                 assert np.array_equal(a[k], b[k]), k
             else:
                 np.testing.assert_allclose(a[k], b[k], rtol=1e-11, atol=1e-13, err_msg=k)
     for k in res_r:
-        if longest <= 64:
-            assert res_s[k] == res_r[k], k
-        else:
-            assert abs(res_s[k] - res_r[k]) <= 1e-9 * (1 + abs(res_r[k])), k
+        # (the objective terms and |x_temp|, |y_temp| were summed by the last check step: in the fused launch's order on the small path)
+        tol = 1e-12 if longest <= 64 else 1e-9
+        assert abs(res_s[k] - res_r[k]) <= tol * (1 + abs(res_r[k])), k
+    # the residual evaluations formed inside the check step's launch (round 4): the same sums in another order
+    assert len(chk_s) == len(chk_r) == 2
+    for rs, rr in zip(chk_s, chk_r):
+        for k in rr:
+            tol = 1e-12 if longest <= 64 else 1e-9
+            assert abs(rs[k] - rr[k]) <= tol * (1 + abs(rr[k])), (k, rs[k], rr[k])
     model.free()
 
 
+@pytest.mark.parametrize("fused_check", [False, True])
 @pytest.mark.parametrize("dense", [0.0, 0.01])
-def test_small_kernel_matches_oracle(gpu, dense):
+def test_small_kernel_matches_oracle(gpu, dense, fused_check, monkeypatch):
     """Normal steps by the single-workgroup kernel, check steps by the regular kernels, against the oracle: bit for bit when no
     row has more than 64 entries (kLongRow: the regular kernels add longer rows wave-wide), to rounding otherwise."""
+    if fused_check:   # check step + residual sums in one single-workgroup launch (small.hip: SmallTail)
+        monkeypatch.setenv("HPRLP_SMALL_CHECK", "1")
     m, n = 400, 650
     lp = lpgen.planted_lp(m, n, 4000, 8, dense_col_frac=dense)
     model = make(lp)
