@@ -89,6 +89,8 @@ struct FarPush {
     const int *pos = nullptr;
     const uint16_t *lcol = nullptr;
     double *P = nullptr;
+    // run tables of the consumer's source side (tiled.h: f_rptr / f_rk / f_rp); null: positions come from `pos`
+    const int *rptr = nullptr, *rk = nullptr, *rp = nullptr;
 };
 
 struct XHalfArgs {

@@ -767,6 +767,66 @@ __device__ __forceinline__ void push_products(const FarPush &f, const double *va
     }
 }
 
+// P position of entry k of a source group's list from the group's run table in LDS (tiled.h: f_rk / f_rp): the last run that
+// starts at or before k.  Neighbouring lanes hold neighbouring entries -- mostly the same run: the reads are broadcasts.
+__device__ __forceinline__ int run_position(const int *tab_k, const int *tab_p, int nr, int k) {
+    int lo = 0, hi = nr - 1;  // tab_k[0] <= k
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab_k[mid] <= k) lo = mid;
+        else hi = mid - 1;
+    }
+    return tab_p[lo] + (k - tab_k[lo]);
+}
+
+// push_products without reading f.pos: the consumer's run tables give the positions (all-remainder form: 18 instead of 22 bytes
+// of traffic per entry on this side).  tab: 2 * kPbRunTabCap ints of LDS nobody else uses; g: the source group.
+__device__ __forceinline__ void push_products_runs(const FarPush &f, const double *vals, int *tab, int g, int pb, int pe, int tid) {
+    constexpr int NT = kTileThreads, U = 4;
+    if (pb >= pe) return;  // (uniform)
+    const int r0 = f.rptr[g], nr = f.rptr[g + 1] - r0;
+    int *tab_k = tab, *tab_p = tab + kPbRunTabCap;
+    double a4[U];
+    uint16_t c4[U];
+    auto load_batch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = min(k0 + u * NT, pe - 1);  // clamped: branch-free, surplus lanes are masked at the store
+            a4[u] = __builtin_nontemporal_load(f.val + z);
+            c4[u] = __builtin_nontemporal_load(f.lcol + z);
+        }
+    };
+    int k = pb + tid;
+    load_batch(k);
+    for (int i = tid; i < nr; i += NT) {
+        tab_k[i] = f.rk[r0 + i];
+        tab_p[i] = f.rp[r0 + i];
+    }
+    lds_barrier();
+    // the positions of a batch are looked up while its loads are in flight (they depend on the entry index only)
+    int ps[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ps[u] = run_position(tab_k, tab_p, nr, min(k + u * NT, pe - 1));
+    for (; k < pe; k += U * NT) {
+        double prd[U];
+        int pc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            prd[u] = a4[u] * vals[c4[u]];
+            pc[u] = ps[u];
+        }
+        const int kn = k + U * NT;
+        if (kn < pe) load_batch(kn);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + u * NT < pe) f.P[pc[u]] = prd[u];
+        if (kn < pe) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ps[u] = run_position(tab_k, tab_p, nr, min(kn + u * NT, pe - 1));
+        }
+    }
+}
+
 template <class Epi, bool REP, bool PUSH = false, bool NARROW = false>
 __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi epi) {  // 4 waves per SIMD = two workgroups per CU
     static_assert(Epi::NV == 1, "the tiled kernel stages one gathered vector");
@@ -899,7 +959,8 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
             // hand-off (kernels.h: FarPush), as in k_tiled_fused: this super-block's fresh values are source group `sb` of the
             // other matrix' lists
             lds_barrier();
-            push_products(epi.push, acc, pb, pe, tid);
+            if (epi.push.rk) push_products_runs(epi.push, acc, reinterpret_cast<int *>(prod), sb, pb, pe, tid);  // (prod is free by now)
+            else push_products(epi.push, acc, pb, pe, tid);
         }
         PB_STAMP(6);
     }
@@ -1074,6 +1135,70 @@ __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const 
         for (int u = 0; u < U; ++u)
             if (k + u * kFarThreads < e) t.P[ps[u]] = pr[u];
     }
+}
+
+// The same pre-pass for a consumer with run tables (all-remainder form, source groups of at most kPbRowsMax columns): positions
+// from the group's run table in LDS instead of 4 bytes of f_pos per entry.
+template <bool LOGTERM = false>
+__global__ void __launch_bounds__(kFarThreads) k_far_products_runs(TiledDev t, const double *__restrict__ vec, int ncols) {
+    __shared__ double v[kPbRowsMax];
+    __shared__ int tab[2 * kPbRunTabCap];
+    const int per = (t.n_groups + 7) / 8;
+    const int G = t.G;
+    const int g = (blockIdx.x % 8) * per + blockIdx.x / 8, c0 = g * G, tid = threadIdx.x;
+    if (g >= t.n_groups) return;
+    const int b = t.f_gptr[g], e = t.f_gptr[g + 1];
+    if (b >= e) return;
+    const int w = min(G, ncols - c0);
+    const int r0 = t.f_rptr[g], nr = t.f_rptr[g + 1] - r0;
+    int *tab_k = tab, *tab_p = tab + kPbRunTabCap;
+    constexpr int U = 4;
+    double a[U];
+    uint16_t lc[U];
+    int k = b + tid;
+    auto load_batch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = min(k0 + u * kFarThreads, e - 1);
+            a[u] = __builtin_nontemporal_load(t.f_val + q);
+            lc[u] = __builtin_nontemporal_load(t.f_lcol + q);
+        }
+    };
+    load_batch(k);
+    for (int i = tid; i < G; i += kFarThreads) v[i] = vec[c0 + min(i, w - 1)];
+    for (int i = tid; i < nr; i += kFarThreads) {
+        tab_k[i] = t.f_rk[r0 + i];
+        tab_p[i] = t.f_rp[r0 + i];
+    }
+    __syncthreads();
+    int ps[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ps[u] = run_position(tab_k, tab_p, nr, min(k + u * kFarThreads, e - 1));
+    for (; k < e; k += U * kFarThreads) {
+        double pr[U];
+        int pc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pr[u] = LOGTERM ? a[u] - v[lc[u]] : a[u] * v[lc[u]];
+            pc[u] = ps[u];
+        }
+        const int kn = k + U * kFarThreads;
+        if (kn < e) load_batch(kn);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + u * kFarThreads < e) t.P[pc[u]] = pr[u];
+        if (kn < e) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ps[u] = run_position(tab_k, tab_p, nr, min(kn + u * kFarThreads, e - 1));
+        }
+    }
+}
+
+template <bool LOGTERM>
+static void launch_far_products(const TiledDev &t, const double *vec, int ncols, hipStream_t s) {
+    const dim3 grid((t.n_groups + 7) / 8 * 8);
+    if (t.f_rk && t.G <= kPbRowsMax) hipLaunchKernelGGL(k_far_products_runs<LOGTERM>, grid, dim3(kFarThreads), 0, s, t, vec, ncols);
+    else hipLaunchKernelGGL(k_far_products<LOGTERM>, grid, dim3(kFarThreads), 0, s, t, vec, ncols);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1443,7 +1568,7 @@ static bool launch_fused(const CsrDev &M, const Epi &e, hipStream_t s, bool far_
 template <class Epi>
 static bool launch_tiled(const CsrDev &M, const Epi &e, hipStream_t s, bool far_ready) {
     if (M.tiled.n_groups > 0 && !far_ready)
-        hipLaunchKernelGGL(k_far_products<false>, dim3((M.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, M.tiled, e.gv[0], M.cols);
+        launch_far_products<false>(M.tiled, e.gv[0], M.cols, s);
     // copies with narrow tiles (tiled.h: kTileColsNarrow) run their own instantiation of the sweep, without the repeated-tile
     // shortcut (re-staging 8 KiB is cheap; REP only saves work, it is not needed for correctness)
     const bool narrow = M.tiled.T == kTileColsNarrow;
@@ -1488,6 +1613,11 @@ FarPush far_push_of(const CsrDev &consumer) {
         f.pos = consumer.tiled.f_pos;
         f.lcol = consumer.tiled.f_lcol;
         f.P = consumer.tiled.P;
+        if (consumer.tiled.f_rk) {
+            f.rptr = consumer.tiled.f_rptr;
+            f.rk = consumer.tiled.f_rk;
+            f.rp = consumer.tiled.f_rp;
+        }
     }
     return f;
 }
@@ -1730,7 +1860,7 @@ void launch_cr_log_update(const CsrDev &M, const double *other_full, double *res
         L.tiled.tval = tval_log;
         L.tiled.f_val = fval_log;
         if (L.tiled.n_groups > 0)
-            hipLaunchKernelGGL(k_far_products<true>, dim3((L.tiled.n_groups + 7) / 8 * 8), dim3(kFarThreads), 0, s, L.tiled, other_full, L.cols);
+            launch_far_products<true>(L.tiled, other_full, L.cols, s);
         if (L.tiled.rem_cap == kPbRemCap) hipLaunchKernelGGL((k_pb_fused<CrEpi, false>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);  // all-remainder form
         else if (L.tiled.T == kTileColsNarrow) hipLaunchKernelGGL((k_tiled_fused<CrEpi, false, false, true>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);
         else if (L.tiled.repeats) hipLaunchKernelGGL((k_tiled_fused<CrEpi, true>), dim3(L.tiled.grid), dim3(kTileThreads), 0, s, L, e);

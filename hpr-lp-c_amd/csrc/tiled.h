@@ -46,6 +46,7 @@ constexpr int kPbRemK = 6;                        // remainder entries per lane 
 constexpr int kPbRemCap = kTileThreads * kPbRemK;  // 3072
 constexpr int kPbRowsMax = 4096;
 constexpr int kPbRun = 32;
+constexpr int kPbRunTabCap = 3072;                 // run-table entries a producer holds in LDS (two ints each: 24 KiB)
 constexpr int kTileMaxRow = 1024;  // matrices with a longer row are not tiled: a long row's remainder entries all go through ONE workgroup
                                    // (2M x 2M, five rows of L entries, per launch: L = 1000 192 us, 3000 265-327 us, 8000 433-470 us; stream kernel 262 us)
 constexpr int kTileDenseMin = 256;                                            // entries for a tile to be staged
@@ -125,6 +126,13 @@ struct TiledDev {
     const double *f_val = nullptr;
     const int *f_pos = nullptr;       // position in P
     const uint16_t *f_lcol = nullptr; // column - group * kFarGroup
+    // Run tables of the source side (all-remainder form): inside a source group's list the P positions ascend in runs -- one run
+    // per destination super-block -- so position = f_rp[run] + (entry - f_rk[run]); the producers look the run up (a table of
+    // at most kPbRunTabCap runs per group in LDS, binary search) instead of reading 4 bytes of f_pos per entry.
+    const int *f_rptr = nullptr;      // n_groups + 1: runs of a group
+    const int *f_rk = nullptr;        // first entry (index into the f lists) of a run
+    const int *f_rp = nullptr;        // its position in P
+    int f_maxruns = 0;                // most runs in one group (0: no tables)
 };
 
 // Host-side result of the analysis; perm arrays give, for every stored entry, its index in the CSR
@@ -165,6 +173,7 @@ struct DeviceTiled {
     DBuf<double> P, f_val;
     DBuf<uint32_t> rq;
     DBuf<int> f_gptr, f_pos, f_perm;
+    DBuf<int> f_rptr, f_rk, f_rp;
     DBuf<uint16_t> f_lcol;
     TiledDev view;
     long n_tile = 0, n_rem = 0;

@@ -677,6 +677,37 @@ __global__ void __launch_bounds__(kThreads) k_far_gptr(int ngroups, int n, const
     gptr[g] = lo;
 }
 
+// run tables of the source side (tiled.h: f_rk / f_rp / f_rptr): entry f starts a run if it is the first of its group or its
+// P position does not follow its predecessor's
+__global__ void __launch_bounds__(kThreads) k_far_run_flags(int n, const unsigned long long *__restrict__ skey, const int *__restrict__ f_pos,
+                                                           int *__restrict__ flag) {
+    const int f = blockIdx.x * kThreads + threadIdx.x;
+    if (f >= n) return;
+    flag[f] = (f == 0 || (skey[f] >> 32) != (skey[f - 1] >> 32) || f_pos[f] != f_pos[f - 1] + 1) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kThreads) k_far_run_fill(int n, const int *__restrict__ flag, const int *__restrict__ run_excl,
+                                                          const int *__restrict__ f_pos, int *__restrict__ rk, int *__restrict__ rp) {
+    const int f = blockIdx.x * kThreads + threadIdx.x;
+    if (f >= n || !flag[f]) return;
+    rk[run_excl[f]] = f;
+    rp[run_excl[f]] = f_pos[f];
+}
+
+// rptr[g] = runs before group g's first entry (a group's first entry starts a run); rptr[ngroups] = all runs
+__global__ void __launch_bounds__(kThreads) k_far_rptr(int ngroups, int n, int nruns, const int *__restrict__ gptr, const int *__restrict__ run_excl,
+                                                      int *__restrict__ rptr, int *__restrict__ maxruns) {
+    const int g = blockIdx.x * kThreads + threadIdx.x;
+    if (g > ngroups) return;
+    const int f = gptr[g];
+    rptr[g] = f < n ? run_excl[f] : nruns;
+    if (g < ngroups) {
+        const int f1 = gptr[g + 1];
+        const int r1 = f1 < n ? run_excl[f1] : nruns;
+        atomicMax(maxruns, r1 - rptr[g]);
+    }
+}
+
 void sort_pairs(DBuf<unsigned long long> &kin, DBuf<unsigned long long> &kout, DBuf<int> &vin, DBuf<int> &vout, int n, int end_bit, hipStream_t s) {
     size_t bytes = 0;
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin.p, kout.p, vin.p, vout.p, n, 0, end_bit, s));
@@ -752,6 +783,45 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
     hipLaunchKernelGGL(k_far_gptr, dim3(grid_for(ngroups + 1)), dim3(kThreads), 0, s, ngroups, n, kout.p, f_gptr.p);
     P.alloc_zero(static_cast<size_t>(n) + 8);
     HIP_CHECK(hipStreamSynchronize(s));
+    view.f_rptr = view.f_rk = view.f_rp = nullptr;
+    view.f_maxruns = 0;
+    if (view.rem_cap == kPbRemCap) {
+        // all-remainder form: run tables, so that the producers need not read f_pos (4 of the 22 bytes per entry they move)
+        DBuf<int> flag(static_cast<size_t>(n)), excl(static_cast<size_t>(n));
+        hipLaunchKernelGGL(k_far_run_flags, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kout.p, f_pos.p, flag.p);
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flag.p, excl.p, n, s));
+        {
+            DBuf<char> tmp(bytes + 16);
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, flag.p, excl.p, n, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        int last_excl = 0, last_flag = 0;
+        HIP_CHECK(hipMemcpy(&last_excl, excl.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&last_flag, flag.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost));
+        const int nruns = last_excl + last_flag;
+        f_rk.alloc(static_cast<size_t>(nruns) + 8);
+        f_rp.alloc(static_cast<size_t>(nruns) + 8);
+        f_rptr.alloc(static_cast<size_t>(ngroups) + 1);
+        DBuf<int> mx;
+        mx.alloc_zero(1);
+        hipLaunchKernelGGL(k_far_run_fill, dim3(grid_for(n)), dim3(kThreads), 0, s, n, flag.p, excl.p, f_pos.p, f_rk.p, f_rp.p);
+        hipLaunchKernelGGL(k_far_rptr, dim3(grid_for(ngroups + 1)), dim3(kThreads), 0, s, ngroups, n, nruns, f_gptr.p, excl.p, f_rptr.p, mx.p);
+        int h_mx = 0;
+        HIP_CHECK(hipMemcpyAsync(&h_mx, mx.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        // (only where runs are long: with 14 entries per run -- the config-3 recipe x 30 -- neighbouring lanes sit in different
+        // runs, the lookups stop being broadcasts and the table costs more than the 4 bytes it saves: measured +6-8 %)
+        if (h_mx > 0 && h_mx <= kPbRunTabCap && static_cast<long>(n) >= 48L * nruns) {
+            view.f_rptr = f_rptr.p;
+            view.f_rk = f_rk.p;
+            view.f_rp = f_rp.p;
+            view.f_maxruns = h_mx;
+        }
+        if (std::getenv("HPRLP_TIMING"))
+            std::fprintf(stderr, "[timing]   source-side run tables: %d runs of %d entries (%.1f per run), most in one group %d%s\n", nruns, n,
+                         static_cast<double>(n) / std::max(nruns, 1), h_mx, view.f_rk ? "" : " -- not used (too many for the producers' LDS table)");
+    }
     rcol.release(); rrow.release(); rperm.release();
     view.P = P.p;
     view.rq = rq.p;
