@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iomanip>
 #include <iostream>
 #include <limits>
@@ -25,8 +26,21 @@ constexpr int kDeviceStartRows = 1000000;  // power iteration: start vectors lon
 constexpr int kPowerBlockKey = -10;  // Solver::graphs: the power iteration's block of ten iterations (positive keys: normal iterations)
 
 // ------------------------------------------------------------------------------------------------
-std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows) {
+// cuts (optional): for rows that are to be split at given entries -- row index -> ascending chunk starts relative to the row's
+// first entry (the first one is 0) and the XCD share (0..7) each chunk should run on, -1 for "anywhere".  See slab_cuts().
+struct RowCuts {
+    std::vector<int> rows;                 // ascending
+    std::vector<std::vector<int>> starts;  // per row
+    std::vector<std::vector<int>> share;   // per chunk
+    int find(int r) const {
+        const auto it = std::lower_bound(rows.begin(), rows.end(), r);
+        return it != rows.end() && *it == r ? static_cast<int>(it - rows.begin()) : -1;
+    }
+};
+
+static std::vector<int4> build_row_blocks_cut(int rows, const int *rowptr, std::vector<int4> *longrows, const RowCuts *cuts) {
     std::vector<int4> blk;
+    std::vector<int> blk_share;  // wanted XCD share of a block, -1: none
     blk.reserve(static_cast<size_t>(rows) / 8 + 16);
     // block shape: at most cap_rows rows and cap_nnz nonzeros per wave (tuning knobs; the kernel needs
     // rows <= kStreamRows and nonzeros <= kStreamW)
@@ -38,18 +52,35 @@ std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4
     int r = 0, slots = 0;
     while (r < rows) {
         const int len = rowptr[r + 1] - rowptr[r];
+        const int cq = (cuts && longrows) ? cuts->find(r) : -1;
+        if (cq >= 0) {
+            // a dense row cut where its columns cross into another XCD's eighth of the gathered vector (slab_cuts)
+            const std::vector<int> &st = cuts->starts[cq];
+            const int first = slots;
+            for (size_t q = 0; q < st.size(); ++q) {
+                const int b0 = st[q], e0 = q + 1 < st.size() ? st[q + 1] : len;
+                blk.push_back(make_int4(slots++, 0, rowptr[r] + b0, e0 - b0));
+                blk_share.push_back(cuts->share[cq][q]);
+            }
+            longrows->push_back(make_int4(r, first, slots, 0));
+            ++r;
+            continue;
+        }
         if (len > kSplitRow && longrows) {
             // a dense row/column (LPs have them): kSplitRow-sized chunks on separate waves, descriptor
             // {chunk slot, 0, first nonzero, count}; the row itself is finished by k_long_finish
             const int first = slots;
-            for (int k = rowptr[r]; k < rowptr[r + 1]; k += kSplitRow)
+            for (int k = rowptr[r]; k < rowptr[r + 1]; k += kSplitRow) {
                 blk.push_back(make_int4(slots++, 0, k, std::min(kSplitRow, rowptr[r + 1] - k)));
+                blk_share.push_back(-1);
+            }
             longrows->push_back(make_int4(r, first, slots, 0));
             ++r;
             continue;
         }
         if (len > kLongRow) {
             blk.push_back(make_int4(r, 1, rowptr[r], len));
+            blk_share.push_back(-1);
             ++r;
             continue;
         }
@@ -62,26 +93,98 @@ std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4
             ++r;
         }
         blk.push_back(make_int4(start, r - start, rowptr[start], nz));
+        blk_share.push_back(-1);
     }
     // The stream kernel gives every XCD a contiguous eighth of the block list (kernels.hip: k_spmv_fused), and a vector-mode
-    // block -- a long row or a 4096-entry chunk of a split row -- is up to eight times the work of a stream block.  LPs carry
-    // such rows in bunches (linking constraints at the end of a block-angular model: 400 chunk blocks in the last XCD's range
-    // made that XCD's share 1.6 x the others').  Spread the heavy blocks evenly over the list; the others keep their order
-    // (neighbouring rows stay neighbours), the heavy ones theirs (split-row chunk slots ascend).
-    if (blk.size() >= 256) {
-        std::vector<int4> light, heavy;
-        for (const int4 &d : blk) (d.y == 0 || (d.y == 1 && d.w > kLongRow) ? heavy : light).push_back(d);
-        if (!heavy.empty() && !light.empty()) {
-            const size_t N = blk.size(), H = heavy.size();
-            size_t ih = 0, il = 0;
-            for (size_t i = 0; i < N; ++i) {
-                // heavy block ih belongs at position ih * N / H
-                if (ih < H && (il >= light.size() || ih * N / H <= i)) blk[i] = heavy[ih++];
-                else blk[i] = light[il++];
+    // block -- a long row or a chunk of a split row -- is up to eight times the work of a stream block.  LPs carry such rows
+    // in bunches (linking constraints at the end of a block-angular model: 400 chunk blocks in the last XCD's range made that
+    // XCD's share 1.6 x the others').  Chunks with a wanted share go to the front of that share (their columns lie in the
+    // eighth of the vector that share's rows mostly read: one L2 holds it); the other heavy blocks are spread evenly; light
+    // blocks keep their order (neighbouring rows stay neighbours); split-row chunk slots keep ascending inside a share.
+    const size_t N = blk.size();
+    if (N >= 256) {
+        std::vector<int4> light, heavy, pinned[8];
+        for (size_t i = 0; i < N; ++i) {
+            const int4 &d = blk[i];
+            if (blk_share[i] >= 0) pinned[blk_share[i] & 7].push_back(d);
+            else if (d.y == 0 || (d.y == 1 && d.w > kLongRow)) heavy.push_back(d);
+            else light.push_back(d);
+        }
+        size_t npinned = 0;
+        for (int x = 0; x < 8; ++x) npinned += pinned[x].size();
+        if ((!heavy.empty() || npinned > 0) && !light.empty()) {
+            // the shares' block ranges, as k_spmv_fused maps them: grid = ceil(N / 4) workgroups of 4 blocks
+            const size_t grid = (N + kWavesPerBlock - 1) / kWavesPerBlock, per_lo = grid >> 3, rem = grid & 7;
+            size_t ih = 0, il = 0, pos = 0;
+            const size_t rest = N - npinned, H = heavy.size();
+            size_t placed_rest = 0;  // light + evenly spread heavy blocks placed so far
+            for (int x = 0; x < 8; ++x) {
+                const size_t wg0 = x * per_lo + std::min<size_t>(x, rem), wg1 = wg0 + per_lo + (static_cast<size_t>(x) < rem ? 1 : 0);
+                const size_t end = std::min(N, wg1 * kWavesPerBlock);
+                size_t ip = 0;
+                while (pos < end) {
+                    if (ip < pinned[x].size()) {
+                        blk[pos++] = pinned[x][ip++];
+                        continue;
+                    }
+                    // heavy block ih belongs at position ih * rest / H of the unpinned sequence
+                    if (ih < H && (il >= light.size() || ih * rest / H <= placed_rest)) blk[pos++] = heavy[ih++];
+                    else if (il < light.size()) blk[pos++] = light[il++];
+                    else break;
+                    ++placed_rest;
+                }
+                // pinned chunks that did not fit their share (more of them than the share holds) spill into the next one
+                if (ip < pinned[x].size()) {
+                    std::vector<int4> &nx = pinned[std::min(x + 1, 7)];
+                    if (x < 7) nx.insert(nx.begin(), pinned[x].begin() + static_cast<long>(ip), pinned[x].end());
+                    else throw std::runtime_error("row blocks: pinned chunks exceed the block list");
+                }
             }
+            if (pos != N || ih != H || il != light.size()) throw std::runtime_error("row blocks: arrangement lost a block");
         }
     }
     return blk;
+}
+
+std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows) {
+    return build_row_blocks_cut(rows, rowptr, longrows, nullptr);
+}
+
+// Dense rows of a large matrix, cut at the columns where the gathered vector's XCD eighths meet.  A row of thousands of entries
+// gathers from all over the vector: every gather pulls a 128-byte line into the L2 of whichever XCD runs the chunk, and 200
+// such rows (linking constraints) were a third of the y-half's memory traffic on the block-angular ladder point.  Chunks by
+// column eighth, each run by the XCD whose own rows read that eighth anyway: the lines are fetched once.  cols_of(row, out):
+// the row's column indices (host copy or a download).
+constexpr int kSlabSplitMin = 2048;   // rows at least this long are cut by column eighths (shorter ones: one wave, anywhere)
+constexpr int kSlabChunkMin = 96;     // a chunk shorter than this joins its predecessor
+template <class ColsOf>
+static RowCuts slab_cuts(int rows, int cols, const int *rp, ColsOf cols_of) {
+    RowCuts rc;
+    const int W = (cols + 7) / 8;
+    std::vector<int> ci;
+    for (int r = 0; r < rows; ++r) {
+        const int len = rp[r + 1] - rp[r];
+        if (len < kSlabSplitMin) continue;
+        ci.resize(static_cast<size_t>(len));
+        cols_of(r, ci.data());
+        std::vector<int> st{0}, sh{std::min(ci[0] / W, 7)};
+        for (int k = 1; k < len; ++k) {
+            const int slab = std::min(ci[k] / W, 7);
+            const bool too_long = k - st.back() >= kSplitRow;
+            if ((slab != sh.back() && k - st.back() >= kSlabChunkMin) || too_long) {
+                st.push_back(k);
+                sh.push_back(slab);
+            }
+        }
+        if (st.size() > 1 && len - st.back() < kSlabChunkMin) {  // a short tail joins its predecessor
+            st.pop_back();
+            sh.pop_back();
+        }
+        rc.rows.push_back(r);
+        rc.starts.push_back(std::move(st));
+        rc.share.push_back(std::move(sh));
+    }
+    return rc;
 }
 
 // HPRLP_TIMING=1: wall time of the set-up phases on stderr
@@ -135,16 +238,35 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
     view.tiled = TiledDev();
     const int nnz = rp[rows];
     std::vector<int4> lr;
-    std::vector<int4> b = build_row_blocks(rows, rp, &lr);
+    // dense rows of a matrix whose gathered vector is beyond one L2: cut by column eighths (slab_cuts); the column indices of
+    // those rows come from the host copy or, for a matrix built on the device, from a download of just those rows
+    RowCuts cuts;
+    const char *noslab = std::getenv("HPRLP_NO_SLAB_CUTS");
+    if (cols >= (1 << 19) && nnz >= (1 << 22) && !(noslab && noslab[0] == '1')) {
+        const int *hci = ci;
+        const int *dcol = col.p;
+        cuts = slab_cuts(rows, cols, rp, [&](int r, int *out) {
+            const size_t len = static_cast<size_t>(rp[r + 1] - rp[r]);
+            if (hci) std::memcpy(out, hci + rp[r], len * sizeof(int));
+            else HIP_CHECK(hipMemcpy(out, dcol + rp[r], len * sizeof(int), hipMemcpyDeviceToHost));
+        });
+    }
+    std::vector<int4> b = build_row_blocks_cut(rows, rp, &lr, cuts.rows.empty() ? nullptr : &cuts);
     int nslots = 0;
+    std::vector<char> seen;
     for (const int4 &d : b) {
         const bool vec = d.y == 0 || (d.y == 1 && d.w > kLongRow);
         if (d.y == 0) {
-            if (d.w < 1 || d.w > kSplitRow || d.x != nslots++) throw std::runtime_error("bad split-row block");
+            // (chunk slots: each exactly once -- the arrangement by XCD shares moves chunks, k_long_finish adds a row's slots in order)
+            if (d.w < 1 || d.w > kSplitRow || d.x < 0) throw std::runtime_error("bad split-row block");
+            if (static_cast<size_t>(d.x) >= seen.size()) seen.resize(static_cast<size_t>(d.x) + 1, 0);
+            if (seen[d.x]++) throw std::runtime_error("bad split-row block: slot used twice");
+            ++nslots;
         } else if (!vec && (d.w > kStreamW || d.y > kStreamRows || d.y < 1)) {
             throw std::runtime_error("bad row block");
         }
     }
+    if (static_cast<size_t>(nslots) != seen.size()) throw std::runtime_error("bad split-row blocks: slots not contiguous");
     blk.alloc(b.size());
     blk.upload(b.data(), b.size());
     pt.tick("  row blocks");

@@ -1,5 +1,7 @@
 """Edge cases of the boundary on the GPU: ragged/empty rows, infinite and free bounds, CSC input,
 limits and error statuses (behaviour of reference src/HPRLP.cu:321-524, main_iterate.cu:406-420)."""
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -188,6 +190,69 @@ def test_dense_rows_and_columns_are_split(gpu):
     assert r.status == "OPTIMAL"
     want = highs(A, AL, AU, l, u, c)
     assert abs(r.primal_obj - want) <= 1e-4 * (1 + abs(want))
+    model.free()
+
+
+def test_dense_rows_of_a_large_matrix_are_cut_by_column_eighths(gpu):
+    """Round 4 (solver.cpp: slab_cuts): in a matrix whose gathered vector is beyond one L2 (>= 2^19 columns, >= 2^22 entries)
+    a row of 2048 entries and more is cut where its columns cross into another eighth of the vector, the chunks are pinned to
+    the XCD share whose own rows read that eighth, k_long_finish adds them in order.  Rows / columns of 2048 .. 9000 entries
+    (one of them with all its entries in ONE eighth, one with a 4097-entry run in one eighth: cut again at kSplitRow) in a
+    block-diagonal matrix: iterates against the oracle over normal and check steps, and against the uncut form."""
+    from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
+    rng = np.random.default_rng(12)
+    m, n, per_row = 560_000, 640_000, 8
+    blk = 80   # diagonal blocks: 7000 rows x 8000 columns
+    r = np.repeat(np.arange(m), per_row)
+    c = (r // (m // blk)) * (n // blk) + rng.integers(0, n // blk, size=len(r))
+    rows, cols = [r], [c]
+    for i, L in zip(rng.choice(m, 4, replace=False), (2048, 3000, 5000, 9000)):       # dense rows of A over all columns
+        rows.append(np.full(L, i)); cols.append(rng.choice(n, L, replace=False))
+    i1 = int(rng.integers(0, m))
+    rows.append(np.full(2500, i1)); cols.append(3 * (n // 8) + rng.choice(n // 8 - 10, 2500, replace=False))   # all in one eighth
+    i2 = int(rng.integers(0, m))
+    rows.append(np.full(4500, i2)); cols.append(5 * (n // 8) + rng.choice(n // 8 - 10, 4500, replace=False))   # > kSplitRow in one eighth
+    for j, L in zip(rng.choice(n, 3, replace=False), (2100, 4097, 7000)):              # dense columns (rows of A^T)
+        rows.append(rng.choice(m, L, replace=False)); cols.append(np.full(L, j))
+    rr, cc = np.concatenate(rows), np.concatenate(cols)
+    A = sparse.csr_matrix((np.ones(len(rr)), (rr, cc)), shape=(m, n))
+    A.sum_duplicates()
+    A.data = rng.uniform(0.5, 1.5, size=A.nnz) * rng.choice([-1.0, 1.0], size=A.nnz)
+    A.sort_indices()
+    assert A.nnz >= 1 << 22 and np.diff(A.indptr).max() >= 9000 and np.diff(A.tocsc().indptr).max() >= 7000
+    x0 = rng.uniform(0, 1, n)
+    b = A @ x0
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    AL, AU, l, u, cost = b - 0.5, b + 0.5, np.zeros(n), np.full(n, 2.0), rng.uniform(-1, 1, n)
+    model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, cost)
+    ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, cost, O.Params.default(use_CR_scaling=0))
+    states = {}
+    for cut in (True, False):
+        os.environ["HPRLP_NO_TILED"] = "1"   # (this pattern would take the tiled kernel with its long rows aside: here the stream kernel's rows are meant)
+        if not cut:
+            os.environ["HPRLP_NO_SLAB_CUTS"] = "1"
+        try:
+            s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+            assert s.info()["tiled"] == 0
+            d = s.describe()
+            nsplit = [int(x) for x in __import__("re").findall(r"(\d+) split rows", d)]
+            assert nsplit == ([6, 3] if cut else [3, 2]), d     # cut: every row of 2048+; uncut: only rows over 4096
+            s.scale()
+            if cut:
+                adopt_gpu_data(s, ref)
+                st = run_steps(s, ref, 0.7, 1.2, [(9, True), (3, True), (5, False)])
+                for name in NAMES_N + NAMES_M:
+                    np.testing.assert_allclose(s.get(name), st[name], rtol=1e-10, atol=1e-12, err_msg=name)   # tree / chunk order
+            else:
+                s.init(0.7, 1.2)
+                s.iterate(9, True); s.iterate(3, True); s.iterate(5, False)
+            states[cut] = {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar")}
+            s.close()
+        finally:
+            os.environ.pop("HPRLP_NO_SLAB_CUTS", None)
+            os.environ.pop("HPRLP_NO_TILED", None)
+    for k in states[True]:
+        np.testing.assert_allclose(states[True][k], states[False][k], rtol=1e-10, atol=1e-12, err_msg=k)
     model.free()
 
 
