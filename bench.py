@@ -436,13 +436,17 @@ def ladder():
     return out
 
 
-def xhalf_kernel_key(tiled):
+def xhalf_kernel_key(tiled, description=""):
     """Short identity of the kernel avg_launch_ms covers; tools/profile_c5.sh stores the same key beside the counters it collects,
-    and the bench line carries `traffic` only when the two agree."""
+    and the bench line carries `traffic` only when the two agree.  k_tiled_fused<XEpi<false, true>, REP, PUSH, NARROW>: the key
+    names PUSH (hand-off) and NARROW (1024-column tiles, from hprlp_solver_describe of A^T)."""
     if not tiled & 2:
         return "k_spmv_fused<XEpi<false>>"
+    at = description.split("A^T:")[-1]
+    if "all-remainder form" in at:
+        return "k_pb_fused<XEpi<false, true>>"
     push = os.environ.get("HPRLP_NO_FAR_PUSH", "0") != "1"
-    return "k_tiled_fused<XEpi<false, true>, *, %s>" % ("true" if push else "false")
+    return "k_tiled_fused<XEpi<false, true>, *, %s, %s>" % ("true" if push else "false", "true" if "tiles of 1024 columns" in at else "false")
 
 
 def xhalf_kernel_label(tiled):
@@ -452,7 +456,7 @@ def xhalf_kernel_label(tiled):
     if os.environ.get("HPRLP_NO_FAR_PUSH", "0") == "1":
         return ("k_far_products + k_tiled_fused<XEpi<false, true>> (x-half: SpMV(A^T,y) + prox + Halpern; avg_launch_ms = remainder "
                 "pre-pass + fused kernel, the two launches of the half-step)")
-    return ("k_tiled_fused<XEpi<false, true>, REP, PUSH=true> (x-half: SpMV(A^T,y) + prox + Halpern in ONE launch; the products of its "
+    return ("k_tiled_fused<XEpi<false, true>, REP, PUSH=true, NARROW> (x-half: SpMV(A^T,y) + prox + Halpern in ONE launch; the products of its "
             "far-column remainder were written by the preceding y-half's epilogue and its own epilogue writes the y-half's "
             "(hand-off, DESIGN.md section 4); shard-shaped matrices: k_tiled_part + k_tiled_finish)")
 
@@ -645,6 +649,7 @@ def main():
     sc = s.scalars()
     info = s.info()
     tiled = info["tiled"]
+    kernels_desc = s.describe()
     if rank == 0:
         log(f"[bench] setup {time.time() - t0:.1f}s (device setup {sc['setup_time']:.2f}s, scaling {sc['scaling_time']:.2f}s, "
             f"power iteration {sc['power_time']:.2f}s / {pw_it} its, lambda_max={lam:.4g})")
@@ -688,8 +693,8 @@ def main():
             try:
                 ent = json.load(open(tf)).get(args.workload, {})
                 traffic_source = {"file": "profiles/pmc_traffic.json", "entry": args.workload, "kernel": ent.get("kernel_key"),
-                                  "commit": ent.get("commit"), "date": ent.get("date"), "this_run_kernel": xhalf_kernel_key(tiled)}
-                if ent.get("kernel_key") == xhalf_kernel_key(tiled):
+                                  "commit": ent.get("commit"), "date": ent.get("date"), "this_run_kernel": xhalf_kernel_key(tiled, kernels_desc)}
+                if ent.get("kernel_key") == xhalf_kernel_key(tiled, kernels_desc):
                     traffic = ent.get("xhalf_hbm_bytes_per_launch")
                 else:
                     traffic_source["note"] = "counters were taken on another kernel: traffic withheld"
@@ -707,6 +712,7 @@ def main():
                        "m": m, "n": n, "nnz": nnz, "parallelism": f"rowpart{P}",
                        "launcher": os.environ.get("HPRLP_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
                                                   else "single process" if P == 1 else "external"),
+                       "kernels": kernels_desc,
                        "rccl": comm_report,
                        "exchange": None if dinfo is None else {
                            "kind_m": "neighbour send/recv" if dinfo["m_sparse"] else "all-gather",

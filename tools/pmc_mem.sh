@@ -1,6 +1,7 @@
 #!/bin/bash
 # Memory-path counters (L1 <-> L2 latency, TLB, L2 -> fabric queues, TA stalls) of the tiled kernels for one library variant, in
-# separate rocprofv3 --pmc passes.  usage (inside one gpurun call, repo root):  bash tools/pmc_mem.sh NAME [workload]   (NAME: base | variant)
+# separate rocprofv3 --pmc passes (the TA_* set is split over two passes: in one, rocprofv3 aborted with "Request exceeds the
+# capabilities of the hardware to collect" -- round 3, gpurun_out/pmcmem_*/p7.err).  usage (inside one gpurun call, repo root):  bash tools/pmc_mem.sh NAME [workload]   (NAME: base | variant)
 name=${1:-base}; wl=${2:-c5}
 if [ "$name" = base ]; then lib=$PWD/lib/libhprlp.so; else lib=$PWD/lib/variants/libhprlp_$name.so; fi
 out=$PWD/gpurun_out/pmcmem_$name
@@ -18,7 +19,8 @@ TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_s
 TCP_UTCL1_SERIALIZATION_STALL_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_THRASHING_STALL_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum
 TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_sum
 TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum TCC_CYCLE_sum
-TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
+TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum
+TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
 TCP_RFIFO_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_BUSY_avr
 LIST

@@ -62,8 +62,9 @@ xk = [n for n in res if "k_tiled_fused" in n and "XEpi<false" in n]
 hs = res["_half_steps"]
 key = None
 if xk:
-    push = xk[0].rstrip(">").split(",")[-1].strip()
-    key = "k_tiled_fused<XEpi<false, true>, *, %s>" % push if "XEpi<false, true>" in xk[0] else xk[0]
+    # k_tiled_fused<XEpi<false, true>, REP, PUSH, NARROW>: the key names PUSH and NARROW (REP depends on the matrix only)
+    args = [a.strip() for a in xk[0].rstrip(">").split(">,")[-1].split(",")]
+    key = ("k_tiled_fused<XEpi<false, true>, *, %s, %s>" % (args[1], args[2] if len(args) > 2 else "false")) if "XEpi<false, true>" in xk[0] and len(args) >= 2 else xk[0]
 try:
     commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
 except Exception:
