@@ -133,6 +133,16 @@ def test_gpu_calls_fail_loudly_without_gpu(model_mps_arrays):
     m.free()
 
 
+def test_warmup_without_a_gpu_says_so():
+    """hprlp_warmup (include/hprlp_amd.h, round 4) on a host without a GPU: -1 and a message, no crash; the model API stays usable."""
+    if os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK):
+        pytest.skip("this host has a GPU")
+    L = hprlp.lib()
+    L.hprlp_warmup.restype = C.c_int
+    assert L.hprlp_warmup(0) == -1
+    assert "GPU" in hprlp.last_error()
+
+
 def test_banded_generator_is_row_consistent():
     import bench_helpers as bh
     rp, ci, v = bh.gen_banded(5000, 5000, 20, 100, seed=7)

@@ -74,3 +74,19 @@ def test_reset_iterates_gives_the_run_of_a_fresh_solver(gpu):
     assert r1.status == r0.status == "OPTIMAL" and r1.iter == r0.iter
     assert r1.primal_obj == r0.primal_obj and np.array_equal(r1.x, r0.x) and np.array_equal(r1.y, r0.y)
     model.free()
+
+
+def test_warmup_then_solve(gpu, model_mps_arrays):
+    """hprlp_warmup (round 4): runtime, device context, first stream and the library's code objects up front; returns 0 on a GPU
+    box, reports its phases, and a solve behind it gives the known answer (reference examples/cpp/example_direct_lp.cpp:14)."""
+    import ctypes as C
+    L = hprlp.lib()
+    L.hprlp_warmup.restype = C.c_int
+    assert L.hprlp_warmup(0) == 0
+    out = (C.c_double * 4)()
+    assert L.hprlp_warmup_seconds(out) == 0 and out[3] > 0 and abs(out[0] + out[1] + out[2] - out[3]) <= 1e-6
+    a = model_mps_arrays
+    model = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"])
+    r = model.solve(hprlp.Parameters(stop_tol=1e-6, use_presolve=False))
+    assert r.status == "OPTIMAL" and abs(r.primal_obj + 26.4) <= 1e-3
+    model.free()
