@@ -80,36 +80,46 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
             const Ent *b = ents.data() + b_begin[slot[tl]];
             const size_t bn = static_cast<size_t>(b_begin[slot[tl] + 1] - b_begin[slot[tl]]);
             const size_t tile_begin = L->tidx.size();
-            size_t i = 0;
-            int last_row = bn == 0 ? 0 : b[0].row;
-            while (i < bn) {
+            // segments of 1..4 entries are laid down by the bin-packed layout their counts define (tiled.h: PackLayout); longer
+            // ones go to the remainder list whole
+            int cnt[5] = {0, 0, 0, 0, 0};
+            for (size_t i = 0; i < bn;) {
                 size_t j = i;
                 while (j < bn && b[j].row == b[i].row) ++j;
                 const int len = static_cast<int>(j - i);
-                if (len > K) {  // long segment: remainder path keeps it whole
+                if (len > K) {
                     for (size_t q = i; q < j; ++q) rem_long.emplace_back(b[q].row, b[q].k);
-                    i = j;
-                    continue;
+                } else {
+                    ++cnt[len];
+                    L->dense += len;
                 }
-                const int pos = static_cast<int>((L->tidx.size() - tile_begin) % K);
-                if (pos + len > K)
-                    for (int q = pos; q < K; ++q) {
-                        L->tidx.push_back(static_cast<uint32_t>(last_row));
-                        L->tperm.push_back(-1);
-                        ++L->pad;
-                    }
-                for (size_t q = i; q < j; ++q) {
-                    L->tidx.push_back(tile_code(b[q].lcol, b[q].row));
-                    L->tperm.push_back(b[q].k);
-                    ++L->dense;
-                }
-                last_row = b[i].row;
                 i = j;
             }
-            while ((L->tidx.size() - tile_begin) % K) {
-                L->tidx.push_back(static_cast<uint32_t>(last_row));
-                L->tperm.push_back(-1);
-                ++L->pad;
+            PackLayout lay;
+            lay.set(cnt[1], cnt[2], cnt[3], cnt[4]);
+            const int total = lay.entries();
+            L->pad += total - (cnt[1] + 2 * cnt[2] + 3 * cnt[3] + 4 * cnt[4]);
+            L->tidx.resize(tile_begin + static_cast<size_t>(total), 0u);
+            L->tperm.resize(tile_begin + static_cast<size_t>(total), -1);
+            int rank[5] = {0, 0, 0, 0, 0};
+            for (size_t i = 0; i < bn;) {
+                size_t j = i;
+                while (j < bn && b[j].row == b[i].row) ++j;
+                const int len = static_cast<int>(j - i);
+                if (len <= K) {
+                    const int rk = rank[len]++;
+                    const size_t at = tile_begin + static_cast<size_t>(lay.pos(len, rk));
+                    for (size_t q = i; q < j; ++q) {
+                        L->tidx[at + (q - i)] = tile_code(b[q].lcol, b[q].row);
+                        L->tperm[at + (q - i)] = b[q].k;
+                    }
+                    const int np = lay.pads_after(len, rk);
+                    for (int q = 0; q < np; ++q) {
+                        L->tidx[at + static_cast<size_t>(len + q)] = static_cast<uint32_t>(b[i].row);
+                        L->tperm[at + static_cast<size_t>(len + q)] = -1;
+                    }
+                }
+                i = j;
             }
             size_t p = tile_begin;
             const size_t end = L->tidx.size();

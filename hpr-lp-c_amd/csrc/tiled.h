@@ -65,6 +65,51 @@ static_assert((1 << kTileRowBits) == kTileRows && kTileCols <= (1 << (24 - kTile
               "entry codes are 24 bits: 13 of local row, 11 of local column, four per chunk");
 inline uint32_t tile_code(int lcol, int row) { return (static_cast<uint32_t>(lcol) << kTileRowBits) | static_cast<uint32_t>(row); }
 
+// Chunk layout of one (super-block, tile) list (round 4).  A row's segment (1-4 entries; longer ones go to the remainder) must
+// not straddle a chunk of 4, and rows may come in ANY order inside a tile (the accumulators are addressed by the row code), so the
+// segments are bin-packed by length instead of laid down in row order: 4 | 3 + 1 | 2 + 2 | 2 + 1 + 1 | 1 + 1 + 1 + 1.  In row order
+// a narrow-band matrix padded 11.7 % of its tile entries -- enough to push every full tile of the banded 2e7 ladder point just
+// over a step's 2048 entries and into a second, nearly empty step (40 steps per super-block instead of 25).  Both builders
+// use these formulas; a segment's position depends only on its length and its rank among the tile's segments of that length
+// (row order).  Padding (value 0, no CSR entry) repeats the row of the slot before it.
+struct PackLayout {
+    int n1 = 0, n2 = 0, n3 = 0, n4 = 0;  // segments of each length
+    int u3 = 0, u2 = 0, r1 = 0, c2 = 0;  // ones that complete the 3-chunks / the odd 2-chunk, ones left over, chunks of the 2-class
+    __host__ __device__ void set(int a1, int a2, int a3, int a4) {
+        n1 = a1; n2 = a2; n3 = a3; n4 = a4;
+        u3 = n1 < n3 ? n1 : n3;
+        c2 = (n2 + 1) / 2;
+        const int left = n1 - u3;
+        u2 = (n2 & 1) ? (left < 2 ? left : 2) : 0;
+        r1 = left - u2;
+    }
+    __host__ __device__ int entries() const { return kTileChunk * (n4 + n3 + c2 + (r1 + 3) / 4); }   // padded length of the list
+    // offset (in the tile's list) of the first entry of the j-th segment of length L
+    __host__ __device__ int pos(int L, int j) const {
+        if (L == 4) return 4 * j;
+        if (L == 3) return 4 * (n4 + j);
+        if (L == 2) return 4 * (n4 + n3 + j / 2) + 2 * (j & 1);
+        if (j < u3) return 4 * (n4 + j) + 3;
+        j -= u3;
+        if (j < u2) return 4 * (n4 + n3 + n2 / 2) + 2 + j;
+        j -= u2;
+        return 4 * (n4 + n3 + c2) + j;
+    }
+    // padding slots that directly follow that segment (they carry its row)
+    __host__ __device__ int pads_after(int L, int j) const {
+        if (L == 3) return j >= u3 ? 1 : 0;
+        if (L == 2) return ((n2 & 1) && j == n2 - 1) ? (u2 == 0 ? 2 : 0) : 0;
+        if (L == 1) {
+            if (j < u3) return 0;
+            j -= u3;
+            if (j < u2) return (u2 == 1) ? 1 : 0;   // the single one behind the odd 2-segment leaves one slot
+            j -= u2;
+            return (j == r1 - 1) ? (4 - (r1 & 3)) & 3 : 0;
+        }
+        return 0;
+    }
+};
+
 constexpr int kTileResidentPerCu = 2;  // 80 KiB of LDS per workgroup, 160 KiB per CU
 constexpr int kFarGroup = kTileRows;   // most source columns per workgroup of the remainder pre-pass (64 KiB of LDS); TiledDev::G
 constexpr int kFarThreads = 512;

@@ -80,11 +80,14 @@ template <int PASS>
 __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long long *__restrict__ skey,
                                         const int *__restrict__ sperm, const int *__restrict__ col, int col0,
                                         char *__restrict__ flag_sorted, uint32_t *__restrict__ tidx, int *__restrict__ tperm,
-                                        int out0, int *dense, int *pad, const WalkWindow &w) {
+                                        int out0, int *dense, int *pad, const WalkWindow &w, int4 *counts) {
     constexpr int W = kWalkWin, NTH = kWalkThreads;
-    int len_out = 0;  // entries emitted so far (position in the tile list)
     constexpr int RM = (1 << kRowBits) - 1;
-    int last_row = static_cast<int>(skey[begin] & RM);
+    // PASS 1 counts the segments by length (and flags the long ones for the remainder); PASS 2 lays them down by the
+    // bin-packed layout those counts define (tiled.h: PackLayout)
+    int cnt[5] = {0, 0, 0, 0, 0};   // PASS 1: segments of length 1..4; PASS 2: rank of the next segment of each length
+    PackLayout lay;
+    if (PASS == 2) lay.set(counts->x, counts->y, counts->z, counts->w);
     int i = begin;
     int wb = begin - W;  // window base: the window holds entries [wb, wb + W) of this lane's run
     auto key_at = [&](int idx) { return idx < wb + W ? w.key[(idx - wb) * NTH] : skey[idx]; };  // (beyond the window: a long segment's scan)
@@ -122,43 +125,38 @@ __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long 
             i = j;
             continue;
         }
-        const int pos = len_out % K;
-        if (pos + len > K) {
-            for (int q = pos; q < K; ++q) {
-                if (PASS == 2) {
-                    tidx[out0 + len_out] = static_cast<uint32_t>(last_row);
-                    tperm[out0 + len_out] = -1;
-                }
-                ++len_out;
-                if (PASS == 1) ++*pad;
+        if (PASS == 1) {
+            ++cnt[len];
+            *dense += len;
+        } else {
+            const int rank = cnt[len]++;
+            const int at = out0 + lay.pos(len, rank);
+            for (int q = i; q < j; ++q) {  // (i + K <= wb + W: inside the window)
+                tperm[at + (q - i)] = w.perm[(q - wb) * NTH];
+                tidx[at + (q - i)] = (static_cast<uint32_t>(w.col[(q - wb) * NTH] - col0) << kRowBits) | static_cast<uint32_t>(row);
+            }
+            const int np = lay.pads_after(len, rank);
+            for (int q = 0; q < np; ++q) {
+                tidx[at + len + q] = static_cast<uint32_t>(row);
+                tperm[at + len + q] = -1;
             }
         }
-        for (int q = i; q < j; ++q) {
-            if (PASS == 2) {  // (i + K <= wb + W: inside the window)
-                tperm[out0 + len_out] = w.perm[(q - wb) * NTH];
-                tidx[out0 + len_out] = (static_cast<uint32_t>(w.col[(q - wb) * NTH] - col0) << kRowBits) | static_cast<uint32_t>(row);
-            }
-            ++len_out;
-        }
-        if (PASS == 1) *dense += len;
-        last_row = row;
         i = j;
     }
-    while (len_out % K) {
-        if (PASS == 2) {
-            tidx[out0 + len_out] = static_cast<uint32_t>(last_row);
-            tperm[out0 + len_out] = -1;
-        }
-        ++len_out;
-        if (PASS == 1) ++*pad;
+    if (PASS == 1) {
+        lay.set(cnt[1], cnt[2], cnt[3], cnt[4]);
+        *counts = make_int4(cnt[1], cnt[2], cnt[3], cnt[4]);
+        const int total = lay.entries();
+        *pad += total - *dense;
+        return total;
     }
-    return len_out;
+    return lay.entries();
 }
 
 __global__ void __launch_bounds__(kWalkThreads) k_run_pass1(int nruns, bool all_rem, const int *__restrict__ run_start,
                                                            const unsigned long long *__restrict__ skey, char *__restrict__ flag_sorted,
                                                            int *__restrict__ padded_len, int *__restrict__ nsteps,
-                                                           unsigned long long *__restrict__ totals) {
+                                                           unsigned long long *__restrict__ totals, int4 *__restrict__ seg_counts) {
     __shared__ unsigned long long wkey[kWalkWin * kWalkThreads];
     const int r = blockIdx.x * kWalkThreads + threadIdx.x;
     if (r >= nruns) return;
@@ -171,7 +169,9 @@ __global__ void __launch_bounds__(kWalkThreads) k_run_pass1(int nruns, bool all_
     }
     int dense = 0, pad = 0;
     const WalkWindow w{wkey + threadIdx.x, nullptr, nullptr};
-    const int len = walk_run<1>(begin, end, skey, nullptr, nullptr, 0, flag_sorted, nullptr, nullptr, 0, &dense, &pad, w);
+    int4 c4;
+    const int len = walk_run<1>(begin, end, skey, nullptr, nullptr, 0, flag_sorted, nullptr, nullptr, 0, &dense, &pad, w, &c4);
+    seg_counts[r] = c4;
     padded_len[r] = len;
     nsteps[r] = (len + kTileStepCap - 1) / kTileStepCap;
     atomicAdd(&totals[0], static_cast<unsigned long long>(dense));
@@ -198,7 +198,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_run_pass2(int nruns, int tile_
                                                        const int *__restrict__ padded_len, const int *__restrict__ run_off,
                                                        const int *__restrict__ run_step_off, const int *__restrict__ first_run,
                                                        const int *__restrict__ sb_ptr, const int *__restrict__ col,
-                                                       uint32_t *__restrict__ tidx, int *__restrict__ tperm, TileStep *__restrict__ steps) {
+                                                       uint32_t *__restrict__ tidx, int *__restrict__ tperm, TileStep *__restrict__ steps,
+                                                       const int4 *__restrict__ seg_counts) {
     __shared__ unsigned long long wkey[kWalkWin * kWalkThreads];
     __shared__ int wperm[kWalkWin * kWalkThreads], wcol[kWalkWin * kWalkThreads];
     const int r = blockIdx.x * kWalkThreads + threadIdx.x;
@@ -209,7 +210,8 @@ __global__ void __launch_bounds__(kWalkThreads) k_run_pass2(int nruns, int tile_
     const unsigned long long k0 = skey[begin];
     const int tl = static_cast<int>((k0 >> kRowBits) & ((1ULL << tile_bits) - 1));
     const WalkWindow w{wkey + threadIdx.x, wperm + threadIdx.x, wcol + threadIdx.x};
-    walk_run<2>(begin, end, skey, sperm, col, tl * T, nullptr, tidx, tperm, out0, nullptr, nullptr, w);
+    int4 c4 = seg_counts[r];
+    walk_run<2>(begin, end, skey, sperm, col, tl * T, nullptr, tidx, tperm, out0, nullptr, nullptr, w, &c4);
     const int sb = static_cast<int>(k0 >> (tile_bits + kRowBits));
     const int s0 = sb_ptr[sb] + (run_step_off[r] - run_step_off[first_run[sb]]);
     for (int p = 0, j = 0; p < len; p += kTileStepCap, ++j)
@@ -481,12 +483,13 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     DBuf<char> flag_sorted;
     flag_sorted.alloc_zero(static_cast<size_t>(nnz));
     DBuf<int> padded_len(static_cast<size_t>(nruns) + 1), nsteps(static_cast<size_t>(nruns) + 1);
+    DBuf<int4> seg_counts(static_cast<size_t>(nruns) + 1);  // per run: its segments of length 1..4 (tiled.h: PackLayout)
     DBuf<unsigned long long> totals;
     totals.alloc_zero(2);
     HIP_CHECK(hipMemsetAsync(padded_len.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
     HIP_CHECK(hipMemsetAsync(nsteps.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
     hipLaunchKernelGGL(k_run_pass1, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, rem_cap == kPbRemCap, run_start.p, skey.p, flag_sorted.p, padded_len.p,
-                       nsteps.p, totals.p);
+                       nsteps.p, totals.p, seg_counts.p);
     unsigned long long tot[2] = {0, 0};
     HIP_CHECK(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -548,7 +551,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     tperm.alloc(static_cast<size_t>(n_tile) + 8);
     tval.alloc_zero(static_cast<size_t>(n_tile) + 8);
     hipLaunchKernelGGL(k_run_pass2, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, tile_bits, T, run_start.p, skey.p, sperm.p, padded_len.p,
-                       run_off.p, run_step_off.p, first_run.p, sb_ptr.p, col, tidx.p, tperm.p, steps.p);
+                       run_off.p, run_step_off.p, first_run.p, sb_ptr.p, col, tidx.p, tperm.p, steps.p, seg_counts.p);
     rcol.alloc_zero(static_cast<size_t>(n_rem) + 8);
     rperm.alloc(static_cast<size_t>(n_rem) + 8);
     rrow.alloc_zero(static_cast<size_t>(n_rem) + 8);
