@@ -612,7 +612,8 @@ bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
     const char *nt = std::getenv("HPRLP_NO_TILED");
     if (nt && nt[0] == '1') return false;
     static const long min_cols = std::getenv("HPRLP_PB_MIN_COLS") ? std::atol(std::getenv("HPRLP_PB_MIN_COLS")) : kPbMinCols;
-    return !comm && !M.view.tiled.valid && M.declined_sparse && M.view.cols >= min_cols && M.view.nnz >= 4000000;
+    static const long min_nnz = std::getenv("HPRLP_PB_MIN_NNZ") ? std::atol(std::getenv("HPRLP_PB_MIN_NNZ")) : 4000000L;  // (tests lower it)
+    return !comm && !M.view.tiled.valid && M.declined_sparse && M.view.cols >= min_cols && M.view.nnz >= min_nnz;
 }
 
 // Super-block heights of this LP's tiled copies (tiled.h).  A matrix with fewer than 512 full-height super-blocks cannot give

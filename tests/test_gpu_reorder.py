@@ -263,3 +263,55 @@ def test_solve_batched_on_a_matrix_the_single_solver_would_reorder(gpu, lp):
     assert s1.status == "OPTIMAL"
     assert abs(s1.primal_obj - r["primal_obj"][1]) <= 10 * tol * (1 + abs(s1.primal_obj))
     mk.free(); model.free()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_all_remainder_kernel_on_small_random_shapes(gpu, seed):
+    """k_pb_fused and the lane-chunk remainder steps (kernels.hip: remainder_steps) on shapes the size thresholds normally keep
+    away from them -- a few thousand rows, row lengths from 0 to several hundred, empty rows and columns, sizes that are not
+    multiples of anything -- forced by lowering the thresholds (a separate process per case: they are read once).  Iterates over
+    mixed normal / check steps, one residual evaluation and lambda_max against the oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+from scipy import sparse
+sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import hprlp
+from oracle import oracle as O
+from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
+seed = int(sys.argv[1])
+rng = np.random.default_rng(100 + seed)
+m = int(rng.integers(2500, 9000)); n = int(rng.integers(2500, 12000))
+lens = np.minimum(rng.geometric(0.12, size=m) - 1, n)          # many short rows, zeros included
+for i in rng.choice(m, 6, replace=False):
+    lens[i] = int(rng.integers(100, min(900, n)))               # a few long ones
+rows = np.repeat(np.arange(m), lens)
+cols = np.concatenate([rng.choice(n, L, replace=False) for L in lens if L > 0]) if lens.sum() else np.zeros(0, int)
+j = int(rng.integers(0, n)); L = int(rng.integers(200, min(1000, m)))
+rows = np.concatenate([rows, rng.choice(m, L, replace=False)]); cols = np.concatenate([cols, np.full(L, j)])   # a long column
+A = sparse.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(m, n)); A.sum_duplicates()
+A.data = rng.normal(size=A.nnz) * 10.0 ** rng.uniform(-1, 1, size=A.nnz); A.sort_indices()
+assert np.diff(A.indptr).max() <= 1024 and np.bincount(A.indices, minlength=n).max() <= 1024
+x0 = rng.uniform(0, 1, size=n); b = A @ x0
+rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+AL, AU = np.where(rng.random(m) < 0.5, b, -np.inf), b + np.where(rng.random(m) < 0.5, 0.0, 1.0)
+l, u, c = np.zeros(n), np.where(rng.random(n) < 0.3, 2.0, np.inf), rng.normal(size=n)
+model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, c)
+s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+d = s.describe()
+assert d.count("all-remainder form (k_pb_fused") == 2, d
+ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, c, O.Params.default(use_CR_scaling=0))
+s.scale(); adopt_gpu_data(s, ref)
+st = run_steps(s, ref, 0.6, 1.4, [(9, True), (3, True), (5, False)])
+for name in NAMES_N + NAMES_M:
+    np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-13, err_msg=name)
+lam_g, it = s.power_iteration(max_iter=30); lam_ref, it_ref = ref.power_iteration(max_iter=30)
+assert it == it_ref and abs(lam_g - lam_ref) <= 1e-11 * lam_ref
+print("OK", m, n, A.nnz)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPRLP_DEVICE_TRANSPOSE_MIN="1000", HPRLP_PB_MIN_COLS="1", HPRLP_PB_MIN_NNZ="1", HPRLP_TILED_MIN_ROWS="1",
+               HPRLP_NO_REORDER="1", HPRLP_NO_SMALL="1", HPRLP_TILED_MIN_DENSE="1.01")   # (1.01: the staged-tile form always declines)
+    r = subprocess.run([sys.executable, "-c", code, str(seed)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
