@@ -572,7 +572,7 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
 template <int K>
 __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int s1, double *acc, double *prod, double *bnd, int tid) {
     constexpr int NT = kTileThreads, NW = kTileThreads / 64;
-    static_assert(K == 4 || K == 6, "code loads: one 16-byte or two 12-byte loads per lane");
+    static_assert(K == 4 || K == 6 || K == 8, "code loads: one or two 16-byte loads, or two 12-byte loads, per lane");
     if (smid >= s1) return;
     const int wave = tid >> 6, lane = tid & 63;
     double *bnd_val = bnd;
@@ -597,6 +597,10 @@ __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int
             typedef uint32_t u4_t __attribute__((ext_vector_type(4), aligned(4)));
             const u4_t w0 = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(t.rq + z.e_begin + c0));
             cv[0] = w0.x; cv[1] = w0.y; cv[2] = w0.z; cv[3] = w0.w;
+            if constexpr (K == 8) {
+                const u4_t w1 = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(t.rq + z.e_begin + c0 + 4));
+                cv[4] = w1.x; cv[5] = w1.y; cv[6] = w1.z; cv[7] = w1.w;
+            }
         }
     };
     issue(st);
@@ -901,13 +905,12 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
 // All-remainder form (round 4; tiled.h: kPbRemCap): the copy of a matrix without column locality stages no tile at all -- every
 // entry's product arrives through P (written by the other half-step's epilogue, or by k_far_products) and a super-block's work is
 // to add its slice of P row by row.  Its own kernel: LDS holds the accumulators of at most kPbRowsMax rows and steps of
-// kPbRemCap = 3072 products with their codes (k_tiled_fused's remainder steps have the 16 KiB tile buffer: 1024), and a step's
-// work is COMPACTED over the lanes.  One head lane per row left most lanes idle behind a few chains of dependent LDS reads (every
-// row of such a matrix holds all its ~20 entries here: 0.28 ms for the 4e7 entries of a 2M x 2M matrix, three times the time its
-// bytes take).  An item = an entry at a row change or at a multiple of kPbRun; the items' positions go to a dense list (wave
-// ballots + the waves' counts through LDS), lane t takes item t.  Level 1: every item adds the products up to the next item
-// (eight independent reads at a time) and leaves the partial sum in its own product slot; level 2: the items at a row change add
-// their row's partials.  Per-row order of the additions: as stored ((source group, CSR) order), in groups of kPbRun -- fixed by the
+// kPbRemCap = 4096 products with their codes (k_tiled_fused's remainder steps have the 16 KiB tile buffer: 1024), and a step's
+// work is spread evenly over the lanes (remainder_steps<K>): lane t holds entries [t K, (t+1) K) of the step in registers, adds
+// them per row, and a segmented scan over the wave (then over the waves' edge runs, through bnd) joins the rows that cross lanes.
+// One head lane per row -- the first form -- left most lanes idle behind a few chains of dependent LDS reads (every row of such a
+// matrix holds all its ~20 entries here: 0.28 ms for the 4e7 entries of a 2M x 2M matrix, three times the time its bytes take).
+// Per-row order of the additions: as stored ((source group, CSR) order), grouped by lane and wave boundaries -- fixed by the
 // matrix, so results are reproducible run to run.  Same persistent schedule, epilogue and hand-off as k_tiled_fused.
 // ------------------------------------------------------------------------------------------------
 template <class Epi, bool PUSH = false>

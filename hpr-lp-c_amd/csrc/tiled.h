@@ -40,12 +40,14 @@ constexpr int kTileRemRun = 16;    // (the builder still marks remainder steps i
                                    // for the statistics line; since round 4 the kernels add rows of any length the same way)
 // All-remainder form (round 4; a matrix without column locality: no tile is staged, every entry goes through the
 // propagation-blocking lists): the copy has its own fused kernel (kernels.hip: k_pb_fused) whose LDS holds the accumulators of
-// at most kPbRowsMax rows and remainder steps of kPbRemCap entries -- three times the kTileRemCap of a copy that also stages
-// tiles (16 KiB of scratch there) -- with the step's work compacted over the lanes (kPbRun: entries per work item).
-constexpr int kPbRemK = 6;                        // remainder entries per lane per step
-constexpr int kPbRemCap = kTileThreads * kPbRemK;  // 3072
+// at most kPbRowsMax rows and remainder steps of kPbRemCap entries -- twice the kTileRemCap of a copy that also stages
+// tiles (16 KiB of scratch there) -- kPbRemK entries per lane, added by a segmented reduction over the lanes.
+#ifndef HPRLP_PB_REM_K
+#define HPRLP_PB_REM_K 8  // (6 and 8 measured same-box: 8 is 0-2.5 % faster on the unstructured and expander ladder points)
+#endif
+constexpr int kPbRemK = HPRLP_PB_REM_K;            // remainder entries per lane per step
+constexpr int kPbRemCap = kTileThreads * kPbRemK;  // 4096
 constexpr int kPbRowsMax = 4096;
-constexpr int kPbRun = 32;
 constexpr int kPbRunTabCap = 3072;                 // run-table entries a producer holds in LDS (two ints each: 24 KiB)
 constexpr int kTileMaxRow = 1024;  // matrices with a longer row are not tiled: a long row's remainder entries all go through ONE workgroup
                                    // (2M x 2M, five rows of L entries, per launch: L = 1000 192 us, 3000 265-327 us, 8000 433-470 us; stream kernel 262 us)
