@@ -1907,7 +1907,7 @@ __global__ void __launch_bounds__(kThreads) k_row_norm(int rows, const int *rowp
 // The max-norm passes (Ruiz: 10 per matrix) over the row blocks of the stream kernel: one wave per block, lanes
 // over the entries (coalesced), |a| through LDS, one lane per row takes the maximum of its segment.  A maximum does
 // not depend on the order, so the result equals the thread-per-row loop's bit for bit (2.2 -> 0.4 ms per pass on
-// 2e8 nonzeros).  The sum norm keeps the sequential loop: its order is part of the parity with the oracle.
+// 2e8 nonzeros).  The sum norm: k_row_sum_blocks below.
 __device__ __forceinline__ double norm_result(double acc) {
     acc = sqrt(acc);
     return acc < 1e-15 ? 1.0 : acc;
@@ -1975,11 +1975,80 @@ __global__ void __launch_bounds__(kThreads) k_row_max_long(CsrDev M, double *res
     }
 }
 
+// The sum norm (Pock-Chambolle, one pass per matrix) over the same row blocks: |a| through LDS (coalesced reads), one lane per
+// row adds its segment in CSR order -- the order of the thread-per-row loop and of the oracle, so the sums are the same bit for
+// bit (2.3 -> 0.5 ms per pass on 2e8 nonzeros).  Rows in vector mode or split into chunks: one lane, in order, from memory.
+__global__ void __launch_bounds__(kThreads) k_row_sum_blocks(CsrDev M, double *result) {
+    __shared__ double lds[kWavesPerBlock][kStreamW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * kWavesPerBlock + wave;
+    if (b >= M.nblk) return;
+    const int4 d = M.blk[b];
+    const int r0 = d.x, nr = d.y, k0 = d.z, nz = d.w;
+    if (nr == 0) return;  // chunk of a split row: k_row_sum_long
+    const double *__restrict__ val = M.val + k0;
+    if (nr == 1 && nz > kLongRow) {
+        if (lane == 0) {
+            double acc = 0.0;
+            for (int j = 0; j < nz; ++j) acc += fabs(val[j]);
+            result[r0] = norm_result(acc);
+        }
+        return;
+    }
+    int rs = 0, re = 0;
+    if (lane < nr) {
+        rs = M.rowptr[r0 + lane] - k0;
+        re = M.rowptr[r0 + lane + 1] - k0;
+    }
+    for (int j = lane; j < nz; j += kWave) lds[wave][j] = fabs(val[j]);
+    wave_lds_sync();
+    if (lane < nr) {
+        double acc = 0.0;
+        for (int j = rs; j < re; ++j) acc += lds[wave][j];
+        result[r0 + lane] = norm_result(acc);
+    }
+}
+
+__global__ void __launch_bounds__(kWave) k_row_sum_long(CsrDev M, double *result) {
+    const int i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= M.nlong) return;
+    const int r = M.longrows[i].x;
+    double acc = 0.0;
+    for (int k = M.rowptr[r]; k < M.rowptr[r + 1]; ++k) acc += fabs(M.val[k]);
+    result[r] = norm_result(acc);
+}
+
+__global__ void __launch_bounds__(kThreads) k_longest_row(const int *__restrict__ rowptr, int rows, int *out) {
+    int best = 0;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < rows; i += gridDim.x * kThreads) best = max(best, rowptr[i + 1] - rowptr[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
+    if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
+}
+
+int launch_longest_row(const int *rowptr, int rows, hipStream_t s) {
+    if (rows <= 0) return 0;
+    DBuf<int> out;
+    out.alloc(1);
+    HIP_CHECK(hipMemsetAsync(out.p, 0, sizeof(int), s));
+    const int grid = std::min((rows + kThreads - 1) / kThreads, 2048);
+    hipLaunchKernelGGL(k_longest_row, dim3(grid), dim3(kThreads), 0, s, rowptr, rows, out.p);
+    int h = 0;
+    HIP_CHECK(hipMemcpyAsync(&h, out.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return h;
+}
+
 void launch_row_norm(const CsrDev &M, double *result, int norm, hipStream_t s) {
     if (M.rows <= 0) return;
     if (norm == 99 && M.nblk > 0) {
         hipLaunchKernelGGL(k_row_max_blocks, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, result);
         if (M.nlong > 0) hipLaunchKernelGGL(k_row_max_long, dim3(M.nlong), dim3(kThreads), 0, s, M, result);
+        return;
+    }
+    if (norm == 1 && M.nblk > 0) {
+        hipLaunchKernelGGL(k_row_sum_blocks, dim3(M.csr_grid()), dim3(kThreads), 0, s, M, result);
+        if (M.nlong > 0) hipLaunchKernelGGL(k_row_sum_long, dim3((M.nlong + kWave - 1) / kWave), dim3(kWave), 0, s, M, result);
         return;
     }
     hipLaunchKernelGGL(k_row_norm, dim3((M.rows + kThreads - 1) / kThreads), dim3(kThreads), 0, s, M.rows, M.rowptr,
@@ -1988,8 +2057,7 @@ void launch_row_norm(const CsrDev &M, double *result, int norm, hipStream_t s) {
 
 // val = op(op(val, first), second) with first/second = the row's scale and the gathered column scale (reference
 // scale_rows/scale_columns kernels, HPR_cuda_kernels.cu:91-157).  One wave per row block, lane = matrix entry
-// (coalesced read-modify-write of val, coalesced col); the entry's row comes from a binary search in the block's
-// <= 65 row offsets held in LDS.  (The thread-per-row loop this replaces took 8.7 ms per pass on 2e8 nonzeros.)
+// (coalesced read-modify-write of val, coalesced col).  (The thread-per-row loop this replaces took 8.7 ms per pass on 2e8 nonzeros.)
 template <bool ROW_FIRST, bool DIVIDE>
 __device__ __forceinline__ double scale_entry(double v, double rv, double cv) {
     if (ROW_FIRST) {
@@ -2002,10 +2070,13 @@ __device__ __forceinline__ double scale_entry(double v, double rv, double cv) {
     return v;
 }
 
-template <bool ROW_FIRST, bool DIVIDE>
-__global__ void __launch_bounds__(kThreads) k_scale_matrix(CsrDev M, const double *rowvec, const double *colvec) {
-    __shared__ int rp[kWavesPerBlock][kStreamRows + 1];
-    __shared__ double rs[kWavesPerBlock][kStreamRows];
+// Round 4: the entry's row scale is spread over the block's entries by the row's own lane first (rsv[j] = rowvec[row of j]: plain
+// LDS stores, no dependent chain -- the binary search in the row offsets this replaces was six dependent LDS reads per entry and
+// held the pass at 2.0 ms on 2e8 nonzeros), and with NEXT the pass also leaves norm_result(max |new value|) of every row in
+// next_norm: the following Ruiz pass's row norm, which otherwise re-read the matrix.  The maximum does not depend on the order.
+template <bool ROW_FIRST, bool DIVIDE, bool NEXT>
+__global__ void __launch_bounds__(kThreads) k_scale_matrix(CsrDev M, const double *rowvec, const double *colvec, double *next_norm) {
+    __shared__ double rsv[kWavesPerBlock][kStreamW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * kWavesPerBlock + wave;
     if (b >= M.nblk) return;
@@ -2014,51 +2085,122 @@ __global__ void __launch_bounds__(kThreads) k_scale_matrix(CsrDev M, const doubl
     if (nr == 0) return;  // chunk of a split row: k_scale_long_rows
     const int *__restrict__ col = M.col + k0;
     double *__restrict__ val = M.val + k0;
-    if (nr == 1) {
+    if (nr == 1 && nz > kLongRow) {
         const double rv = rowvec[r0];
-        for (int j = lane; j < nz; j += kWave) val[j] = scale_entry<ROW_FIRST, DIVIDE>(val[j], rv, colvec[col[j]]);
+        double acc = 0.0;
+        for (int j = lane; j < nz; j += kWave) {
+            const double nv = scale_entry<ROW_FIRST, DIVIDE>(val[j], rv, colvec[col[j]]);
+            val[j] = nv;
+            if (NEXT && acc < fabs(nv)) acc = fabs(nv);
+        }
+        if (NEXT) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(acc, off);
+                if (acc < o) acc = o;
+            }
+            if (lane == 0) next_norm[r0] = norm_result(acc);
+        }
         return;
     }
-    if (lane < nr) {
-        rp[wave][lane] = M.rowptr[r0 + lane] - k0;
-        rs[wave][lane] = rowvec[r0 + lane];
-    }
-    if (lane == 0) rp[wave][nr] = nz;
-    wave_lds_sync();
-    for (int j = lane; j < nz; j += kWave) {
-        int lo = 0, hi = nr;  // largest t in [0, nr) with rp[t] <= j (empty rows share an offset: the last one wins,
-        while (hi - lo > 1) {  //  which is the row that owns entry j)
-            const int mid = (lo + hi) >> 1;
-            if (rp[wave][mid] <= j) lo = mid;
-            else hi = mid;
+    // all of the block's entries (at most kStreamW / kWave = 8 per lane) are requested before anything waits: with one entry per
+    // trip of a loop the pass sat at 2 TB/s behind two dependent memory latencies per trip (index, then gathered scale)
+    constexpr int PER = kStreamW / kWave;
+    double v[PER], cv[PER];
+    int c[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int j = lane + kWave * t;
+        if (j < nz) {
+            c[t] = __builtin_nontemporal_load(col + j);
+            v[t] = __builtin_nontemporal_load(val + j);
         }
-        val[j] = scale_entry<ROW_FIRST, DIVIDE>(val[j], rs[wave][lo], colvec[col[j]]);
+    }
+    int rs = 0, re = 0;
+    if (lane < nr) {
+        rs = M.rowptr[r0 + lane] - k0;
+        re = M.rowptr[r0 + lane + 1] - k0;
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+        if (lane + kWave * t < nz) cv[t] = colvec[c[t]];
+    if (lane < nr) {
+        const double rv = rowvec[r0 + lane];
+        for (int j = rs; j < re; ++j) rsv[wave][j] = rv;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int j = lane + kWave * t;
+        if (j < nz) {
+            const double nv = scale_entry<ROW_FIRST, DIVIDE>(v[t], rsv[wave][j], cv[t]);
+            __builtin_nontemporal_store(nv, val + j);
+            if (NEXT) rsv[wave][j] = fabs(nv);  // the slot's row scale has been read by this lane
+        }
+    }
+    if (NEXT) {
+        wave_lds_sync();
+        if (lane < nr) {
+            double acc = 0.0;
+            for (int j = rs; j < re; ++j) {
+                const double a = rsv[wave][j];
+                if (acc < a) acc = a;
+            }
+            next_norm[r0 + lane] = norm_result(acc);
+        }
     }
 }
 
 // rows longer than kSplitRow (their blocks carry chunk slots, not row numbers): one workgroup per row
-template <bool ROW_FIRST, bool DIVIDE>
-__global__ void __launch_bounds__(kThreads) k_scale_long_rows(CsrDev M, const double *rowvec, const double *colvec) {
+template <bool ROW_FIRST, bool DIVIDE, bool NEXT>
+__global__ void __launch_bounds__(kThreads) k_scale_long_rows(CsrDev M, const double *rowvec, const double *colvec, double *next_norm) {
+    __shared__ double red[kWavesPerBlock];
     const int r = M.longrows[blockIdx.x].x;
     const double rv = rowvec[r];
-    for (int k = M.rowptr[r] + threadIdx.x; k < M.rowptr[r + 1]; k += kThreads)
-        M.val[k] = scale_entry<ROW_FIRST, DIVIDE>(M.val[k], rv, colvec[M.col[k]]);
+    double acc = 0.0;
+    for (int k = M.rowptr[r] + threadIdx.x; k < M.rowptr[r + 1]; k += kThreads) {
+        const double nv = scale_entry<ROW_FIRST, DIVIDE>(M.val[k], rv, colvec[M.col[k]]);
+        M.val[k] = nv;
+        if (NEXT && acc < fabs(nv)) acc = fabs(nv);
+    }
+    if (NEXT) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(acc, off);
+            if (acc < o) acc = o;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kWavesPerBlock; ++w)
+                if (acc < red[w]) acc = red[w];
+            next_norm[r] = norm_result(acc);
+        }
+    }
 }
 
-template <bool ROW_FIRST, bool DIVIDE>
-static void launch_scale_matrix_t(const CsrDev &M, const double *rowvec, const double *colvec_full, hipStream_t s) {
-    hipLaunchKernelGGL((k_scale_matrix<ROW_FIRST, DIVIDE>), dim3(M.csr_grid()), dim3(kThreads), 0, s, M, rowvec, colvec_full);
+template <bool ROW_FIRST, bool DIVIDE, bool NEXT>
+static void launch_scale_matrix_t(const CsrDev &M, const double *rowvec, const double *colvec_full, double *next_norm, hipStream_t s) {
+    hipLaunchKernelGGL((k_scale_matrix<ROW_FIRST, DIVIDE, NEXT>), dim3(M.csr_grid()), dim3(kThreads), 0, s, M, rowvec, colvec_full, next_norm);
     if (M.nlong > 0)
-        hipLaunchKernelGGL((k_scale_long_rows<ROW_FIRST, DIVIDE>), dim3(M.nlong), dim3(kThreads), 0, s, M, rowvec, colvec_full);
+        hipLaunchKernelGGL((k_scale_long_rows<ROW_FIRST, DIVIDE, NEXT>), dim3(M.nlong), dim3(kThreads), 0, s, M, rowvec, colvec_full, next_norm);
 }
 
+// next_max_norm (optional; not rowvec): receives what launch_row_norm(M, ., 99) would give on the scaled matrix
 void launch_scale_matrix(const CsrDev &M, const double *rowvec, const double *colvec_full, bool row_first,
-                         bool divide, hipStream_t s) {
+                         bool divide, hipStream_t s, double *next_max_norm) {
     if (M.rows <= 0 || M.nblk <= 0) return;
-    if (row_first && divide) launch_scale_matrix_t<true, true>(M, rowvec, colvec_full, s);
-    else if (row_first && !divide) launch_scale_matrix_t<true, false>(M, rowvec, colvec_full, s);
-    else if (!row_first && divide) launch_scale_matrix_t<false, true>(M, rowvec, colvec_full, s);
-    else launch_scale_matrix_t<false, false>(M, rowvec, colvec_full, s);
+    if (next_max_norm) {
+        if (row_first && divide) launch_scale_matrix_t<true, true, true>(M, rowvec, colvec_full, next_max_norm, s);
+        else if (row_first && !divide) launch_scale_matrix_t<true, false, true>(M, rowvec, colvec_full, next_max_norm, s);
+        else if (!row_first && divide) launch_scale_matrix_t<false, true, true>(M, rowvec, colvec_full, next_max_norm, s);
+        else launch_scale_matrix_t<false, false, true>(M, rowvec, colvec_full, next_max_norm, s);
+        return;
+    }
+    if (row_first && divide) launch_scale_matrix_t<true, true, false>(M, rowvec, colvec_full, nullptr, s);
+    else if (row_first && !divide) launch_scale_matrix_t<true, false, false>(M, rowvec, colvec_full, nullptr, s);
+    else if (!row_first && divide) launch_scale_matrix_t<false, true, false>(M, rowvec, colvec_full, nullptr, s);
+    else launch_scale_matrix_t<false, false, false>(M, rowvec, colvec_full, nullptr, s);
 }
 
 __global__ void __launch_bounds__(kThreads) k_vec_scale(double *x, const double *s, int n, int divide) {

@@ -198,6 +198,24 @@ struct PhaseTimer {
     }
 };
 
+// A long copy on its own stream (driven by a helper thread) as a sequence of pieces with a short sleep after each.  While a
+// pageable-memory copy is inside the HIP runtime, other threads' runtime calls wait for it: beside one 1.6 GB copy the device build
+// of the tiled copy stood still for 20 ms at its first stream wait, and back-to-back pieces starved it just the same.  With the
+// sleep the waiting thread gets its turn (measured on config 5, warm process: set-up of A 89 -> 67 ms; 16 / 32 / 64 MB pieces
+// with 30 / 100 us equal within 3 ms).  HPRLP_COPY_PIECE_MB / HPRLP_COPY_PAUSE_US: for measurements.
+static hipError_t copy_in_pieces(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t cs) {
+    static const size_t kPiece = size_t(std::getenv("HPRLP_COPY_PIECE_MB") ? std::max(1, std::atoi(std::getenv("HPRLP_COPY_PIECE_MB"))) : 64) << 20;
+    static const int pause_us = std::getenv("HPRLP_COPY_PAUSE_US") ? std::atoi(std::getenv("HPRLP_COPY_PAUSE_US")) : 100;
+    for (size_t off = 0; off < bytes; off += kPiece) {
+        const size_t len = std::min(kPiece, bytes - off);
+        hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len, kind, cs);
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);
+        if (e != hipSuccess) return e;
+        if (pause_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(pause_us));
+    }
+    return hipSuccess;
+}
+
 void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, const double *v, std::shared_ptr<void> keep) {
     PhaseTimer pt;
     const int nnz = rp[rows];
@@ -223,35 +241,105 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
         if (b) throw std::runtime_error("column index out of range");
     }
     val.alloc(nnz);
-    val.upload(v, nnz);
-    pt.tick("  upload CSR");
-    describe(rows, cols, rp, ci, std::move(keep));
+    // The values are not needed before the tiled copy is filled (or, without one, before describe() returns): a large array
+    // travels on a copy stream of its own, driven by a helper thread, beside the host-side row blocks and the device build
+    // of the tiled copy, which work on the index arrays (config 5: 27 ms of 1.6 GB hidden).
+    std::future<void> val_job;
+    if (nnz > 4000000 && std::getenv("HPRLP_NO_SETUP_OVERLAP") == nullptr) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        double *dst = val.p;
+        val_job = std::async(std::launch::async, [dev, dst, v, nnz]() {
+            HIP_CHECK(hipSetDevice(dev));
+            hipStream_t cs = nullptr;
+            HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            const hipError_t e = copy_in_pieces(dst, v, static_cast<size_t>(nnz) * sizeof(double), hipMemcpyHostToDevice, cs);
+            (void)hipStreamDestroy(cs);
+            HIP_CHECK(e);
+        });
+    } else {
+        val.upload(v, nnz);
+    }
+    pt.tick("  upload CSR (values may still be in flight)");
+    std::promise<const int *> have_rp;
+    have_rp.set_value(rp);
+    describe_when(rows, cols, nnz, have_rp.get_future().share(), ci, std::move(keep), -1.0, &val_job);
 }
 
-// Row blocks, kernel views and the background job for the tiled copy, for a matrix whose CSR arrays are already in
-// rowptr / col / val on the device (rp / ci: the same index arrays on the host).
 void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep, double min_dense_override) {
+    std::promise<const int *> have_rp;
+    have_rp.set_value(rp);
+    describe_when(rows, cols, rp[rows], have_rp.get_future().share(), ci, std::move(keep), min_dense_override, nullptr);
+}
+
+// Row blocks, kernel views and the tiled copy, for a matrix whose CSR arrays are already in rowptr / col / val on the device.
+// rp_ready delivers the same row pointers on the host (for A^T after a device transpose: when their download, running in a thread
+// of the caller, is done); ci: the host column indices or null.  The row blocks of the stream kernel are a host-side walk over the
+// row pointers (13-18 ms at 1e7 rows): a job of their own beside the device build of the tiled copy, which reads only the device
+// arrays.  values_ready (optional): the upload of val still in flight -- joined before the first use of the values.
+void DeviceMatrix::describe_when(int rows, int cols, long nnz_l, std::shared_future<const int *> rp_ready, const int *ci, std::shared_ptr<void> keep,
+                                 double min_dense_override, std::future<void> *values_ready) {
     PhaseTimer pt;
     view.longrows = nullptr;  // (describe() may run again on a permuted copy of the matrix: start from a clean view)
     view.nlong = 0;
     view.long_partial = nullptr;
     view.tiled = TiledDev();
-    const int nnz = rp[rows];
-    std::vector<int4> lr;
+    const int nnz = static_cast<int>(nnz_l);
+    auto host_rp = [&rp_ready]() { return rp_ready.get(); };
+    auto join_values = [values_ready]() {
+        if (values_ready && values_ready->valid()) values_ready->get();
+    };
+    struct Blocks {
+        std::vector<int4> b, lr;
+    };
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const int *dcol = col.p;
     // dense rows of a matrix whose gathered vector is beyond one L2: cut by column eighths (slab_cuts); the column indices of
     // those rows come from the host copy or, for a matrix built on the device, from a download of just those rows
-    RowCuts cuts;
-    const char *noslab = std::getenv("HPRLP_NO_SLAB_CUTS");
-    if (cols >= (1 << 19) && nnz >= (1 << 22) && !(noslab && noslab[0] == '1')) {
-        const int *hci = ci;
-        const int *dcol = col.p;
-        cuts = slab_cuts(rows, cols, rp, [&](int r, int *out) {
-            const size_t len = static_cast<size_t>(rp[r + 1] - rp[r]);
-            if (hci) std::memcpy(out, hci + rp[r], len * sizeof(int));
-            else HIP_CHECK(hipMemcpy(out, dcol + rp[r], len * sizeof(int), hipMemcpyDeviceToHost));
-        });
+    auto make_blocks = [rows, cols, nnz, rp_ready, ci, dev, dcol]() {
+        HIP_CHECK(hipSetDevice(dev));
+        const int *rp = rp_ready.get();
+        RowCuts cuts;
+        const char *noslab = std::getenv("HPRLP_NO_SLAB_CUTS");
+        if (cols >= (1 << 19) && nnz >= (1 << 22) && !(noslab && noslab[0] == '1')) {
+            cuts = slab_cuts(rows, cols, rp, [&](int r, int *out) {
+                const size_t len = static_cast<size_t>(rp[r + 1] - rp[r]);
+                if (ci) std::memcpy(out, ci + rp[r], len * sizeof(int));
+                else HIP_CHECK(hipMemcpy(out, dcol + rp[r], len * sizeof(int), hipMemcpyDeviceToHost));
+            });
+        }
+        Blocks out;
+        out.b = build_row_blocks_cut(rows, rp, &out.lr, cuts.rows.empty() ? nullptr : &cuts);
+        return out;
+    };
+    const bool overlap = rows > 100000 && std::getenv("HPRLP_NO_SETUP_OVERLAP") == nullptr;
+    std::future<Blocks> blocks_job = std::async(overlap ? std::launch::async : std::launch::deferred, make_blocks);
+    view.rows = rows;
+    view.cols = cols;
+    view.nnz = nnz;
+    view.rowptr = rowptr.p;
+    view.col = col.p;
+    view.val = val.p;
+    // nontemporal matrix loads only when the matrix cannot stay in the eight 4 MiB L2s anyway
+    view.nt = static_cast<size_t>(nnz) * 12 > (static_cast<size_t>(16) << 20);
+    if (const char *e = std::getenv("HPRLP_NT")) view.nt = std::atoi(e) != 0;
+    try {
+        longest_row = 0;
+        if (rows > 100000) {  // (from the device copy: the host row pointers of A^T may still be on their way)
+            longest_row = launch_longest_row(rowptr.p, rows, nullptr);
+        } else {
+            const int *rp = host_rp();
+            for (int i = 0; i < rows; ++i) longest_row = std::max(longest_row, rp[i + 1] - rp[i]);
+        }
+        build_tiled_copy(rows, cols, nnz, host_rp, ci, std::move(keep), min_dense_override, join_values, pt);
+        join_values();
+    } catch (...) {
+        if (blocks_job.valid()) blocks_job.wait();
+        throw;
     }
-    std::vector<int4> b = build_row_blocks_cut(rows, rp, &lr, cuts.rows.empty() ? nullptr : &cuts);
+    Blocks B = blocks_job.get();
+    std::vector<int4> &b = B.b, &lr = B.lr;
     int nslots = 0;
     std::vector<char> seen;
     for (const int4 &d : b) {
@@ -278,20 +366,25 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         view.nlong = static_cast<int>(lr.size());
         view.long_partial = long_partial.p;
     }
-    view.rows = rows;
-    view.cols = cols;
-    view.nnz = nnz;
-    view.rowptr = rowptr.p;
-    view.col = col.p;
-    view.val = val.p;
     view.blk = blk.p;
     view.nblk = static_cast<int>(b.size());
-    // nontemporal matrix loads only when the matrix cannot stay in the eight 4 MiB L2s anyway
-    view.nt = static_cast<size_t>(nnz) * 12 > (static_cast<size_t>(16) << 20);
-    if (const char *e = std::getenv("HPRLP_NT")) view.nt = std::atoi(e) != 0;
+}
+
+// The tiled copy of describe_when(): decision, device build (or the host builder's background job), values filled in.
+void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::function<const int *()> &host_rp, const int *ci, std::shared_ptr<void> keep,
+                                    double min_dense_override, const std::function<void()> &join_values, PhaseTimer &pt) {
     // column-tiled copy: only for matrices with at least one 8192-row super-block per CU
     // and with enough column locality (HPRLP_NO_TILED=1 disables; thresholds overridable for tests)
     const char *no = std::getenv("HPRLP_NO_TILED");
+    // the build's own stream (HPRLP_BUILD_STREAM=1): its waits are for its own work, not for the value upload beside it
+    struct BuildStream {
+        hipStream_t s = nullptr;
+        ~BuildStream() {
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } own;
+    if (const char *e = std::getenv("HPRLP_BUILD_STREAM"); e && e[0] == '1') HIP_CHECK(hipStreamCreate(&own.s));
+    const hipStream_t bs = own.s;
     if (!(no && no[0] == '1')) {
         const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
         const char *md = std::getenv("HPRLP_TILED_MIN_DENSE");
@@ -313,9 +406,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         //    us.  Such matrices keep the stream kernel, which spreads a long row over a wave or several.
         const char *mc = std::getenv("HPRLP_TILED_MIN_COLS");
         const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (short_form ? (1 << 19) : 800000));  // (800 k: as kPbMinCols, a vector beyond one L2)
-        int longest = 0;
-        if (rp)
-            for (int i = 0; i < rows; ++i) longest = std::max(longest, rp[i + 1] - rp[i]);
+        const int longest = longest_row;  // (describe_when)
         declined_shape = cols < min_cols || longest > kTileMaxRow;
         const char *ht = std::getenv("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
@@ -323,7 +414,8 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         // tiled copy and summed by the stream kernel's vector / split-row mode into a base vector that every tiled launch
         // adds (tiled.h: TiledDev::side_*).  At most 0.1 % of the rows (and 64) and a fifth of the nonzeros.
         const char *nside = std::getenv("HPRLP_NO_LONG_SIDE");
-        if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && rp && !host_tiling && !(nside && nside[0] == '1')) {
+        if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && !host_tiling && !(nside && nside[0] == '1')) {
+            const int *rp = host_rp();
             std::vector<int> long_rows;
             long long_nnz = 0;
             for (int i = 0; i < rows; ++i)
@@ -340,17 +432,18 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
                 const long nnz_c = rp_c[rows];
                 DBuf<int> d_rp_c(rp_c.size()), col_c(static_cast<size_t>(std::max<long>(nnz_c, 1))), map_c(static_cast<size_t>(std::max<long>(nnz_c, 1)));
                 d_rp_c.upload(rp_c.data(), rp_c.size());
-                compact_without_rows(nnz, rows, rowptr.p, d_rp_c.p, col.p, col_c.p, map_c.p, nullptr);
-                const bool ok = tiled.build_on_device(rows, cols, nnz_c, d_rp_c.p, col_c.p, min_rows, min_dense, nullptr, rb, tile_cols, rem_cap);
+                compact_without_rows(nnz, rows, rowptr.p, d_rp_c.p, col.p, col_c.p, map_c.p, bs);
+                const bool ok = tiled.build_on_device(rows, cols, nnz_c, d_rp_c.p, col_c.p, min_rows, min_dense, bs, rb, tile_cols, rem_cap);
                 if (pt.on)
                     std::cerr << "[timing]   tiled copy without " << long_rows.size() << " long rows (" << long_nnz << " entries, longest " << longest
                               << "): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, " << tiled.n_steps << " steps" << std::endl;
                 if (ok) {
-                    tiled.build_far(cols, nullptr, gb);
-                    tiled.compose_perms(map_c.p, nullptr);
+                    tiled.build_far(cols, bs, gb);
+                    tiled.compose_perms(map_c.p, bs);
                     tiled.set_side(rows, rp, long_rows);
                     view.tiled = tiled.view;
-                    launch_tiled_refresh(tiled, val.p, nullptr);
+                    join_values();
+                    launch_tiled_refresh(tiled, val.p, bs);
                     HIP_CHECK(hipDeviceSynchronize());
                     declined_shape = false;
                 }
@@ -363,7 +456,7 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
             // built on the device from the device CSR arrays (tiled_build.hip); HPRLP_TILING_CHECK=1 also runs the
             // host builder and compares every array
-            const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, nullptr, rb, tile_cols, rem_cap);
+            const bool ok = tiled.build_on_device(rows, cols, nnz, rowptr.p, col.p, min_rows, min_dense, bs, rb, tile_cols, rem_cap);
             declined_sparse = !ok;  // rows >= min_rows here: what was missing is dense tiles
             if (pt.on)
                 std::cerr << "[timing]   tiled copy (device build): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, "
@@ -372,20 +465,22 @@ void DeviceMatrix::describe(int rows, int cols, const int *rp, const int *ci, st
             const char *chk = std::getenv("HPRLP_TILING_CHECK");
             if (chk && chk[0] == '1' && ci) {
                 TiledHost th;
-                const bool hok = build_tiled(rows, cols, rp, ci, &th, min_rows, min_dense, rb, tile_cols, rem_cap);
+                const bool hok = build_tiled(rows, cols, host_rp(), ci, &th, min_rows, min_dense, rb, tile_cols, rem_cap);
                 if (hok != ok) throw std::runtime_error("tiling check: host and device builders disagree on acceptance");
                 if (ok) tiled.compare_with(th);
             }
             if (ok) {
-                tiled.build_far(cols, nullptr, gb);  // consumes the remainder lists the check above compares
+                tiled.build_far(cols, bs, gb);  // consumes the remainder lists the check above compares
                 view.tiled = tiled.view;
-                launch_tiled_refresh(tiled, val.p, nullptr);
+                join_values();
+                launch_tiled_refresh(tiled, val.p, bs);
                 HIP_CHECK(hipDeviceSynchronize());
             }
             pt.tick("  build tiled copy (device)");
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && ci) {  // the host builder needs the host column indices
             planned_grid = std::max(((rows + rb - 1) / rb + 7) / 8 * 8, (rows + kThreads - 1) / kThreads);  // fused grid or the split form's finish grid
             const int tc = tile_cols, rc = rem_cap;
+            const int *rp = host_rp();
             tiling = std::async(std::launch::async, [=]() -> std::shared_ptr<TiledHost> {
                 (void)keep;  // keeps the host arrays alive for the duration of the build
                 auto th = std::make_shared<TiledHost>();
@@ -483,6 +578,41 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     choose_sb_rows(model);
     A.upload(m, n, As->rowPtr, As->colIndex, As->value);
     pt.tick("A upload total");
+    // the five model vectors (in the solver's numbering): uploaded beside the device build of A^T's tiled copy when the matrix is
+    // large (own copy stream, helper thread), otherwise in line
+    std::future<void> vec_job;
+    auto upload_vectors = [this, model](bool own_stream) {
+        int dev = prm.device_number;
+        HIP_CHECK(hipSetDevice(dev));
+        hipStream_t cs = nullptr;
+        if (own_stream) HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        auto upload_vec = [cs, own_stream](DBuf<double> &d, const double *src, int len, const std::vector<int> &perm) {
+            std::vector<double> tmp;
+            if (!perm.empty()) {
+                tmp.resize(static_cast<size_t>(len));
+                for (int i = 0; i < len; ++i) tmp[i] = src[perm[i]];
+                src = tmp.data();
+            }
+            if (own_stream) HIP_CHECK(copy_in_pieces(d.p, src, static_cast<size_t>(len) * sizeof(double), hipMemcpyHostToDevice, cs));
+            else d.upload(src, len);
+        };
+        try {
+            upload_vec(AL, model->AL, m, perm_r);
+            upload_vec(AU, model->AU, m, perm_r);
+            upload_vec(l, model->l, n, perm_c);
+            upload_vec(u, model->u, n, perm_c);
+            upload_vec(c, model->c, n, perm_c);
+        } catch (...) {
+            if (cs) (void)hipStreamDestroy(cs);
+            throw;
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+    };
+    AL.alloc(m);
+    AU.alloc(m);
+    l.alloc(n);
+    u.alloc(n);
+    c.alloc(n);
     {   // explicit A^T built on the host, stable in row order (reference src/preprocess.cu:78-82); its index
         // arrays are handed to the background job that builds the tiled copy of A^T
         struct HostT {
@@ -513,8 +643,24 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
                 A.describe(m, n, As->rowPtr, nullptr, nullptr, 0.0);
                 pt.tick("tiled copy of A without a dense-tile requirement (propagation blocking for all entries)");
             }
-            trp.resize(static_cast<size_t>(n) + 1);
-            AT.rowptr.download(trp.data(), trp.size());
+            // the host copy of A^T's row pointers (row blocks, statistics) comes back on a copy stream of its own, driven by a
+            // thread, while the tiled copy of A^T is built from the device arrays (describe_when)
+            int dev = 0;
+            HIP_CHECK(hipGetDevice(&dev));
+            const bool overlap_setup = std::getenv("HPRLP_NO_SETUP_OVERLAP") == nullptr;
+            const int *d_trp = AT.rowptr.p;
+            const int n_rows_t = n;
+            std::shared_future<const int *> trp_ready =
+                std::async(overlap_setup ? std::launch::async : std::launch::deferred, [ht, dev, d_trp, n_rows_t]() -> const int * {
+                    HIP_CHECK(hipSetDevice(dev));
+                    ht->trp.resize(static_cast<size_t>(n_rows_t) + 1);
+                    hipStream_t cs = nullptr;
+                    HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                    const hipError_t e = copy_in_pieces(ht->trp.data(), d_trp, ht->trp.size() * sizeof(int), hipMemcpyDeviceToHost, cs);
+                    (void)hipStreamDestroy(cs);
+                    HIP_CHECK(e);
+                    return ht->trp.data();
+                }).share();
             // the column indices of A^T are only needed on the host by the host tiled builder (or its check)
             const char *htile = std::getenv("HPRLP_HOST_TILING"), *chk = std::getenv("HPRLP_TILING_CHECK");
             const bool need_tci = (htile && htile[0] == '1') || (chk && chk[0] == '1');
@@ -522,8 +668,9 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
                 tci.resize(static_cast<size_t>(nnz));
                 AT.col.download(tci.data(), tci.size());
             }
-            pt.tick("download A^T indices");
-            AT.describe(n, m, trp.data(), need_tci ? tci.data() : nullptr, ht);
+            if (overlap_setup) vec_job = std::async(std::launch::async, upload_vectors, true);  // (the numbering is final here)
+            AT.describe_when(n, m, nnz, trp_ready, need_tci ? tci.data() : nullptr, ht, -1.0, nullptr);
+            trp_ready.wait();
             if (pb_fallback_wanted(AT)) {
                 choose_pb_rows(AT, A, n, m);
                 AT.describe(n, m, trp.data(), nullptr, nullptr, 0.0);
@@ -535,8 +682,8 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             AT.upload(n, m, trp.data(), tci.data(), tv.data(), ht);
         }
         pt.tick("A^T upload total");
-        for (int i = 0; i < m; ++i) max_row_A = std::max(max_row_A, As->rowPtr[i + 1] - As->rowPtr[i]);
-        for (int j = 0; j < n; ++j) max_row_AT = std::max(max_row_AT, trp[j + 1] - trp[j]);
+        max_row_A = std::max(max_row_A, A.longest_row);  // (describe_when; a renumbering does not change the longest row)
+        max_row_AT = std::max(max_row_AT, AT.longest_row);
         const char *ns = std::getenv("HPRLP_NO_SMALL");
         use_small = !(ns && ns[0] == '1') && small_path_fits(m, n, nnz, max_row_A, max_row_AT);
         if (use_small) {
@@ -565,23 +712,8 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             small_posA.upload(posA.data(), posA.size());
         }
     }
-    {
-        auto upload_vec = [](DBuf<double> &d, const double *src, int len, const std::vector<int> &perm) {
-            d.alloc(len);
-            if (perm.empty()) {
-                d.upload(src, len);
-            } else {
-                std::vector<double> tmp(static_cast<size_t>(len));
-                for (int i = 0; i < len; ++i) tmp[i] = src[perm[i]];
-                d.upload(tmp.data(), len);
-            }
-        };
-        upload_vec(AL, model->AL, m, perm_r);
-        upload_vec(AU, model->AU, m, perm_r);
-        upload_vec(l, model->l, n, perm_c);
-        upload_vec(u, model->u, n, perm_c);
-        upload_vec(c, model->c, n, perm_c);
-    }
+    if (vec_job.valid()) vec_job.get();
+    else upload_vectors(false);
     alloc_work();
     // the tiled copy of A was built from the model's own arrays, which the caller may free once we return; the
     // job of A^T owns its arrays and keeps running under scale()
@@ -1054,7 +1186,22 @@ void Solver::scale() {
     overlap_ready = false;  // the split copies of the shards carry matrix values
     ovA.reset();
     ovAT.reset();
-    double *t1 = gsm.p + row_off, *t2 = gsn.p + col_off;
+    // Every matrix-scaling pass that a Ruiz pass follows also leaves that pass's row norms (max |a| of the scaled rows, kernels.hip:
+    // k_scale_matrix<.., NEXT>) in a second pair of gathered vectors, so the norm passes over the matrices are not run; the pairs
+    // change roles pass by pass.  HPRLP_NO_FUSED_NORMS=1: separate norm passes (A/B runs, tests).
+    const bool fuse_norms = prm.use_Ruiz_scaling && std::getenv("HPRLP_NO_FUSED_NORMS") == nullptr;
+    DBuf<double> gsm2, gsn2;
+    if (fuse_norms) {
+        gsm2.alloc(static_cast<size_t>(m_pad));
+        gsn2.alloc(static_cast<size_t>(n_pad));
+        HIP_CHECK(hipMemsetAsync(gsm2.p, 0, sizeof(double) * m_pad, stream));
+        HIP_CHECK(hipMemsetAsync(gsn2.p, 0, sizeof(double) * n_pad, stream));
+    }
+    double *gm = gsm.p, *gn = gsn.p, *gm_next = gsm2.p, *gn_next = gsn2.p;
+    double *t1 = gm + row_off, *t2 = gn + col_off;
+    double *t1n = fuse_norms ? gm_next + row_off : nullptr, *t2n = fuse_norms ? gn_next + col_off : nullptr;
+    bool have_norms = false;  // t1n / t2n hold the next pass's row norms
+    const bool max_next = fuse_norms;  // (a CR scaling pass is followed by Ruiz pass 0)
     launch_fill(row_norm.p, 1.0, m_loc, stream);
     launch_fill(col_norm.p, 1.0, n_loc, stream);
     norm_b_org = 1.0 + std::sqrt(bnorm_sq(this));
@@ -1091,8 +1238,9 @@ void Solver::scale() {
         gather(gsn.p, false);
         launch_vec_scale(row_norm.p, t1, m_loc, true, stream);
         launch_vec_scale(col_norm.p, t2, n_loc, true, stream);
-        launch_scale_matrix(A.view, t1, gsn.p, /*row_first=*/true, /*divide=*/false, stream);
-        launch_scale_matrix(AT.view, t2, gsm.p, /*row_first=*/false, /*divide=*/false, stream);
+        launch_scale_matrix(A.view, t1, gsn.p, /*row_first=*/true, /*divide=*/false, stream, max_next ? t1n : nullptr);
+        launch_scale_matrix(AT.view, t2, gsm.p, /*row_first=*/false, /*divide=*/false, stream, max_next ? t2n : nullptr);
+        have_norms = max_next;
         launch_vec_scale(AL.p, t1, m_loc, false, stream);
         launch_vec_scale(AU.p, t1, m_loc, false, stream);
         launch_vec_scale(c.p, t2, n_loc, false, stream);
@@ -1103,16 +1251,24 @@ void Solver::scale() {
     const int passes = (prm.use_Ruiz_scaling ? 10 : 0) + (prm.use_Pock_Chambolle_scaling ? 1 : 0);
     for (int it = 0; it < passes; ++it) {  // Ruiz :123-153 then Pock-Chambolle :157-183
         const int norm = (prm.use_Ruiz_scaling && it < 10) ? 99 : 1;
-        launch_row_norm(A.view, t1, norm, stream);
-        launch_row_norm(AT.view, t2, norm, stream);
-        gather(gsm.p, true);
-        gather(gsn.p, false);
+        if (have_norms) {  // left by the previous scaling pass in the other pair of vectors
+            std::swap(gm, gm_next);
+            std::swap(gn, gn_next);
+            t1 = gm + row_off, t2 = gn + col_off, t1n = gm_next + row_off, t2n = gn_next + col_off;
+        } else {
+            launch_row_norm(A.view, t1, norm, stream);
+            launch_row_norm(AT.view, t2, norm, stream);
+        }
+        gather(gm, true);
+        gather(gn, false);
         launch_vec_scale(row_norm.p, t1, m_loc, false, stream);
         launch_vec_scale(AL.p, t1, m_loc, true, stream);
         launch_vec_scale(AU.p, t1, m_loc, true, stream);
         launch_vec_scale(col_norm.p, t2, n_loc, false, stream);
-        launch_scale_matrix(A.view, t1, gsn.p, true, true, stream);
-        launch_scale_matrix(AT.view, t2, gsm.p, false, true, stream);
+        const bool next = fuse_norms && it + 1 < passes && it + 1 < 10;  // a max-norm (Ruiz) pass follows
+        launch_scale_matrix(A.view, t1, gn, true, true, stream, next ? t1n : nullptr);
+        launch_scale_matrix(AT.view, t2, gm, false, true, stream, next ? t2n : nullptr);
+        have_norms = next;
         launch_vec_scale(c.p, t2, n_loc, true, stream);
         launch_vec_scale(l.p, t2, n_loc, false, stream);
         launch_vec_scale(u.p, t2, n_loc, false, stream);

@@ -3,6 +3,7 @@
 // (reference include/structs.h:127-277) without vendor-library handles.
 #pragma once
 
+#include <functional>
 #include <future>
 #include <map>
 #include <memory>
@@ -56,6 +57,12 @@ struct DeviceMatrix {
     // after the arrays are on the device.  min_dense >= 0 overrides the share of the entries the tiled build wants in
     // staged tiles (0: accept any pattern -- everything outside dense tiles goes through the propagation-blocking remainder)
     void describe(int rows, int cols, const int *rp, const int *ci, std::shared_ptr<void> keep, double min_dense_override = -1.0);
+    // the same with the host row pointers delivered later and the values possibly still being uploaded (solver.cpp)
+    void describe_when(int rows, int cols, long nnz, std::shared_future<const int *> rp_ready, const int *ci, std::shared_ptr<void> keep,
+                       double min_dense_override, std::future<void> *values_ready);
+    void build_tiled_copy(int rows, int cols, int nnz, const std::function<const int *()> &host_rp, const int *ci, std::shared_ptr<void> keep,
+                          double min_dense_override, const std::function<void()> &join_values, struct PhaseTimer &pt);
+    int longest_row = 0;  // entries of the longest row (set by describe)
     bool declined_sparse = false;  // the last tiled build was declined for lack of dense tiles (not for size)
     bool declined_shape = false;   // ... not attempted: too few columns for staging to pay, or rows too long for the remainder list
     void finish_tiling(hipStream_t s);  // wait for the job, upload the copy, fill its values from the CSR values

@@ -72,6 +72,42 @@ def test_scaling_without_cr_is_bit_exact(gpu):
     s.close(); model.free()
 
 
+def lp_with_split_rows(seed=9):
+    """220 x 6000 LP: a 5000-nonzero row (cut into chunks, kSplitRow), a 350-nonzero row (vector mode), a 200-nonzero column and
+    two empty rows."""
+    from scipy import sparse
+    lp = lpgen.planted_lp(220, 6000, 9000, seed)
+    A = lp["A"].tolil()
+    rng = np.random.default_rng(seed)
+    A[3, rng.choice(6000, size=5000, replace=False)] = rng.normal(size=5000)
+    A[40, rng.choice(6000, size=350, replace=False)] = rng.normal(size=350)
+    A[rng.choice(220, size=200, replace=False), 17] = rng.normal(size=200).reshape(-1, 1)
+    A[100, :] = 0
+    A[219, :] = 0
+    A = sparse.csr_matrix(A)
+    A.eliminate_zeros()
+    A.sort_indices()
+    out = lpgen._plant(np.random.default_rng(seed + 1), A)
+    out.update(m=220, n=6000, A=A, rowptr=A.indptr.astype(np.int32), colind=A.indices.astype(np.int32), values=A.data.copy())
+    return out
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("which", ["long", "split"])
+def test_scaling_bit_exact_on_every_row_kind(gpu, which, fused, monkeypatch):
+    """The scaling passes that also leave the next Ruiz pass's row norms (k_scale_matrix<.., NEXT>) and the LDS-staged sum norm,
+    on stream-mode, vector-mode, split and empty rows: bits of the oracle, with and without the fusion."""
+    if not fused:
+        monkeypatch.setenv("HPRLP_NO_FUSED_NORMS", "1")
+    lp = lp_with_long_rows() if which == "long" else lp_with_split_rows()
+    model, s, ref = make(lp, use_CR_scaling=False, use_bc_scaling=False)
+    s.scale()
+    for name, want in (("A_val", ref.Av), ("AT_val", ref.ATv), ("AL", ref.AL), ("AU", ref.AU), ("l", ref.l),
+                       ("u", ref.u), ("c", ref.c), ("row_norm", ref.row_norm), ("col_norm", ref.col_norm)):
+        assert np.array_equal(s.get(name), want), name
+    s.close(); model.free()
+
+
 def test_scaling_with_cr_matches(gpu):
     lp = lpgen.planted_lp(300, 500, 3000, 22)
     model, s, ref = make(lp)

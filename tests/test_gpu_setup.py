@@ -150,3 +150,33 @@ def test_power_start_vector_formed_on_the_device_for_long_vectors(gpu):
     assert it_d == it_h and it_d >= 10
     assert abs(lam_d - lam_h) <= 1e-10 * lam_h
     s.close(); model.free()
+
+
+def test_overlapped_setup_equals_the_sequential_one(gpu):
+    """Round 4: the value upload, the host-side row blocks, the download of A^T's row pointers and the model vectors travel
+    beside the device builds (helper threads, own copy streams; solver.cpp: describe_when).  HPRLP_NO_SETUP_OVERLAP=1 runs
+    everything in line: the device arrays, the scaled data and the iterates must be the same bits, on a matrix large enough
+    for every overlap to be taken (over 4e6 nonzeros, over 1e5 rows, tiled copies)."""
+    m = n = 300000
+    lp = bh.banded_lp(m, n, 16, 3000, seed=77)
+
+    def grab():
+        model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        desc = s.describe()
+        raw = [s.get(k) for k in ("A_val", "AT_val", "AL", "AU", "l", "u", "c")]
+        s.scale()
+        lam, it = s.power_iteration()
+        s.init(-1.0, lam * 1.01)
+        s.iterate(12, True)
+        out = (desc, raw, [s.get(k) for k in ("A_val", "AT_val", "x", "y")], lam, it)
+        s.close()
+        model.free()
+        return out
+
+    seq = with_env({"HPRLP_NO_SETUP_OVERLAP": "1", "HPRLP_TILED_MIN_ROWS": "65536"}, grab)
+    ovl = with_env({"HPRLP_TILED_MIN_ROWS": "65536"}, grab)
+    assert "tiled" in ovl[0] and seq[0] == ovl[0]
+    for a, b_ in zip(seq[1] + seq[2], ovl[1] + ovl[2]):
+        assert np.array_equal(a, b_)
+    assert seq[3:] == ovl[3:]
