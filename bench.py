@@ -369,6 +369,11 @@ LADDER_POINTS = {
 }
 
 
+# The four Mittelmann-family generators at table size (lpgen.FAMILIES_LARGE): `--ladder-point family_<name>` measures their
+# half-steps the same way; they are not part of the default ladder (generation takes longer than the measurement).
+FAMILY_POINTS = {"family_" + k: mk for k, mk in G.FAMILIES_LARGE.items()}
+
+
 def ladder_traffic(key, kernels):
     """FETCH / WRITE counters of this ladder point (profiles/pmc_traffic.json, entry "ladder:<key>", collected by
     tools/profile_ladder.sh in separate rocprofv3 --pmc passes): carried only if they were taken on the kernel forms this run
@@ -392,7 +397,7 @@ def ladder_point(key, steps=100, warmup=20, timed=True):
     """One ladder point: which kernels the library chose, the half-step times by HIP events around every kernel
     (hprlp_solver_time_iterations mode 1), the algorithmic-bytes fraction of 8 TB/s and -- from the counter passes -- the HBM
     bytes a half-step really moves and their ratio to the algorithmic bytes."""
-    lp = LADDER_POINTS[key]()
+    lp = (LADDER_POINTS.get(key) or FAMILY_POINTS[key])()
     m, n, nnz = lp["m"], lp["n"], len(lp["values"])
     model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
     del lp
@@ -536,7 +541,7 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the config-2/3 side measurements")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-tolerance solve of the workload")
     ap.add_argument("--no-ladder", action="store_true", help="skip the size-and-structure ladder (2e6 .. 6e7 nnz)")
-    ap.add_argument("--ladder-point", default=None, choices=sorted(LADDER_POINTS),
+    ap.add_argument("--ladder-point", default=None, choices=sorted(LADDER_POINTS) + sorted(FAMILY_POINTS),
                     help="run ONE ladder point and print its record (what tools/profile_ladder.sh puts under rocprofv3)")
     args = ap.parse_args()
     if args.gpus < 1:

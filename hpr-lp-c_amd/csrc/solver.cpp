@@ -187,6 +187,14 @@ static RowCuts slab_cuts(int rows, int cols, const int *rp, ColsOf cols_of) {
     return rc;
 }
 
+static int workgroup_slots() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus * kTileResidentPerCu;
+}
+
+constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of the gathered vector that one 4 MiB L2 keeps beside the matrix stream
+
 // HPRLP_TIMING=1: wall time of the set-up phases on stderr
 struct PhaseTimer {
     bool on;
@@ -408,6 +416,18 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (short_form ? (1 << 19) : 800000));  // (800 k: as kPbMinCols, a vector beyond one L2)
         const int longest = longest_row;  // (describe_when)
         declined_shape = cols < min_cols || longest > kTileMaxRow;
+        // Round 4, late.  A matrix of fewer full-height super-blocks than workgroup slots whose height could not be lowered (its
+        // rows' column windows are too wide for short super-blocks) would run the piece form: partial sums through memory and a
+        // finish launch.  When the stream kernel's gathers stay inside one L2 anyway -- every XCD runs a contiguous eighth of the
+        // rows, whose columns (median row span + the eighth's own drift along the diagonal, Solver::choose_sb_rows) cover less
+        // than kStreamL2Bytes of the vector -- the stream kernel is the faster form: multicommodity-flow LP, 535 k x 2.03 M,
+        // 40 diagonal blocks: y-half 64.9 us (512 pieces of 66 super-blocks) against 22.4 us, 10.1 k -> 18.0 k iterations/s.
+        // Config 5's quarter shard (window 4.0 MB: pieces 0.31 ms, stream 0.38) keeps the pieces.
+        declined_l2 = false;
+        if (!declined_shape && rb == kTileRows && (rows + rb - 1) / rb < workgroup_slots() && xcd_gather_bytes > 0.0 &&
+            xcd_gather_bytes <= kStreamL2Bytes && std::getenv("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
+            declined_shape = declined_l2 = true;
+        }
         const char *ht = std::getenv("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
         // A FEW long rows (dense LP columns / rows) do not have to cost the matrix the tiled kernel: they are left out of the
@@ -767,12 +787,6 @@ static int whole_rounds_height(int rows, int slots) {
     return std::min(kTileRows, (per + 63) / 64 * 64);
 }
 
-static int workgroup_slots() {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus * kTileResidentPerCu;
-}
-
 // Heights for a matrix that runs the tiled form WITHOUT staged tiles (pb_fallback_wanted: every entry through the
 // propagation-blocking remainder).  No tile is staged, so a lower super-block costs nothing in tile traffic: take the height
 // that gives every workgroup slot whole super-blocks -- the half-step is then ONE fused launch whose epilogue hands the
@@ -804,6 +818,7 @@ void Solver::choose_pb_rows(DeviceMatrix &M, DeviceMatrix &other, int rows, int 
 void Solver::choose_sb_rows(const LP_info_cpu *model) {
     A.sb_rows = A.far_group = AT.sb_rows = AT.far_group = kTileRows;
     A.tile_cols = AT.tile_cols = kTileCols;
+    A.xcd_gather_bytes = AT.xcd_gather_bytes = 0.0;
     if (const char *force = std::getenv("HPRLP_TILE_COLS")) {  // tests / A/B runs: one tile width for both matrices
         A.tile_cols = AT.tile_cols = std::atoi(force) <= kTileColsNarrow ? kTileColsNarrow : kTileCols;
     }
@@ -837,6 +852,9 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     std::nth_element(span.begin(), span.begin() + span.size() / 2, span.end());
     const double w_a = static_cast<double>(std::max<long>(span[span.size() / 2], 1));
     const double slope = static_cast<double>(n) / m;  // columns per row along the "diagonal"
+    // what one XCD's eighth of the rows gathers from (stream kernel; DeviceMatrix::build_tiled_copy weighs it against the piece form)
+    A.xcd_gather_bytes = (w_a + m / 8.0 * slope) * 8.0;
+    AT.xcd_gather_bytes = (w_a / slope + n / 8.0 / slope) * 8.0;
     // Tile width (round 4).  A row segment of more than kTileChunk entries in one tile goes to the remainder lists WHOLE (34
     // bytes of traffic per entry against 11 in a tile).  With d entries per row spread over a window of w columns a tile of T
     // columns holds d T / w of them on average; from about 1.2 on, segments of five and more are common (1M x 1M, band 1e4,
@@ -1942,6 +1960,8 @@ void Solver::collect_solution(HPRLP_results *out) {
     out->y = static_cast<double *>(std::malloc(sizeof(double) * std::max(m_loc, 1)));
     out->z = static_cast<double *>(std::malloc(sizeof(double) * std::max(n_loc, 1)));
     if (!out->x || !out->y || !out->z) throw std::runtime_error("host allocation of the solution failed");
+    // (three copies side by side, each driven by its own thread on its own stream, were measured on config 5's 3 x 80 MB: 0.036-0.045 s
+    // against 0.017 s for this sequence -- pageable copies serialise inside the runtime)
     HIP_CHECK(hipMemcpyAsync(out->x, sn1.p, sizeof(double) * n_loc, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(out->y, sm1.p, sizeof(double) * m_loc, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(out->z, zo, sizeof(double) * n_loc, hipMemcpyDeviceToHost, stream));
