@@ -397,7 +397,11 @@ def ladder_point(key, steps=100, warmup=20, timed=True):
     """One ladder point: which kernels the library chose, the half-step times by HIP events around every kernel
     (hprlp_solver_time_iterations mode 1), the algorithmic-bytes fraction of 8 TB/s and -- from the counter passes -- the HBM
     bytes a half-step really moves and their ratio to the algorithmic bytes."""
-    lp = (LADDER_POINTS.get(key) or FAMILY_POINTS[key])()
+    if key.startswith("banded_"):  # banded_<rows>_<entries per row>_<band>: sweeps of the kernel-form decision (tools/ab_forms.sh)
+        rows_, per_row_, band_ = (int(v) for v in key.split("_")[1:4])
+        lp = banded_lp(rows_, rows_, per_row_, band_)
+    else:
+        lp = (LADDER_POINTS.get(key) or FAMILY_POINTS[key])()
     m, n, nnz = lp["m"], lp["n"], len(lp["values"])
     model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
     del lp
@@ -541,7 +545,7 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the config-2/3 side measurements")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-tolerance solve of the workload")
     ap.add_argument("--no-ladder", action="store_true", help="skip the size-and-structure ladder (2e6 .. 6e7 nnz)")
-    ap.add_argument("--ladder-point", default=None, choices=sorted(LADDER_POINTS) + sorted(FAMILY_POINTS),
+    ap.add_argument("--ladder-point", default=None,
                     help="run ONE ladder point and print its record (what tools/profile_ladder.sh puts under rocprofv3)")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -836,7 +836,8 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
         std::string d = std::string(name) + ": ";
         if (!t.valid) {
             d += "stream kernel (k_spmv_fused, " + std::to_string(M.view.nblk) + " row blocks, " + std::to_string(M.view.nlong) + " split rows)";
-            if (M.declined_l2) d += " [tiled piece form not attempted: the stream kernel's gathers stay in one L2]";
+            if (M.declined_coalesced) d += " [tiled form not attempted: neighbouring rows gather from the same lines]";
+            else if (M.declined_l2) d += " [tiled piece form not attempted: the stream kernel's gathers stay in one L2]";
             else if (M.declined_shape) d += " [tiled form not attempted: shape]";
             else if (M.declined_sparse) d += " [tiled form declined: too few entries in dense tiles]";
             return d;

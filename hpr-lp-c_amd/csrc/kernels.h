@@ -193,6 +193,7 @@ void launch_cr_log_update(const CsrDev &M, const double *other_full, double *res
 bool cr_runs_tiled(const CsrDev &M);
 void launch_exp_clamp(double *v, int n, hipStream_t s);
 void launch_row_norm(const CsrDev &M, double *result, int norm, hipStream_t s);
+double launch_line_density(const int *rowptr, const int *col, int rows, hipStream_t s);  // distinct 64-byte lines gathered per entry, sampled (synchronises)
 int launch_longest_row(const int *rowptr, int rows, hipStream_t s);  // max_i rowptr[i+1] - rowptr[i] (synchronises the stream)
 // val = op(op(val, first), second) where first/second are the row vector or the gathered column vector
 void launch_scale_matrix(const CsrDev &M, const double *rowvec, const double *colvec_full, bool row_first,

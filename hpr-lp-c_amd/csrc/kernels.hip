@@ -2018,6 +2018,56 @@ __global__ void __launch_bounds__(kWave) k_row_sum_long(CsrDev M, double *result
     result[r] = norm_result(acc);
 }
 
+// How well the stream kernel's gathers coalesce: distinct 64-byte lines of the gathered vector per matrix entry, over sampled
+// windows of 64 consecutive rows (what one wave of k_spmv_fused gathers for at most).  1: every entry pulls its own line through
+// the L2 (a banded-random row pattern); 1/8: eight entries share a line (stencil rows, incidence matrices).  One workgroup of 64
+// lanes per window; lines within 2^16 of the window's lowest are marked in an LDS bitmap, lines beyond that count as distinct.
+constexpr int kDensityWindowRows = 64;
+__global__ void __launch_bounds__(kWave) k_line_density(const int *__restrict__ rowptr, const int *__restrict__ col, int rows, int nwin,
+                                                        unsigned long long *out) {
+    __shared__ unsigned int bits[2048];  // 65536 lines
+    __shared__ int lo_s;
+    const int lane = threadIdx.x;
+    const int r0 = static_cast<int>(static_cast<long>(blockIdx.x) * (rows - kDensityWindowRows) / max(nwin - 1, 1));
+    const int k0 = rowptr[r0], k1 = rowptr[min(r0 + kDensityWindowRows, rows)];
+    for (int i = lane; i < 2048; i += kWave) bits[i] = 0u;
+    int lo = 0x7fffffff;
+    for (int k = k0 + lane; k < k1; k += kWave) lo = min(lo, col[k] >> 3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lo = min(lo, __shfl_xor(lo, off));
+    if (lane == 0) lo_s = lo;
+    __syncthreads();
+    lo = lo_s;
+    unsigned long long far = 0;
+    for (int k = k0 + lane; k < k1; k += kWave) {
+        const int d = (col[k] >> 3) - lo;
+        if (d < 65536) atomicOr(&bits[d >> 5], 1u << (d & 31));
+        else ++far;
+    }
+    __syncthreads();
+    unsigned long long cnt = far;
+    for (int i = lane; i < 2048; i += kWave) cnt += __popc(bits[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) {
+        atomicAdd(out, cnt);
+        atomicAdd(out + 1, static_cast<unsigned long long>(k1 - k0));
+    }
+}
+
+double launch_line_density(const int *rowptr, const int *col, int rows, hipStream_t s) {
+    if (rows < 4 * kDensityWindowRows) return 1.0;
+    const int nwin = std::min(1024, rows / kDensityWindowRows);
+    DBuf<unsigned long long> out;
+    out.alloc(2);
+    HIP_CHECK(hipMemsetAsync(out.p, 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_line_density, dim3(nwin), dim3(kWave), 0, s, rowptr, col, rows, nwin, out.p);
+    unsigned long long h[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return h[1] ? static_cast<double>(h[0]) / static_cast<double>(h[1]) : 1.0;
+}
+
 __global__ void __launch_bounds__(kThreads) k_longest_row(const int *__restrict__ rowptr, int rows, int *out) {
     int best = 0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < rows; i += gridDim.x * kThreads) best = max(best, rowptr[i + 1] - rowptr[i]);

@@ -193,6 +193,7 @@ static int workgroup_slots() {
     return cus * kTileResidentPerCu;
 }
 
+constexpr double kStreamLineDensity = 0.25;  // build_tiled_copy: at most this many 64-byte lines gathered per entry -> stream kernel
 constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of the gathered vector that one 4 MiB L2 keeps beside the matrix stream
 
 // HPRLP_TIMING=1: wall time of the set-up phases on stderr
@@ -424,6 +425,17 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // 40 diagonal blocks: y-half 64.9 us (512 pieces of 66 super-blocks) against 22.4 us, 10.1 k -> 18.0 k iterations/s.
         // Config 5's quarter shard (window 4.0 MB: pieces 0.31 ms, stream 0.38) keeps the pieces.
         declined_l2 = false;
+        line_density = (rows > 100000 && nnz > 1000000) ? launch_line_density(rowptr.p, col.p, rows, nullptr) : 1.0;
+        if (pt.on) std::cerr << "[timing]   gathered 64-byte lines per entry (sampled 64-row windows): " << line_density << std::endl;
+        // Rows whose neighbours gather from the same 64-byte lines (stencil rows, incidence matrices, bands a few hundred columns
+        // wide) are what the stream kernel is good at: its gathers coalesce and hit the L1 / L2, and there is nothing for staged
+        // tiles to save.  Measured (tools/ab_forms.sh, 1M x 1M, 20 per row): band 500 (0.1 lines per entry) stream 0.071 ms per
+        // half-step, band 2000 (0.2) 0.107 -- the tiled build declines such bands (more than four entries of a row per tile) and the
+        // all-remainder form that used to follow took 0.138 / 0.149; grid PDE-control LP (0.11 / 0.20): stream 0.0245 against
+        // 0.0361 ms in the lowered fused form.  From 0.37 lines per entry on (band 4000) the fused tiled form wins (0.089 / 0.124).
+        declined_coalesced = false;
+        if (!declined_shape && line_density <= kStreamLineDensity && !mr && min_dense_override < 0.0 && std::getenv("HPRLP_TILED_ANYWAY") == nullptr)
+            declined_shape = declined_coalesced = true;
         if (!declined_shape && rb == kTileRows && (rows + rb - 1) / rb < workgroup_slots() && xcd_gather_bytes > 0.0 &&
             xcd_gather_bytes <= kStreamL2Bytes && std::getenv("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
             declined_shape = declined_l2 = true;
@@ -765,7 +777,11 @@ bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
     if (nt && nt[0] == '1') return false;
     static const long min_cols = std::getenv("HPRLP_PB_MIN_COLS") ? std::atol(std::getenv("HPRLP_PB_MIN_COLS")) : kPbMinCols;
     static const long min_nnz = std::getenv("HPRLP_PB_MIN_NNZ") ? std::atol(std::getenv("HPRLP_PB_MIN_NNZ")) : 4000000L;  // (tests lower it)
-    return !comm && !M.view.tiled.valid && M.declined_sparse && M.view.cols >= min_cols && M.view.nnz >= min_nnz;
+    // a pattern whose rows stay near a diagonal keeps the stream kernel: each XCD's eighth of the rows gathers from a window of the
+    // vector that its L2 holds (Solver::choose_sb_rows: xcd_gather_bytes; 0 = not estimated).  1M x 1M, band 2000, 20 per row (the
+    // tiled build declines it: too many entries of a row per tile): stream 0.107 ms per half-step, all-remainder form 0.149.
+    const bool in_l2 = M.xcd_gather_bytes > 0.0 && M.xcd_gather_bytes <= kStreamL2Bytes && std::getenv("HPRLP_PB_MIN_COLS") == nullptr;
+    return !comm && !M.view.tiled.valid && M.declined_sparse && !in_l2 && M.view.cols >= min_cols && M.view.nnz >= min_nnz;
 }
 
 // Super-block heights of this LP's tiled copies (tiled.h).  A matrix with fewer than 512 full-height super-blocks cannot give

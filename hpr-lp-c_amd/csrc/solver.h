@@ -66,6 +66,8 @@ struct DeviceMatrix {
     bool declined_sparse = false;  // the last tiled build was declined for lack of dense tiles (not for size)
     bool declined_shape = false;   // ... not attempted: too few columns for staging to pay, or rows too long for the remainder list
     bool declined_l2 = false;      // ... not attempted (a case of declined_shape): piece form against a stream kernel whose gathers stay in one L2
+    bool declined_coalesced = false;  // ... not attempted (a case of declined_shape): neighbouring rows gather from the same lines
+    double line_density = 1.0;     // distinct 64-byte lines of the gathered vector per entry (kernels.hip: launch_line_density)
     double xcd_gather_bytes = 0.0; // estimate by Solver::choose_sb_rows: bytes of the gathered vector an XCD's eighth of the rows reads (0: unknown)
     void finish_tiling(hipStream_t s);  // wait for the job, upload the copy, fill its values from the CSR values
     void refresh_tiled(hipStream_t s);  // re-gather the tiled values from the CSR values (after scaling)

@@ -70,3 +70,46 @@ def test_family_whole_solve_equals_the_oracle(gpu, name, tol):
     rp = model.solve(hprlp.Parameters(stop_tol=tol, use_presolve=True, max_iter=400_000))
     assert rp.status == "OPTIMAL" and abs(rp.primal_obj - GOLD[name]["objective"]) <= 50 * tol * (1 + abs(GOLD[name]["objective"]))
     model.free()
+
+
+@pytest.mark.gpu
+def test_kernel_form_follows_the_gather_pattern(gpu):
+    """Round 4, late (solver.cpp: build_tiled_copy, pb_fallback_wanted).  Which form runs is decided from measurable properties
+    of the pattern: rows whose neighbours gather from the same 64-byte lines keep the stream kernel (a grid stencil: cont-like),
+    and a narrow band that the tiled build declines keeps it too instead of falling into the all-remainder form, because every
+    XCD's share of the rows gathers from a window its L2 holds.  The iterates still follow the oracle."""
+    import bench_helpers as bh
+    lp = lpgen.pde_control_lp(560, 43)
+    model = hprlp.Model.from_csr(*_args(lp))
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    d = s.describe()
+    assert "stream kernel" in d.split("A^T:")[0] and "neighbouring rows gather from the same lines" in d, d
+    s.close()
+    model.free()
+
+    m = n = 600_000
+    lp = bh.banded_lp(m, n, 40, 4000, seed=3)  # ten entries of a row per 1024-column tile: the tiled build declines
+    model = hprlp.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    d = s.describe()
+    assert "all-remainder" not in d and d.count("stream kernel") == 2 and "too few entries in dense tiles" in d, d
+    # twelve iterations and a check step against the oracle on the data the device holds
+    op = O.Params.default()
+    ref = O.ScaledLP(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"], op)
+    s.scale()
+    for name, arr in (("A_val", ref.Av), ("AT_val", ref.ATv), ("AL", ref.AL), ("AU", ref.AU), ("l", ref.l), ("u", ref.u), ("c", ref.c),
+                      ("row_norm", ref.row_norm), ("col_norm", ref.col_norm)):
+        arr[:] = s.get(name)
+    lam = 1.7
+    st = ref.new_state()
+    s.init(1.0, lam)
+    s.iterate(12, True)
+    for k in range(12):
+        ref.x_half(st, 1.0, k, 0)
+        ref.y_half(st, 1.0, lam, k, 0)
+    ref.x_half(st, 1.0, 12, 1)
+    ref.y_half(st, 1.0, lam, 12, 1)
+    for name in ("x", "y", "x_bar", "y_bar"):
+        np.testing.assert_allclose(s.get(name), st[name], rtol=0, atol=1e-11, err_msg=name)
+    s.close()
+    model.free()
