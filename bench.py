@@ -788,13 +788,18 @@ def main():
             try:
                 t1 = time.time()
                 r = model.solve(H.Parameters(stop_tol=1e-4, use_presolve=False, time_limit=600.0))
-                out["time_to_tol"] = {"tol": 1e-4, "seconds": time.time() - t1, "solver_seconds": r.time, "iterations": r.iter,
+                wall = time.time() - t1
+                ph = H.last_solve_phases()
+                # `seconds` = the C call solve() from entry to return, timed inside the library (what a C / C++ caller of the
+                # reference's ABI waits for); the Python wrapper around it then copies the three 80 MB solution vectors into
+                # numpy arrays and frees the C ones, which is the harness's doing: reported beside it
+                out["time_to_tol"] = {"tol": 1e-4, "seconds": ph["whole_call"], "python_wrapper_seconds": wall, "solver_seconds": r.time, "iterations": r.iter,
                                       # the reference's own instrument (HPRLP_results.time4 / iter4, include/structs.h:50-57)
                                       "time4_s": r.time4, "iter4": r.iter4,
                                       "reference_style_iterations_per_s": r.iter / max(r.time, 1e-9),
                                       "status": r.status, "rel_obj_err": abs(r.primal_obj - obj_star) / (1 + abs(obj_star)),
                                       # where `seconds` goes (hprlp_last_solve_phases); the reference's `time` = power iteration + loop
-                                      "phases_s": H.last_solve_phases()}
+                                      "phases_s": ph}
             except Exception as e:
                 out["time_to_tol"] = {"error": str(e)}
             model.free()
