@@ -569,10 +569,14 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
 // reads per entry: a matrix without column locality, 20 entries per row all in here, spent 0.28 ms on 4e7 entries.)
 // Per-row order of the additions: fixed by the matrix (chunks in order, the scan's tree inside a wave).
 // bnd: kTileThreads / 64 doubles of LDS for the values, then as many 32-bit words for the rows.
-template <int K>
+// C16 (all-remainder copies, K = 8; tiled.h: TiledDev::rq16): the codes are 16 bits -- slot in the step (12 bits) | row minus the
+// previous entry's row (4 bits) -- in chunks of 8 that start at the step's chunk base (TileStep::col0), with the row of every
+// chunk's first entry in rhead: 2.25 instead of 4 bytes per entry, one 16-byte load per lane, no cross-lane work to get the rows.
+template <int K, bool C16 = false>
 __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int s1, double *acc, double *prod, double *bnd, int tid) {
     constexpr int NT = kTileThreads, NW = kTileThreads / 64;
     static_assert(K == 4 || K == 6 || K == 8, "code loads: one or two 16-byte loads, or two 12-byte loads, per lane");
+    static_assert(!C16 || K == 8, "16-bit codes come in chunks of 8");
     if (smid >= s1) return;
     const int wave = tid >> 6, lane = tid & 63;
     double *bnd_val = bnd;
@@ -586,6 +590,15 @@ __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int
         const int last = max(z.e_end - z.e_begin - 1, 0);
 #pragma unroll
         for (int k = 0; k < K; ++k) pv[k] = __builtin_nontemporal_load(t.P + z.e_begin + min(tid + k * NT, last));  // clamped: branch-free
+        if constexpr (C16) {
+            // chunk `tid` of the step (clamped to its last chunk: branch-free), 16-byte aligned
+            typedef uint32_t u4_t __attribute__((ext_vector_type(4), aligned(16)));
+            const int ch = z.col0 + min(tid, max(last >> 3, 0));
+            const u4_t w = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(t.rq16) + ch);
+            cv[0] = w.x; cv[1] = w.y; cv[2] = w.z; cv[3] = w.w;
+            cv[4] = __builtin_nontemporal_load(t.rhead + ch);
+            return;
+        }
         // the lane's K consecutive codes in wide loads (4-byte aligned); behind the step's end the last whole chunk is read
         const int c0 = min(K * tid, max(last + 1 - K, 0));
         if constexpr (K == 6) {
@@ -615,7 +628,16 @@ __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int
         }
         // (a lane whose chunk crosses the step's end loaded the LAST whole chunk instead: move its codes down)
         uint32_t code[K];
-        {
+        if constexpr (C16) {
+            // slot << 16 | row, as the 32-bit codes: the rows by adding up the chunk's deltas from its head row
+            uint32_t r = cv[4];
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                const uint32_t c = (u & 1) ? (cv[u >> 1] >> 16) : (cv[u >> 1] & 0xffffu);
+                if (u > 0) r += c >> 12;
+                code[u] = ((c & 0xfffu) << 16) | r;
+            }
+        } else {
             const int shift = K * tid - min(K * tid, max(cnt - K, 0));  // 0 for every lane but at most one
 #pragma unroll
             for (int u = 0; u < K; ++u) code[u] = cv[u];
@@ -942,7 +964,10 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
         lds_barrier();  // the previous super-block's epilogue is done with acc
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
-        if (!HPRLP_DBG_NOREM) remainder_steps<K>(t, smid, s1, acc, prod, bnd, tid);
+        if (!HPRLP_DBG_NOREM) {
+            if (t.rq16) remainder_steps<K, K == 8>(t, smid, s1, acc, prod, bnd, tid);
+            else remainder_steps<K>(t, smid, s1, acc, prod, bnd, tid);
+        }
         lds_barrier();
         PB_STAMP(4);
         const int r0 = sb * R;

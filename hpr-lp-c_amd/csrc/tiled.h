@@ -167,6 +167,11 @@ struct TiledDev {
     // pre-pass of this launch) and rq[e_begin..e_end): the step's entries in (row, CSR) order, slot in P << 16 | local row
     double *P = nullptr;
     const uint32_t *rq = nullptr;
+    // all-remainder copies (round 4, build_far): the same codes in 16 bits -- slot (12 bits) | row - previous entry's row (4 bits) --
+    // in chunks of 8 entries per step, step s starting at chunk steps[s].col0; rhead: local row of a chunk's first entry.  Null when
+    // some chunk holds a row gap over 15 (rq stays) or HPRLP_PB_CODES32=1.
+    const uint16_t *rq16 = nullptr;
+    const uint16_t *rhead = nullptr;
     // remainder entries, source side (grouped by column / kFarGroup, ascending P position inside a group)
     int n_groups = 0;
     const int *f_gptr = nullptr;      // n_groups + 1
@@ -219,6 +224,7 @@ struct DeviceTiled {
     DBuf<double> tval;
     DBuf<double> P, f_val;
     DBuf<uint32_t> rq;
+    DBuf<uint16_t> rq16, rhead;
     DBuf<int> f_gptr, f_pos, f_perm;
     DBuf<int> f_rptr, f_rk, f_rp;
     DBuf<uint16_t> f_lcol;

@@ -648,6 +648,38 @@ __global__ void __launch_bounds__(kThreads) k_far_fill_q(int n, const unsigned l
     rq[i] = (static_cast<uint32_t>(slot) << 16) | static_cast<uint32_t>(rrow[e]);
 }
 
+// key[i] = step of entry i << 32 for every remainder entry (one workgroup per super-block), the form k_far_fill_q16 reads
+__global__ void __launch_bounds__(kThreads) k_far_step_keys(int nsb, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
+                                                           const TileStep *__restrict__ steps, unsigned long long *__restrict__ key) {
+    const int sb = blockIdx.x;
+    if (sb >= nsb) return;
+    for (int s = sb_mid[sb]; s < sb_ptr[sb + 1]; ++s) {
+        const TileStep st = steps[s];
+        for (int e = st.e_begin + threadIdx.x; e < st.e_end; e += kThreads) key[e] = static_cast<unsigned long long>(s) << 32;
+    }
+}
+
+// 16-bit codes of an all-remainder copy from its 32-bit ones (tiled.h: TiledDev::rq16): entry i of step `step` is entry
+// j = i - e_begin of the step, chunk j / 8 from the step's chunk base (TileStep::col0).  over: set when a row gap inside a chunk
+// does not fit 4 bits.
+__global__ void __launch_bounds__(kThreads) k_far_fill_q16(int n, const unsigned long long *__restrict__ skey, const TileStep *__restrict__ steps,
+                                                          const uint32_t *__restrict__ rq, uint16_t *__restrict__ rq16,
+                                                          uint16_t *__restrict__ rhead, int *__restrict__ over) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const TileStep st = steps[static_cast<int>(skey[i] >> 32)];
+    const int j = i - st.e_begin;
+    const uint32_t c = rq[i], row = c & 0xffffu, slot = c >> 16;
+    uint32_t delta = 0;
+    if (j & 7) delta = row - (rq[i - 1] & 0xffffu);
+    else rhead[st.col0 + (j >> 3)] = static_cast<uint16_t>(row);
+    if (delta > 15u || slot > 0xfffu) {
+        atomicOr(over, 1);
+        delta = 0;
+    }
+    rq16[static_cast<size_t>(st.col0) * 8 + j] = static_cast<uint16_t>(slot | (delta << 12));
+}
+
 __global__ void __launch_bounds__(kThreads) k_far_key_f(int n, int G, const int *__restrict__ e_of_p, const int *__restrict__ rcol,
                                                        unsigned long long *__restrict__ key, int *__restrict__ val) {
     const int p = blockIdx.x * kThreads + threadIdx.x;
@@ -824,6 +856,38 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
         if (std::getenv("HPRLP_TIMING"))
             std::fprintf(stderr, "[timing]   source-side run tables: %d runs of %d entries (%.1f per run), most in one group %d%s\n", nruns, n,
                          static_cast<double>(n) / std::max(nruns, 1), h_mx, view.f_rk ? "" : " -- not used (too many for the producers' LDS table)");
+    }
+    view.rq16 = nullptr;
+    view.rhead = nullptr;
+    if (const char *c32 = std::getenv("HPRLP_PB_CODES32"); view.rem_cap == kPbRemCap && kPbRemK == 8 && !(c32 && c32[0] == '1')) {
+        // chunk bases of the steps (on the host: a few ten thousand steps), every entry's step (kin: free by now), then the codes
+        std::vector<TileStep> hs(static_cast<size_t>(n_steps));
+        steps.download(hs.data(), hs.size());
+        long chunks = 0;
+        for (auto &st : hs) {
+            st.col0 = static_cast<int>(chunks);
+            chunks += (st.e_end - st.e_begin + 7) / 8;
+        }
+        steps.upload(hs.data(), hs.size());
+        rq16.alloc_zero(static_cast<size_t>(chunks) * 8 + 8);
+        rhead.alloc_zero(static_cast<size_t>(chunks) + 8);
+        DBuf<int> over;
+        over.alloc_zero(1);
+        hipLaunchKernelGGL(k_far_step_keys, dim3(view.nsb), dim3(kThreads), 0, s, view.nsb, sb_ptr.p, sb_mid.p, steps.p, kin.p);
+        hipLaunchKernelGGL(k_far_fill_q16, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kin.p, steps.p, rq.p, rq16.p, rhead.p, over.p);
+        int h_over = 0;
+        HIP_CHECK(hipMemcpyAsync(&h_over, over.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (!h_over) {
+            view.rq16 = rq16.p;
+            view.rhead = rhead.p;
+            rq.release();
+        } else {
+            rq16.release();
+            rhead.release();
+        }
+        if (std::getenv("HPRLP_TIMING"))
+            std::fprintf(stderr, "[timing]   remainder codes: %s\n", h_over ? "32 bits (a row gap over 15 inside a chunk)" : "16 bits (slot | row delta), chunks of 8");
     }
     rcol.release(); rrow.release(); rperm.release();
     view.P = P.p;

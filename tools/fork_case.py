@@ -1,9 +1,15 @@
-import os, sys
-sys.path.insert(0, "tests")
-import fuzz_parity as F
-for env in ({}, {"HPRLP_NO_SMALL_POWER": "1"}, {"HPRLP_NO_SMALL": "1"}):
-    r = F.one(326, 1416, 1015, 15031, 1e-6, env)
-    print(env, r["status"], r["iters"], "%.2e %.2e" % (r["rel"], r["dobj"]), flush=True)
-for env in ({}, {"HPRLP_NO_SMALL_POWER": "1"}):
-    r = F.one(1238, 1736, 6920, 12022, 1e-6, env)
-    print(env, r["status"], r["iters"], "%.2e %.2e" % (r["rel"], r["dobj"]), flush=True)
+"""A fuzz case whose iteration count differs from the oracle's: the same LP with the single-launch power iteration off, with the
+single-workgroup kernels off (regular kernels), and at a higher iteration limit -- does the difference follow a kernel, or is it a
+fork at a thresholded restart decision that every summation order takes differently?
+usage: python tools/fork_case.py m n nnz seed [max_iter]"""
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import fuzz_parity as F  # noqa: E402
+
+m, n, nnz, seed = (int(v) for v in sys.argv[1:5])
+max_iter = int(sys.argv[5]) if len(sys.argv) > 5 else 200000
+os.dup2(2, 1)
+for env in ({}, {"HPRLP_NO_SMALL_POWER": "1"}, {"HPRLP_NO_SMALL": "1"}, {"HPRLP_NO_SMALL": "1", "HPRLP_NO_GRAPH": "1"}):
+    r = F.one(m, n, nnz, seed, 1e-6, env, max_iter)
+    print("FORK", (m, n, nnz, seed), env, r["status"], "iterations (gpu, oracle)", r["iters"], "rel %.2e dobj %.2e" % (r["rel"], r["dobj"]), file=sys.stderr, flush=True)
