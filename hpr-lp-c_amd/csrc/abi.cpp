@@ -849,7 +849,7 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
         if (t.R != kTileRows || t.T != kTileCols) d += " (" + std::to_string(t.R) + " rows, tiles of " + std::to_string(t.T) + " columns)";
         const double all = static_cast<double>(M.tiled.dense_entries) + static_cast<double>(M.tiled.n_rem);
         if (all > 0) d += ", " + std::to_string(static_cast<int>(100.0 * M.tiled.dense_entries / all + 0.5)) + " % of the entries in staged tiles";
-        if (t.rem_cap == kPbRemCap) d += t.rq16 ? ", 16-bit codes" : ", 32-bit codes";
+        if (t.rem_cap == kPbRemCap && t.rq16) d += ", 16-bit codes";
         if (t.side_nblk > 0) d += ", long rows aside (" + std::to_string(t.side_nblk) + " blocks through the stream kernel)";
         return d;
     };

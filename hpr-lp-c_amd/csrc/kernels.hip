@@ -629,12 +629,22 @@ __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int
         // (a lane whose chunk crosses the step's end loaded the LAST whole chunk instead: move its codes down)
         uint32_t code[K];
         if constexpr (C16) {
-            // slot << 16 | row, as the 32-bit codes: the rows by adding up the chunk's deltas from its head row
-            uint32_t r = cv[4];
+            // slot << 16 | row, as the 32-bit codes: the rows by adding up the chunk's deltas from its head row; a delta of 15
+            // (rare: an entry behind a run of rows without an entry in this step) takes its row from the wide list
+            uint32_t r = cv[4], wide = 0;
+            {
+                const uint32_t lo = 0xf000u, hi = 0xf0000000u;  // (entry 0 of a chunk never carries a delta)
+                const bool any = ((cv[0] & hi) == hi) | ((cv[1] & lo) == lo) | ((cv[1] & hi) == hi) | ((cv[2] & lo) == lo) |
+                                 ((cv[2] & hi) == hi) | ((cv[3] & lo) == lo) | ((cv[3] & hi) == hi);
+                if (any) wide = t.rwide_ptr[st.col0 + min(tid, max((cnt - 1) >> 3, 0))];  // (position in wide_rows)
+            }
 #pragma unroll
             for (int u = 0; u < K; ++u) {
                 const uint32_t c = (u & 1) ? (cv[u >> 1] >> 16) : (cv[u >> 1] & 0xffffu);
-                if (u > 0) r += c >> 12;
+                if (u > 0) {
+                    if ((c >> 12) == 15u) r = t.wide_rows[wide++];
+                    else r += c >> 12;
+                }
                 code[u] = ((c & 0xfffu) << 16) | r;
             }
         } else {

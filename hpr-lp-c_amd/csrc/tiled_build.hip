@@ -660,24 +660,40 @@ __global__ void __launch_bounds__(kThreads) k_far_step_keys(int nsb, const int *
 }
 
 // 16-bit codes of an all-remainder copy from its 32-bit ones (tiled.h: TiledDev::rq16): entry i of step `step` is entry
-// j = i - e_begin of the step, chunk j / 8 from the step's chunk base (TileStep::col0).  over: set when a row gap inside a chunk
-// does not fit 4 bits.
+// j = i - e_begin of the step, chunk j / 8 from the step's chunk base (TileStep::col0).  A row gap of more than 14 inside a chunk
+// (a step holds about one entry per row: runs of rows without one are rare but do occur) is written as 15 = "take the next row of
+// this chunk from the wide list".  Pass 1 writes the codes, the head rows and a flag per wide entry; after a scan of the flags pass 2
+// files the wide rows in entry order and gives every chunk the list position of its first one.
 __global__ void __launch_bounds__(kThreads) k_far_fill_q16(int n, const unsigned long long *__restrict__ skey, const TileStep *__restrict__ steps,
                                                           const uint32_t *__restrict__ rq, uint16_t *__restrict__ rq16,
-                                                          uint16_t *__restrict__ rhead, int *__restrict__ over) {
+                                                          uint16_t *__restrict__ rhead, int *__restrict__ wide_flag, int *__restrict__ over) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const TileStep st = steps[static_cast<int>(skey[i] >> 32)];
+    const int j = i - st.e_begin, chunk = st.col0 + (j >> 3);
+    const uint32_t c = rq[i], row = c & 0xffffu, slot = c >> 16;
+    uint32_t delta = 0;
+    if (j & 7) {
+        delta = row - (rq[i - 1] & 0xffffu);
+        if (delta > 14u) delta = 15;
+    } else {
+        rhead[chunk] = static_cast<uint16_t>(row);
+    }
+    wide_flag[i] = delta == 15u;
+    if (slot > 0xfffu) atomicOr(over, 1);
+    rq16[static_cast<size_t>(st.col0) * 8 + j] = static_cast<uint16_t>((slot & 0xfffu) | (delta << 12));
+}
+
+__global__ void __launch_bounds__(kThreads) k_far_fill_wide(int n, const unsigned long long *__restrict__ skey, const TileStep *__restrict__ steps,
+                                                           const uint32_t *__restrict__ rq, const int *__restrict__ wide_flag,
+                                                           const int *__restrict__ wide_pos, uint16_t *__restrict__ wide_rows,
+                                                           uint32_t *__restrict__ rwide_ptr) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const TileStep st = steps[static_cast<int>(skey[i] >> 32)];
     const int j = i - st.e_begin;
-    const uint32_t c = rq[i], row = c & 0xffffu, slot = c >> 16;
-    uint32_t delta = 0;
-    if (j & 7) delta = row - (rq[i - 1] & 0xffffu);
-    else rhead[st.col0 + (j >> 3)] = static_cast<uint16_t>(row);
-    if (delta > 15u || slot > 0xfffu) {
-        atomicOr(over, 1);
-        delta = 0;
-    }
-    rq16[static_cast<size_t>(st.col0) * 8 + j] = static_cast<uint16_t>(slot | (delta << 12));
+    if (wide_flag[i]) wide_rows[wide_pos[i]] = static_cast<uint16_t>(rq[i] & 0xffffu);
+    if ((j & 7) == 0) rwide_ptr[st.col0 + (j >> 3)] = static_cast<uint32_t>(wide_pos[i]);
 }
 
 __global__ void __launch_bounds__(kThreads) k_far_key_f(int n, int G, const int *__restrict__ e_of_p, const int *__restrict__ rcol,
@@ -859,7 +875,11 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
     }
     view.rq16 = nullptr;
     view.rhead = nullptr;
-    if (const char *c32 = std::getenv("HPRLP_PB_CODES32"); view.rem_cap == kPbRemCap && kPbRemK == 8 && !(c32 && c32[0] == '1')) {
+    view.rwide_ptr = nullptr;
+    view.wide_rows = nullptr;
+    // (opt-in, HPRLP_PB_CODES16=1: built, tested against the oracle and measured same-box -- uniform random 2M x 2M: x-half +1.8 %,
+    // y-half -2.3 %; config-3 recipe x 30: +2 % / 0 -- the steps of the all-remainder form are bound by their LDS work, not by bytes)
+    if (const char *c16 = std::getenv("HPRLP_PB_CODES16"); view.rem_cap == kPbRemCap && kPbRemK == 8 && c16 && c16[0] == '1') {
         // chunk bases of the steps (on the host: a few ten thousand steps), every entry's step (kin: free by now), then the codes
         std::vector<TileStep> hs(static_cast<size_t>(n_steps));
         steps.download(hs.data(), hs.size());
@@ -871,23 +891,42 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
         steps.upload(hs.data(), hs.size());
         rq16.alloc_zero(static_cast<size_t>(chunks) * 8 + 8);
         rhead.alloc_zero(static_cast<size_t>(chunks) + 8);
-        DBuf<int> over;
-        over.alloc_zero(1);
+        rwide_ptr.alloc_zero(static_cast<size_t>(chunks) + 8);
+        DBuf<int> over, wide_flag(static_cast<size_t>(n)), wide_pos(static_cast<size_t>(n));
+        over.alloc_zero(1);  // a slot over 4095 (cannot happen with steps of kPbRemCap entries: checked, not assumed)
         hipLaunchKernelGGL(k_far_step_keys, dim3(view.nsb), dim3(kThreads), 0, s, view.nsb, sb_ptr.p, sb_mid.p, steps.p, kin.p);
-        hipLaunchKernelGGL(k_far_fill_q16, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kin.p, steps.p, rq.p, rq16.p, rhead.p, over.p);
-        int h_over = 0;
-        HIP_CHECK(hipMemcpyAsync(&h_over, over.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_far_fill_q16, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kin.p, steps.p, rq.p, rq16.p, rhead.p, wide_flag.p, over.p);
+        {
+            size_t bytes = 0;
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, wide_flag.p, wide_pos.p, n, s));
+            DBuf<char> tmp(bytes + 16);
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, wide_flag.p, wide_pos.p, n, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        int last_pos = 0, last_flag = 0, h_over = 0;
+        HIP_CHECK(hipMemcpy(&last_pos, wide_pos.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&last_flag, wide_flag.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&h_over, over.p, sizeof(int), hipMemcpyDeviceToHost));
+        const int n_wide = last_pos + last_flag;
+        wide_rows.alloc_zero(static_cast<size_t>(n_wide) + 8);
+        hipLaunchKernelGGL(k_far_fill_wide, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kin.p, steps.p, rq.p, wide_flag.p, wide_pos.p, wide_rows.p, rwide_ptr.p);
         HIP_CHECK(hipStreamSynchronize(s));
+        const int h_ov[2] = {h_over, n_wide};
         if (!h_over) {
             view.rq16 = rq16.p;
             view.rhead = rhead.p;
+            view.rwide_ptr = rwide_ptr.p;
+            view.wide_rows = wide_rows.p;
             rq.release();
         } else {
             rq16.release();
             rhead.release();
+            rwide_ptr.release();
+            wide_rows.release();
         }
         if (std::getenv("HPRLP_TIMING"))
-            std::fprintf(stderr, "[timing]   remainder codes: %s\n", h_over ? "32 bits (a row gap over 15 inside a chunk)" : "16 bits (slot | row delta), chunks of 8");
+            std::fprintf(stderr, "[timing]   remainder codes: %s (%d entries behind a run of more than 14 rows without an entry in their step)\n",
+                         h_over ? "32 bits" : "16 bits (slot | row delta), chunks of 8", h_ov[1]);
     }
     rcol.release(); rrow.release(); rperm.release();
     view.P = P.p;
