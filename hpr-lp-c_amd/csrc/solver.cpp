@@ -1394,8 +1394,12 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
     auto one_iteration = [&]() {
         launch_pw_normalize(z, q, m_loc, scal.p, stream);
         gather(gsm.p, true);
-        // A^T q: its epilogue writes the products A's remainder needs (hand-off, as between the half-steps): A runs without a pre-pass
-        const bool handed = launch_spmv_push(AT.view, gsm.p, ATq, push_into(A, AT), stream);
+        // A^T q: its epilogue writes the products A's remainder needs (hand-off, as between the half-steps; A then runs without a
+        // pre-pass) -- where the remainder is a large part of A.  With a few per cent of the entries in it the pre-pass is the
+        // cheaper way since round 4: config 5 (5 %), same box: push 104 us of the launch against 64 us of k_far_products, power
+        // iteration 0.385 -> 0.374 s
+        const bool push_pays = A.view.tiled.valid && static_cast<double>(A.tiled.n_rem) >= 0.3 * static_cast<double>(A.view.nnz);
+        const bool handed = launch_spmv_push(AT.view, gsm.p, ATq, push_pays ? push_into(A, AT) : FarPush{}, stream);
         gather(gsn.p, false);
         launch_spmv_plain(A.view, gsn.p, z, q, true, part_y.p, stride_y, stream, handed);
         FinalizeArgs f{};
