@@ -447,11 +447,14 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     DBuf<int> idx_in(static_cast<size_t>(nnz)), sperm(static_cast<size_t>(nnz));
     hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(kThreads), 0, s, nnz, rows, tile_bits, R, T, rowptr, col, key_in.p, idx_in.p);
     size_t tmp_bytes = 0;
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), 0,
+    // Sorted on the (super-block, tile) bits only: the sort is stable and the input is in CSR order -- rows ascending -- so inside a
+    // (super-block, tile) run the entries come out by row, then CSR position, exactly as a sort on the whole key leaves them; 24
+    // instead of 37 key bits on config 5 = three radix passes instead of five (7.8 -> 4.7 ms per matrix).
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), kRowBits,
                                                  key_bits, s));
     {
         DBuf<char> tmp(tmp_bytes + 16);
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), 0,
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key_in.p, skey.p, idx_in.p, sperm.p, static_cast<int>(nnz), kRowBits,
                                                      key_bits, s));
         HIP_CHECK(hipStreamSynchronize(s));
     }
