@@ -385,15 +385,8 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
     // column-tiled copy: only for matrices with at least one 8192-row super-block per CU
     // and with enough column locality (HPRLP_NO_TILED=1 disables; thresholds overridable for tests)
     const char *no = std::getenv("HPRLP_NO_TILED");
-    // the build's own stream (HPRLP_BUILD_STREAM=1): its waits are for its own work, not for the value upload beside it
-    struct BuildStream {
-        hipStream_t s = nullptr;
-        ~BuildStream() {
-            if (s) (void)hipStreamDestroy(s);
-        }
-    } own;
-    if (const char *e = std::getenv("HPRLP_BUILD_STREAM"); e && e[0] == '1') HIP_CHECK(hipStreamCreate(&own.s));
-    const hipStream_t bs = own.s;
+    // (a stream of its own for the build was measured: the stall beside the value upload is the runtime's lock, not a stream wait)
+    const hipStream_t bs = nullptr;
     if (!(no && no[0] == '1')) {
         const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
         const char *md = std::getenv("HPRLP_TILED_MIN_DENSE");
