@@ -119,10 +119,27 @@ def planted_vectors(m, n, seed=5):
     return dict(x=x, z=z, l=l, u=u, is_eq=is_eq, active=active, slack=slack, y=y)
 
 
+def shard_rows_lp(name, parts, seed=5):
+    """The (m / parts) x n matrix a MIDDLE rank of a `parts`-rank run of workload `name` really holds -- rows [rank m / parts,
+    (rank + 1) m / parts) of the whole matrix, global column indices -- as an LP of its own (planted the same way): its y-half
+    is that rank's y-half launch on the whole shard, and by the band's symmetry its rows of A^T (the x-half) have the same
+    shape.  (The workloads `c5_half / c5_quarter / c5_eighth` of rounds 2-4 spread m / parts rows over ALL n columns instead:
+    another matrix, with eight times the column window per super-block at parts = 8.)"""
+    m, n, per_row, band = WORKLOADS[name]
+    rank = parts // 2
+    _, row_off, m_loc = SH.partition(m, parts, rank)
+    rp, ci, v = gen_banded(m, n, per_row, band, seed, row0=row_off, rows=m_loc)
+    return planted_on(m_loc, n, rp, ci, v, seed)
+
+
 def banded_lp(m, n, per_row, band, seed=5):
     """Planted LP on the banded matrix: box 0<=x<=u, half equality rows, half active/inactive '<=' rows."""
-    from scipy import sparse
     rp, ci, v = gen_banded(m, n, per_row, band, seed)
+    return planted_on(m, n, rp, ci, v, seed)
+
+
+def planted_on(m, n, rp, ci, v, seed=5):
+    from scipy import sparse
     A = sparse.csr_matrix((v, ci, rp), shape=(m, n), copy=False)
     p = planted_vectors(m, n, seed)
     b = A @ p["x"]
@@ -249,7 +266,7 @@ def fresh_process_solves(which):
     out = {}
     for label, extra in (("first_solve_of_a_process", []), ("after_hprlp_warmup", ["warm"])):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_start.py"), which] + extra, env=dict(os.environ, HPRLP_COLD_START_JSON="1"),
-                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=60)
         rec = None
         for ln in r.stderr.decode(errors="replace").splitlines():
             if ln.startswith("COLDJSON "):
@@ -263,7 +280,7 @@ def fresh_process_solves(which):
     return out
 
 
-def side_configs():
+def side_configs(cold_start=True):
     """BASELINE configs 2 and 3 (shape-matched stand-ins) on one GPU: it/s by graph replay and time-to-1e-4."""
     out = {}
     for key, lp in (("c2_25fv47_like", G.c2_25fv47_like()), ("c3_pds20_like", G.c3_pds20_like())):
@@ -302,10 +319,14 @@ def side_configs():
                     "time_to_1e-4_parts_s": best, "time_to_1e-4_all_runs_s": [q["total"] for q in runs],
                     "rel_obj_err": abs(r.primal_obj - lp["obj_star"]) / (1 + abs(lp["obj_star"]))}
         s.close()
-        try:  # what a caller's FIRST solve() of a process costs, and the following ones (a fresh process each; round 4)
-            out[key]["solve_call_in_a_fresh_process"] = fresh_process_solves("c2" if key.startswith("c2") else "c3")
-        except Exception as e:  # noqa: BLE001
-            out[key]["solve_call_in_a_fresh_process"] = {"error": str(e)}
+        # what a caller's FIRST solve() of a process costs, and the following ones (a fresh process each; round 4).  Four child
+        # processes inside the driver-timed run: 60 s each at most, none under a profiler (its preloaded library would profile
+        # the children as well) or with --no-cold-start
+        if cold_start and "rocprof" not in os.environ.get("LD_PRELOAD", "") and not any(k.startswith("ROCP") for k in os.environ):
+            try:
+                out[key]["solve_call_in_a_fresh_process"] = fresh_process_solves("c2" if key.startswith("c2") else "c3")
+            except Exception as e:  # noqa: BLE001
+                out[key]["solve_call_in_a_fresh_process"] = {"error": str(e)}
         if key == "c3_pds20_like":
             # BASELINE config 4: solve_batched, shared A = config-3 matrix, B = 64 perturbed c / AU columns.  Members are
             # kept bounded (infinite upper bounds -> 50: with the recipe's perturbed c an unbounded-above column makes the
@@ -366,7 +387,33 @@ LADDER_POINTS = {
     "block_angular_2e7": lambda: G.block_angular_lp(1000, 1000, 2000, 18, 200, 200, 5000, 7),
     "unstructured_4e7": lambda: uniform_random_lp(2_000_000, 2_000_000, 20),
     "expander_7e6": lambda: scaled_c3_lp(30),
+    # what ONE rank of a 2 / 4 / 8-GPU run of config 5 holds (round 5): the y-half of these points is a rank's half-step on
+    # its whole shard -- the figures `predicted_scaling` is made of
+    "c5_shard_of_2": lambda: shard_rows_lp("c5", 2),
+    "c5_shard_of_4": lambda: shard_rows_lp("c5", 4),
+    "c5_shard_of_8": lambda: shard_rows_lp("c5", 8),
 }
+SHARD_POINTS = {2: "c5_shard_of_2", 4: "c5_shard_of_4", 8: "c5_shard_of_8"}
+
+
+def predicted_scaling(iteration_ms_1gpu, ladder_out):
+    """What the first N > 1 record can be held against: per-rank kernel time at P ranks = 2 x the y-half of the rank's shard
+    (the x-half runs the same shape: rows of A^T, by the band's symmetry), x 1.05 for the split into a local-column and a
+    remote-column launch that the overlapped exchange needs (measured with thread ranks, HISTORY.md section 5), + the exposed
+    part of the exchange (model: 0.01 / 0.02 / 0.03 ms at 2 / 4 / 8 ranks; the rest hides behind the local-column launch).
+    A MODEL from one-GPU measurements of this run, not a measurement of N GPUs."""
+    out = {"basis": "this run: config 5 iteration on one GPU, y-half launches of the shard-shaped ladder points", "P1_iteration_ms": iteration_ms_1gpu}
+    exposed = {2: 0.01, 4: 0.02, 8: 0.03}
+    for P, key in SHARD_POINTS.items():
+        pt = (ladder_out or {}).get(key) or {}
+        if "yhalf_ms" not in pt:
+            out[f"P{P}"] = {"error": pt.get("error", "shard point not measured")}
+            continue
+        k = 2.0 * pt["yhalf_ms"]
+        it = 1.05 * k + exposed[P]
+        out[f"P{P}"] = {"shard_yhalf_ms": pt["yhalf_ms"], "shard_yhalf_frac_of_8000": pt["yhalf_frac_of_8000"], "kernels_ms": k, "iteration_ms_model": it,
+                        "speedup_model": iteration_ms_1gpu / it, "speedup_kernels_only": iteration_ms_1gpu / k, "shard_kernel": pt["kernels"].split("A^T:")[0].strip()}
+    return out
 
 
 # The four Mittelmann-family generators at table size (lpgen.FAMILIES_LARGE): `--ladder-point family_<name>` measures their
@@ -470,69 +517,175 @@ def xhalf_kernel_label(tiled):
             "(hand-off, DESIGN.md section 4); shard-shaped matrices: k_tiled_part + k_tiled_finish)")
 
 
-def spawn_ranks(n, argv):
-    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, one
-    fresh child process per GPU, BEFORE this process has made any HIP call -- the parent loads neither torch nor
-    lib/libhprlp.so, never touches a GPU and never execs; it relays rank 0's JSON line and the children's exit codes.
-    A run that cannot give N ranks exits non-zero instead of printing a line for fewer GPUs."""
+# ---- N > 1: a supervisor that cannot end without saying why ---------------------------------------------------------------
+# The ranks run in FRESH child processes of a parent that never touches a GPU (it loads neither torch.cuda nor lib/libhprlp.so and
+# never execs).  The parent watches them: a rank that dies ends the tier, and so does SILENCE -- no new line on any rank's stderr
+# for HPRLP_BENCH_STALL_S seconds (every phase of a rank announces itself: "[bench] rank r: phase ...") or a tier outliving its
+# share of HPRLP_BENCH_BUDGET_S; the parent then terminates exactly the PIDs it started and moves to the next transport tier, in
+# fresh processes again.  The line that comes out says which tier produced it and how the earlier ones ended.
+TIERS = [
+    # (name, environment of the ranks)
+    ("rccl: two communicators, neighbour exchange overlapped with the local part of the half-steps", {}),
+    ("rccl: one communicator, exchange in line (HPRLP_NO_OVERLAP=1)", {"HPRLP_NO_OVERLAP": "1", "HPRLP_BENCH_SINGLE_COMM": "1"}),
+    ("rccl: one communicator, in-place all-gather (HPRLP_DIST_EXCHANGE=allgather)",
+     {"HPRLP_NO_OVERLAP": "1", "HPRLP_BENCH_SINGLE_COMM": "1", "HPRLP_DIST_EXCHANGE": "allgather"}),
+    ("host-staged shared memory between the processes, no RCCL (HPRLP_DIST_TRANSPORT=shm)", {"HPRLP_DIST_TRANSPORT": "shm"}),
+]
+TIER_WEIGHTS = [4.0, 2.5, 2.0, 2.5]
+
+
+def _env_float(name, default):
+    try:
+        return float(os.environ.get(name, default))
+    except ValueError:
+        return float(default)
+
+
+def run_tier(n, argv, tier, tier_env, limit_s, stall_s):
+    """One attempt: n fresh rank processes.  Returns (json line or None, how it ended, seconds, last stderr lines)."""
+    import collections
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    drop = ("TORCHELASTIC_", "GROUP_", "ROLE_", "LOCAL_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")
+    base = {k: v for k, v in os.environ.items() if not k.startswith(drop)}
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HPRLP_BENCH_LAUNCHER="self-spawned")
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HPRLP_BENCH_ROLE="rank", HPRLP_BENCH_TIER=str(tier),
+                   HPRLP_BENCH_LAUNCHER=os.environ.get("HPRLP_BENCH_LAUNCHER", "bench.py supervisor") + " -> fresh rank processes")
+        env.update(tier_env)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), start_new_session=False))
-    log(f"[bench] --gpus {n} without a launcher: started ranks as child processes {[p.pid for p in procs]} (127.0.0.1:{port})")
-    # a rank that dies takes the others with it (they would wait for it at the next gloo collective until its time-out)
-    import threading
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE))
+    log(f"[bench] tier {tier}: {TIERS[tier][0]}: started ranks as child processes {[p.pid for p in procs]} (127.0.0.1:{port}); "
+        f"limit {limit_s:.0f}s, silence limit {stall_s:.0f}s")
+    t0 = time.time()
+    state = {"last": time.time()}
+    tail = collections.deque(maxlen=12)
+
+    def relay(r):
+        for raw in procs[r].stderr:
+            ln = raw.decode(errors="replace").rstrip("\n")
+            state["last"] = time.time()
+            tail.append(ln[:300])
+            sys.stderr.write(ln + "\n")
+            sys.stderr.flush()
+
     out0 = []
-    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    failed = None
+    threads = [threading.Thread(target=relay, args=(r,), daemon=True) for r in range(n)]
+    threads.append(threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True))
+    for t in threads:
+        t.start()
+    how = None
     alive = set(range(n))
-    while alive and failed is None:
+    while alive and how is None:
         for r in sorted(alive):
             rc = procs[r].poll()
             if rc is None:
                 continue
             alive.discard(r)
             if rc != 0:
-                failed = (r, rc)
+                how = f"rank {r} exited with code {rc}"
                 break
+        now = time.time()
+        if how is None and alive:
+            if now - state["last"] > stall_s:
+                how = f"stalled: no line from any rank for {stall_s:.0f}s"
+            elif now - t0 > limit_s:
+                how = f"over its time share of {limit_s:.0f}s"
         time.sleep(0.05)
-    if failed is not None:
-        time.sleep(2.0)  # let the others print their own error
+    if how is not None:
+        time.sleep(1.0)  # let the others print their own error
         for r in sorted(alive):
             if procs[r].poll() is None:
                 procs[r].terminate()  # exactly the PIDs started above
+        deadline = time.time() + 15
+        for r in sorted(alive):
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].send_signal(signal.SIGKILL)
         for r in sorted(alive):
             try:
                 procs[r].wait(timeout=20)
             except subprocess.TimeoutExpired:
-                procs[r].kill()
-        reader.join(timeout=5)
-        log(f"[bench] rank {failed[0]} exited with code {failed[1]}: no result line (ranks {[p.returncode for p in procs]})")
-        return failed[1] if failed[1] > 0 else 1
-    reader.join()
+                how += f"; rank {r} (pid {procs[r].pid}) did not die"
+        log(f"[bench] tier {tier} ended: {how} (exit codes {[p.returncode for p in procs]})")
+        return None, how, time.time() - t0, list(tail)
+    for t in threads:
+        t.join(timeout=10)
     line = None
     for ln in (out0[0] if out0 else b"").decode().splitlines():
         if ln.startswith("{"):
             line = ln
     if line is None:
-        log("[bench] rank 0 printed no JSON line")
-        return 1
+        return None, "rank 0 printed no JSON line", time.time() - t0, list(tail)
     got = json.loads(line).get("n_gpus")
     if got != n:
-        log(f"[bench] rank 0 reported n_gpus={got}, wanted {n}: refusing to pass the line on")
-        return 1
-    sys.stdout.write(line + "\n")
+        return None, f"rank 0 reported n_gpus={got}, wanted {n}", time.time() - t0, list(tail)
+    return line, "ok", time.time() - t0, list(tail)
+
+
+def supervise(n, argv, out_fd=1):
+    """`python bench.py --gpus N` (N > 1): the staged fallback over TIERS.  Exit code 0 and ONE line on stdout, or non-zero and
+    on stderr how every tier ended -- never a line for another number of GPUs than asked for."""
+    budget = _env_float("HPRLP_BENCH_BUDGET_S", 1500.0)
+    stall = _env_float("HPRLP_BENCH_STALL_S", 240.0)
+    first = int(_env_float("HPRLP_BENCH_FIRST_TIER", 0))
+    t0 = time.time()
+    attempts = []
+    for tier in range(first, len(TIERS)):
+        left = budget - (time.time() - t0)
+        if left < 20.0:
+            attempts.append({"tier": tier, "name": TIERS[tier][0], "ended": "not started: the time budget is spent"})
+            continue
+        limit = left * TIER_WEIGHTS[tier] / sum(TIER_WEIGHTS[tier:])
+        line, how, secs, tail = run_tier(n, argv, tier, TIERS[tier][1], limit, stall)
+        attempts.append({"tier": tier, "name": TIERS[tier][0], "ended": how, "seconds": round(secs, 1)})
+        if line is None:
+            attempts[-1]["last_lines"] = tail[-6:]
+            continue
+        rec = json.loads(line)
+        rec["transport"] = {"tier": tier, "name": TIERS[tier][0], "attempts": attempts,
+                            "supervisor": {"budget_s": budget, "silence_limit_s": stall, "seconds": round(time.time() - t0, 1)}}
+        sys.stdout.flush()
+        os.write(out_fd, (json.dumps(rec) + "\n").encode())
+        return 0
+    log("[bench] no result line: every transport tier failed")
+    for a in attempts:
+        log(f"[bench]   tier {a['tier']} ({a['name']}): {a['ended']}")
+    return 1
+
+
+def supervise_under_launcher(n, argv):
+    """The same when a launcher (python -m torch.distributed.run --nproc-per-node N) started N copies of this script: the
+    copies become supervisors that make no HIP call; rank 0's runs the tiers (its fresh children are the one-process-per-GPU
+    ranks, on their own rendezvous port), the others wait for its verdict over gloo and leave with the same exit code."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    budget = _env_float("HPRLP_BENCH_BUDGET_S", 1500.0)
     sys.stdout.flush()
-    return 0
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)  # (gloo announces its connections on the C-level stdout; stdout carries the one JSON line and nothing else)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=budget + 900.0))
+    rc = torch.zeros(1, dtype=torch.int64)
+    if rank == 0:
+        os.environ["HPRLP_BENCH_LAUNCHER"] = "torch.distributed.run -> rank 0 as supervisor"
+        try:
+            rc[0] = supervise(n, argv, real_stdout)
+        except BaseException as e:  # noqa: BLE001  (the waiting copies must hear about it)
+            log(f"[bench] supervisor failed: {e!r}")
+            rc[0] = 1
+    dist.broadcast(rc, src=0)
+    dist.destroy_process_group()
+    return int(rc[0])
 
 
 def main():
@@ -543,6 +696,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("HPRLP_BENCH_WORKLOAD", "c5"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-side", action="store_true", help="skip the config-2/3 side measurements")
+    ap.add_argument("--no-cold-start", action="store_true", help="skip the fresh-process first-solve measurements of configs 2 and 3")
     ap.add_argument("--no-solve", action="store_true", help="skip the time-to-tolerance solve of the workload")
     ap.add_argument("--no-ladder", action="store_true", help="skip the size-and-structure ladder (2e6 .. 6e7 nnz)")
     ap.add_argument("--ladder-point", default=None,
@@ -558,8 +712,14 @@ def main():
         sys.stdout.flush()
         os.write(real, (json.dumps({args.ladder_point: rec}) + "\n").encode())
         return
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus > 1 and os.environ.get("HPRLP_BENCH_ROLE") != "rank" and os.environ.get("HPRLP_BENCH_DIRECT") != "1":
+        # (HPRLP_BENCH_DIRECT=1: the launcher's processes ARE the ranks, as in rounds 1-4: no watchdog, no fallback)
+        if "WORLD_SIZE" not in os.environ:
+            raise SystemExit(supervise(args.gpus, sys.argv[1:]))
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one copy per GPU (torch.distributed.run "
+                             f"--nproc-per-node {args.gpus}), or leave WORLD_SIZE unset and bench.py starts the ranks itself")
+        raise SystemExit(supervise_under_launcher(args.gpus, sys.argv[1:]))
     # The library prints its banner / "problem information" lines to the C-level stdout like the
     # reference does; stdout of this script must carry exactly one JSON line, so route fd 1 to
     # stderr for the duration of the run and keep the real stdout for the result.
@@ -575,6 +735,20 @@ def main():
     if world != args.gpus:  # never print a line whose n_gpus is not what --gpus asked for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run "
                          f"--nproc-per-node {args.gpus}), or leave WORLD_SIZE unset and bench.py starts the ranks itself")
+
+    tier = int(os.environ.get("HPRLP_BENCH_TIER", "0"))
+
+    def phase(what):
+        """Every phase of a rank announces itself on stderr (the supervisor's watchdog listens for silence).  Test hook:
+        HPRLP_BENCH_TEST_HANG=<tier>:<rank>:<word> makes that rank of that tier sleep for ever at the first phase whose name
+        contains <word> (tests/test_dist_cpu.py: a hung exchange must not cost the run its line)."""
+        log(f"[bench] rank {rank}: phase {what}")
+        hang = os.environ.get("HPRLP_BENCH_TEST_HANG")
+        if hang:
+            ht, hr, hw = hang.split(":", 2)
+            if int(ht) == tier and int(hr) == rank and hw in what:
+                log(f"[bench] rank {rank}: TEST HOOK: hanging at phase '{what}'")
+                time.sleep(1e7)
 
     import torch
     dist = None
@@ -596,6 +770,7 @@ def main():
         if args.workload in PERMUTED:
             raise SystemExit("the permuted workloads are single-GPU (the locality ordering runs on the whole matrix)")
         # every rank generates ITS rows only; the rows of A^T come through one all-to-all (no rank holds the whole LP)
+        phase("shard assembly")
         shard, obj_star, nnz_loc = banded_lp_shard(m, n, per_row, band, rank, world, dist)
         tn = torch.tensor([nnz_loc], dtype=torch.int64)
         dist.all_reduce(tn)
@@ -606,19 +781,23 @@ def main():
                 f"in {time.time() - t0:.1f}s, peak host RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.2f} GB")
         t0 = time.time()
         # two unique ids: the exchange stream gets its own communicator (no communicator is driven from two streams)
+        # (fallback tiers: one id = one communicator; HPRLP_DIST_TRANSPORT=shm: the id names a shared-memory segment instead)
+        id_bytes = 128 if (os.environ.get("HPRLP_BENCH_SINGLE_COMM") == "1" or os.environ.get("HPRLP_DIST_TRANSPORT") == "shm") else 256
         uid = np.zeros(256 + 1, np.uint8)
+        phase("transport ids")
         if rank == 0:
-            log(f"[bench] rank 0: creating the RCCL unique ids for {world} ranks")
-            if H.lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), 256) != 0:
+            log(f"[bench] rank 0: creating the RCCL unique ids for {world} ranks" if os.environ.get("HPRLP_DIST_TRANSPORT") != "shm" else
+                f"[bench] rank 0: naming the shared-memory segment for {world} ranks")
+            if H.lib().hprlp_dist_unique_id(uid.ctypes.data_as(C.c_void_p), id_bytes) != 0:
                 log(f"[bench] rank 0: FAILED at communicator creation (unique id): {H.last_error()}")
                 uid[256] = 1
         tu = torch.from_numpy(uid)
         dist.broadcast(tu, src=0)
         if uid[256]:
             raise SystemExit(3)  # every rank leaves: no line is better than a line for fewer GPUs
-        log(f"[bench] rank {rank}: creating its RCCL communicators (rank {rank} of {world}, device {local_rank})")
+        phase(f"communicators and device set-up (rank {rank} of {world}, device {local_rank}, {id_bytes // 128} id(s))")
         try:
-            s = H.Solver.create_dist_from_shard(shard, prm, rank, world, uid[:256])
+            s = H.Solver.create_dist_from_shard(shard, prm, rank, world, uid[:id_bytes])
         except Exception as e:  # noqa: BLE001
             log(f"[bench] rank {rank}: FAILED at communicator / solver creation: {e}")
             raise SystemExit(3)
@@ -631,9 +810,13 @@ def main():
         comm_report = {"rccl_ranks": int(min(int(t[0]) for t in allc)),
                        "rccl_ranks_exchange_comm": int(min(int(t[2]) for t in allc)),
                        "devices": [int(t[1]) for t in allc], "hip_devices": [int(t[3]) for t in allc],
-                       "overlap": bool(cinfo["overlap"])}
-        if comm_report["rccl_ranks"] != world or len(set(comm_report["devices"])) != world:
-            log(f"[bench] rank {rank}: RCCL reports {comm_report}: not {world} ranks on {world} distinct devices")
+                       "overlap": bool(cinfo["overlap"]),
+                       "transport": "shared memory (host-staged)" if os.environ.get("HPRLP_DIST_TRANSPORT") == "shm" else "rccl"}
+        one_device = bool(os.environ.get("HPRLP_BENCH_ONE_DEVICE"))
+        if one_device:
+            comm_report["rehearsal"] = f"all {world} ranks on device 0 of a one-GPU box: NOT a {world}-GPU measurement"
+        if comm_report["rccl_ranks"] != world or (len(set(comm_report["devices"])) != world and not one_device):
+            log(f"[bench] rank {rank}: the transport reports {comm_report}: not {world} ranks on {world} distinct devices")
             raise SystemExit(3)
         del shard
     else:
@@ -652,7 +835,9 @@ def main():
         if args.no_solve:
             model.free()
             model = None
+    phase("scaling")
     s.scale()
+    phase("power iteration")
     lam, pw_it = s.power_iteration()
     s.init(-1.0, lam * 1.01)
     sc = s.scalars()
@@ -664,9 +849,11 @@ def main():
             f"power iteration {sc['power_time']:.2f}s / {pw_it} its, lambda_max={lam:.4g})")
 
     # ---- timed region: warmup W, then exactly K iterations between barrier+synchronize pairs
+    phase(f"warm-up, {args.warmup} iterations")
     s.iterate(args.warmup)
     if dist:
         dist.barrier()
+    phase(f"timed region, {args.steps} iterations")
     torch.cuda.set_device(local_rank)  # (for torch.cuda.synchronize below; the library selects its device itself)
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -757,6 +944,7 @@ def main():
         # would need a second set of communicators).  Wall of the loop = max over ranks; scaling and the power iteration were
         # timed when this solver was prepared above.  Every rank takes part (the loop's reductions are collectives).
         ttt = None
+        phase("solve to 1e-4 on the same ranks")
         try:
             s.reset()
             s.init(-1.0, lam * 1.01)
@@ -790,10 +978,12 @@ def main():
                 r = model.solve(H.Parameters(stop_tol=1e-4, use_presolve=False, time_limit=600.0))
                 wall = time.time() - t1
                 ph = H.last_solve_phases()
-                # `seconds` = the C call solve() from entry to return, timed inside the library (what a C / C++ caller of the
-                # reference's ABI waits for); the Python wrapper around it then copies the three 80 MB solution vectors into
-                # numpy arrays and frees the C ones, which is the harness's doing: reported beside it
-                out["time_to_tol"] = {"tol": 1e-4, "seconds": ph["whole_call"], "python_wrapper_seconds": wall, "solver_seconds": r.time, "iterations": r.iter,
+                # `seconds` = the harness's own clock around the C call solve() (hprlp.py: Model.solve, perf_counter before and
+                # after the ctypes call: what a caller of the reference's ABI waits for); `c_call_seconds` = the library's own
+                # figure for the same call (hprlp_last_solve_phases: whole_call; rounds 4's `seconds`), `python_wrapper_seconds`
+                # adds the harness's wrapping of the three 80 MB solution vectors into numpy arrays
+                out["time_to_tol"] = {"tol": 1e-4, "seconds": r.c_call_wall_s, "c_call_seconds": ph["whole_call"], "python_wrapper_seconds": wall,
+                                      "solver_seconds": r.time, "iterations": r.iter,
                                       # the reference's own instrument (HPRLP_results.time4 / iter4, include/structs.h:50-57)
                                       "time4_s": r.time4, "iter4": r.iter4,
                                       "reference_style_iterations_per_s": r.iter / max(r.time, 1e-9),
@@ -805,7 +995,7 @@ def main():
             model.free()
         if not args.no_side:  # before the CPU leg: its OpenMP team keeps spinning for a while and disturbs the
             try:              # latency-bound small solves
-                out["other_configs"] = side_configs()
+                out["other_configs"] = side_configs(cold_start=not args.no_cold_start)
             except Exception as e:
                 out["other_configs"] = {"error": str(e)}
         if not args.no_ladder and not args.no_side:
@@ -813,6 +1003,8 @@ def main():
                 out["ladder"] = ladder()
             except Exception as e:  # noqa: BLE001
                 out["ladder"] = {"error": str(e)}
+            if args.workload == "c5":
+                out["predicted_scaling"] = predicted_scaling(out["ms_per_step"], out["ladder"])
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload)

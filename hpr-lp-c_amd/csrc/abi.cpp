@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <iomanip>
 #include <iostream>
 
@@ -78,7 +79,10 @@ extern "C" int hprlp_warmup(int device) {
         set_last_error("hprlp_warmup: no usable GPU");
         return -1;
     }
-    if (device < 0 || device >= count) device = 0;
+    if (device < 0 || device >= count) {
+        set_last_error("hprlp_warmup: device " + std::to_string(device) + " is outside [0, " + std::to_string(count) + ")");
+        return -1;
+    }
     const auto t1 = time_now();
     hipStream_t s = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess || hipStreamCreate(&s) != hipSuccess) {
@@ -89,6 +93,7 @@ extern "C" int hprlp_warmup(int device) {
     (void)hipStreamDestroy(s);
     const auto t2 = time_now();
     // one attribute query per translation unit loads that unit's code object (deferred loading: otherwise at its first launch)
+    int rc = 0;
     try {
         warm_kernels_tu();
         warm_small_tu();
@@ -96,7 +101,12 @@ extern "C" int hprlp_warmup(int device) {
         warm_transpose_tu();
         warm_tiled_build_tu();
         warm_reorder_tu();
+    } catch (const std::exception &e) {
+        set_last_error(std::string("hprlp_warmup: a code object did not load: ") + e.what());
+        rc = -2;
     } catch (...) {
+        set_last_error("hprlp_warmup: a code object did not load");
+        rc = -2;
     }
     (void)hipGetLastError();
     const auto t3 = time_now();
@@ -107,7 +117,7 @@ extern "C" int hprlp_warmup(int device) {
     if (std::getenv("HPRLP_TIMING"))
         std::cerr << "[timing] warm-up: runtime start-up " << g_warm_seconds[0] << " s, device context + first stream " << g_warm_seconds[1]
                   << " s, code objects " << g_warm_seconds[2] << " s" << std::endl;
-    return 0;
+    return rc;
 }
 
 extern "C" int hprlp_warmup_seconds(double out[4]) {
@@ -440,6 +450,18 @@ static void make_exchange_comm(hprlp_solver *h, int rank, int size, const void *
     h->s.xcomm = h->xcomm;
 }
 
+// The transport a (rank, size, id) names: a shared-memory group of processes (id made under HPRLP_DIST_TRANSPORT=shm; staging
+// room = one full-length vector per rank) or RCCL communicators (one, or two when the launcher handed over two ids).
+static void make_transport(hprlp_solver *h, int m, int n, int rank, int size, const void *unique_id, int id_bytes, int device) {
+    if (is_shm_unique_id(unique_id, static_cast<size_t>(id_bytes))) {
+        const size_t area = (static_cast<size_t>(std::max(m, n)) + 64u * static_cast<size_t>(size)) * sizeof(double) + 4096u * static_cast<size_t>(size + 1);
+        h->comm = make_shm_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), area, device);
+        return;
+    }
+    h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), device);
+    make_exchange_comm(h, rank, size, unique_id, id_bytes, device);
+}
+
 static void destroy_handle(hprlp_solver *h) {
     if (!h) return;
     Comm *c = h->comm, *x = h->xcomm;
@@ -469,8 +491,7 @@ static hprlp_solver *create_sharded(const LP_info_cpu *model, const HPRLP_parame
             h->comm = make_local_comm(group->g, rank);
         } else if (size > 1 || (unique_id && id_bytes >= 128)) {
             // a unique id given with size 1 builds a one-rank RCCL communicator (exercises the collective path)
-            h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
-            make_exchange_comm(h, rank, size, unique_id, id_bytes, p->device_number);
+            make_transport(h, sh.m, sh.n, rank, size, unique_id, id_bytes, p->device_number);
         }
         h->s.setup_shard(sh.m, sh.n, sh.row_off, sh.m_loc, sh.col_off, sh.n_loc, sh.A_rowptr, sh.A_col, sh.A_val,
                          sh.AT_rowptr, sh.AT_col, sh.AT_val, sh.AL, sh.AU, sh.l, sh.u, sh.c, sh.obj_constant, p, h->comm);
@@ -506,8 +527,7 @@ static hprlp_solver *create_from_shard(const hprlp_shard *sh, const HPRLP_parame
         HIP_CHECK(hipSetDevice(p->device_number));
         if (group) h->comm = make_local_comm(group->g, rank);
         else if (size > 1 || (unique_id && id_bytes >= 128)) {
-            h->comm = make_rccl_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), p->device_number);
-            make_exchange_comm(h, rank, size, unique_id, id_bytes, p->device_number);
+            make_transport(h, sh->m, sh->n, rank, size, unique_id, id_bytes, p->device_number);
         }
         h->s.setup_shard(sh->m, sh->n, sh->row_off, sh->m_loc, sh->col_off, sh->n_loc, sh->A_rowptr, sh->A_col, sh->A_val, sh->AT_rowptr,
                          sh->AT_col, sh->AT_val, sh->AL, sh->AU, sh->l, sh->u, sh->c, sh->obj_constant, p, h->comm);
@@ -540,6 +560,51 @@ extern "C" hprlp_solver *hprlp_solver_create_local(const LP_info_cpu *model, con
         return nullptr;
     }
     return create_sharded(model, param, rank, size, nullptr, 0, group);
+}
+
+// The shared-memory transport's protocol on HOST buffers (no GPU, no HIP call): rank `rank` of `size` attaches to the group the
+// id names and runs `rounds` rounds of all-gather, scalar all-reduce and a neighbour exchange whose payloads every receiver
+// checks.  hang_rank >= 0: that rank leaves before round `rounds / 2` without a word (the others must end with an error once
+// HPRLP_DIST_TIMEOUT_S has passed, not wait for ever).  Returns 0, or -1 + hprlp_last_error().
+extern "C" int hprlp_shm_transport_selftest(const void *unique_id, int id_bytes, int rank, int size, int rounds, int hang_rank) {
+    try {
+        const int chunk = 1000 + 7;
+        std::unique_ptr<Comm> c(make_shm_comm(rank, size, unique_id, static_cast<size_t>(id_bytes), sizeof(double) * chunk * static_cast<size_t>(size), -1));
+        std::vector<double> g(static_cast<size_t>(chunk) * size), sc(3);
+        std::vector<std::vector<double>> snd(size), rcv(size);
+        for (int it = 0; it < rounds; ++it) {
+            if (rank == hang_rank && it == rounds / 2) return 0;
+            std::fill(g.begin(), g.end(), -1.0);
+            for (int j = 0; j < chunk; ++j) g[static_cast<size_t>(rank) * chunk + j] = 1e6 * it + 1e3 * rank + j;
+            c->allgather_inplace(g.data(), chunk, nullptr);
+            for (int p = 0; p < size; ++p)
+                for (int j = 0; j < chunk; ++j)
+                    if (g[static_cast<size_t>(p) * chunk + j] != 1e6 * it + 1e3 * p + j) throw std::runtime_error("all-gather delivered a wrong entry");
+            sc[0] = rank + 1.0; sc[1] = it; sc[2] = 0.1 * (rank + 1);
+            c->allreduce_sum(sc.data(), 3, nullptr);
+            double want2 = 0.0;
+            for (int p = 0; p < size; ++p) want2 += 0.1 * (p + 1);
+            if (sc[0] != size * (size + 1) / 2.0 || sc[1] != static_cast<double>(it) * size || sc[2] != want2) throw std::runtime_error("all-reduce gave a wrong sum");
+            // rank a sends (a + 2 b + it) % 5 + (b > a) doubles to rank b: ragged, some empty
+            std::vector<P2P> ops;
+            for (int p = 0; p < size; ++p) {
+                if (p == rank) continue;
+                const size_t ns = static_cast<size_t>((rank + 2 * p + it) % 5 + (p > rank)), nr = static_cast<size_t>((p + 2 * rank + it) % 5 + (rank > p));
+                snd[p].assign(ns, 0.0);
+                for (size_t j = 0; j < ns; ++j) snd[p][j] = 100.0 * rank + p + 0.001 * static_cast<double>(j) + it;
+                rcv[p].assign(nr, -7.0);
+                if (ns || nr) ops.push_back(P2P{p, snd[p].data(), ns * sizeof(double), rcv[p].data(), nr * sizeof(double)});
+            }
+            c->exchange(ops.data(), static_cast<int>(ops.size()), nullptr);
+            for (int p = 0; p < size; ++p)
+                for (size_t j = 0; p != rank && j < rcv[p].size(); ++j)
+                    if (rcv[p][j] != 100.0 * p + rank + 0.001 * static_cast<double>(j) + it) throw std::runtime_error("exchange delivered a wrong entry");
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return -1;
+    }
 }
 
 // out = {halo_m sparse?, entries sent, entries received, halo_n sparse?, sent, received, requests m, requests n}
@@ -790,6 +855,19 @@ extern "C" int hprlp_locality_ordering(int m, int n, const int *rowptr, const in
             out[0] = ok ? 1.0 : 0.0; out[1] = st.fraction_before; out[2] = st.fraction_after;
             out[3] = st.clusters; out[4] = st.components; out[5] = st.seconds;
         }
+        return 0;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return -1;
+    }
+}
+
+// Host only: the stream kernel's row blocks of a CSR pattern (split rows, chunks by column eighths), built and checked as a
+// solver's set-up does.  out = {blocks, split rows, chunk slots, rows cut by column eighths, longest chunk, entries covered}.
+extern "C" int hprlp_row_block_plan(int m, int n, const int *rowptr, const int *col, int with_cuts, long out[6]) {
+    try {
+        if (m <= 0 || n <= 0 || !rowptr || !col || !out) throw std::runtime_error("bad arguments");
+        row_block_plan_host(m, n, rowptr, col, with_cuts != 0, out);
         return 0;
     } catch (const std::exception &e) {
         set_last_error(e.what());

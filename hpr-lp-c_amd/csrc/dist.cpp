@@ -10,11 +10,19 @@
 #include "dist.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
+#include <thread>
 #include <cstring>
 #include <iostream>
 #include <mutex>
@@ -223,6 +231,225 @@ Comm *make_local_comm(LocalGroup *g, int rank) {
     return c;
 }
 
+// ------------------------------------------------------------------------------------------------
+// host-staged group of PROCESSES on one node (see dist.h): a POSIX shared-memory segment carries a barrier, a table of posted
+// sends and one staging area per rank; data moves device -> own area -> peer's device.  No RCCL, no device IPC handle.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr char kShmMagic[8] = {'H', 'P', 'R', 'L', 'P', 'S', 'H', 'M'};
+constexpr int kShmMaxRanks = 64;
+
+struct ShmPost {  // a send posted by rank a for rank b: where it lies in a's area
+    long off, bytes;
+};
+
+struct ShmHeader {
+    std::atomic<int> attached;   // ranks that mapped the segment
+    std::atomic<int> arrived;    // barrier: arrivals of the current generation
+    std::atomic<long> generation;
+    std::atomic<int> broken;     // a rank failed or timed out: everybody leaves with an error
+    int size;
+    long area_bytes;
+    double reduce[kShmMaxRanks][32];
+    ShmPost post[kShmMaxRanks][kShmMaxRanks];  // [sender][receiver]
+};
+
+double shm_timeout_s() {
+    const char *e = std::getenv("HPRLP_DIST_TIMEOUT_S");
+    const double v = e ? std::atof(e) : 120.0;
+    return v > 0.0 ? v : 120.0;
+}
+
+struct ShmComm : Comm {
+    std::string name;
+    ShmHeader *hd = nullptr;
+    char *base = nullptr;   // start of the staging areas
+    size_t map_bytes = 0;
+    bool host_buffers = false;  // the protocol's own test: "device" pointers are host memory (no HIP call at all)
+    bool registered = false;
+    bool owner = false;
+    int device = -1;
+    bool host_blocking() const override { return true; }
+    int reported_device() const override { return device; }
+
+    ~ShmComm() override {
+        if (registered) (void)hipHostUnregister(hd);
+        if (hd) munmap(hd, map_bytes);
+        if (owner) shm_unlink(name.c_str());
+    }
+    char *area(int r) const { return base + static_cast<size_t>(r) * static_cast<size_t>(hd->area_bytes); }
+    [[noreturn]] void fail(const std::string &what) {
+        hd->broken.store(1);
+        throw std::runtime_error("shared-memory group: " + what);
+    }
+    void barrier() {
+        if (hd->broken.load()) throw std::runtime_error("shared-memory group: another rank failed");
+        const long gen = hd->generation.load();
+        if (hd->arrived.fetch_add(1) + 1 == size) {
+            hd->arrived.store(0);
+            hd->generation.fetch_add(1);
+            return;
+        }
+        const auto t0 = time_now();
+        const double limit = shm_timeout_s();
+        for (long spin = 0; hd->generation.load() == gen; ++spin) {
+            if (hd->broken.load()) throw std::runtime_error("shared-memory group: another rank failed");
+            if (spin > 2000) {  // (the first microseconds by spinning: an exchange per half-step is the iteration's latency)
+                std::this_thread::sleep_for(std::chrono::microseconds(spin > 20000 ? 200 : 5));
+                if ((spin & 1023) == 0 && time_since(t0) > limit) fail("barrier timed out (a rank is missing)");
+            }
+        }
+    }
+    void to_host(void *dst, const void *src, size_t bytes, hipStream_t s) {
+        if (!bytes) return;
+        if (host_buffers) std::memcpy(dst, src, bytes);
+        else HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    }
+    void to_device(void *dst, const void *src, size_t bytes, hipStream_t s) {
+        if (!bytes) return;
+        if (host_buffers) std::memcpy(dst, src, bytes);
+        else HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    }
+    void sync(hipStream_t s) {
+        if (!host_buffers) HIP_CHECK(hipStreamSynchronize(s));
+    }
+    void allgather_inplace(double *buf, size_t chunk, hipStream_t s) override {
+        const size_t bytes = chunk * sizeof(double);
+        if (bytes > static_cast<size_t>(hd->area_bytes)) fail("all-gather chunk exceeds the staging area");
+        to_host(area(rank), buf + static_cast<size_t>(rank) * chunk, bytes, s);
+        sync(s);
+        barrier();
+        for (int p = 0; p < size; ++p)
+            if (p != rank) to_device(buf + static_cast<size_t>(p) * chunk, area(p), bytes, s);
+        sync(s);
+        barrier();  // nobody overwrites its area before every peer has read it
+    }
+    void allreduce_sum(double *buf, int count, hipStream_t s) override {
+        if (count > 32) fail("all-reduce of more than 32 scalars");
+        double mine[32];
+        to_host(mine, buf, sizeof(double) * static_cast<size_t>(count), s);
+        sync(s);
+        for (int i = 0; i < count; ++i) hd->reduce[rank][i] = mine[i];
+        barrier();
+        double sum[32];
+        for (int i = 0; i < count; ++i) sum[i] = 0.0;
+        for (int p = 0; p < size; ++p)  // rank order: every rank gets the same bits
+            for (int i = 0; i < count; ++i) sum[i] += hd->reduce[p][i];
+        barrier();
+        to_device(buf, sum, sizeof(double) * static_cast<size_t>(count), s);
+        sync(s);
+    }
+    void exchange(const P2P *ops, int nops, hipStream_t s) override {
+        for (int p = 0; p < size; ++p) hd->post[rank][p] = ShmPost{0, 0};
+        size_t off = 0;
+        for (int i = 0; i < nops; ++i) {
+            const P2P &o = ops[i];
+            if (o.peer < 0 || o.peer >= size || o.peer == rank) fail("bad peer in an exchange");
+            if (!o.send_bytes) continue;
+            if (off + o.send_bytes > static_cast<size_t>(hd->area_bytes)) fail("sends exceed the staging area");
+            to_host(area(rank) + off, o.send, o.send_bytes, s);
+            hd->post[rank][o.peer] = ShmPost{static_cast<long>(off), static_cast<long>(o.send_bytes)};
+            off += (o.send_bytes + 63) & ~static_cast<size_t>(63);
+        }
+        sync(s);
+        barrier();
+        for (int i = 0; i < nops; ++i) {
+            const P2P &o = ops[i];
+            if (!o.recv_bytes) continue;
+            const ShmPost &q = hd->post[o.peer][rank];
+            if (static_cast<size_t>(q.bytes) != o.recv_bytes) fail("unmatched receive");
+            to_device(o.recv, area(o.peer) + q.off, o.recv_bytes, s);
+        }
+        sync(s);
+        barrier();
+    }
+};
+
+}  // namespace
+
+bool is_shm_unique_id(const void *unique_id, size_t id_bytes) {
+    return unique_id && id_bytes >= 128 && std::memcmp(unique_id, kShmMagic, sizeof(kShmMagic)) == 0;
+}
+
+// A fresh segment name in the 128-byte id: magic, then "/hprlp-<pid>-<clock>".
+void shm_make_unique_id(void *out, size_t bytes) {
+    if (bytes < 128) throw std::runtime_error("unique-id buffer too small");
+    std::memset(out, 0, bytes);
+    std::memcpy(out, kShmMagic, sizeof(kShmMagic));
+    const long long t = std::chrono::duration_cast<std::chrono::nanoseconds>(clock_type::now().time_since_epoch()).count();
+    std::snprintf(static_cast<char *>(out) + sizeof(kShmMagic), 100, "/hprlp-%ld-%llx", static_cast<long>(getpid()), static_cast<unsigned long long>(t));
+}
+
+// Rank 0 creates the segment, the others wait for it; area_bytes: staging room per rank (pages are touched only where used).
+// device < 0: the buffers handed to the collectives are HOST memory (the transport's own test, no HIP call).
+Comm *make_shm_comm(int rank, int size, const void *unique_id, size_t id_bytes, size_t area_bytes, int device) {
+    if (!is_shm_unique_id(unique_id, id_bytes)) throw std::runtime_error("not a shared-memory group id");
+    if (size < 1 || size > kShmMaxRanks || rank < 0 || rank >= size) throw std::runtime_error("shared-memory group: bad rank / size");
+    char nm[101];
+    std::memcpy(nm, static_cast<const char *>(unique_id) + sizeof(kShmMagic), 100);
+    nm[100] = 0;
+    area_bytes = (area_bytes + 4095) & ~static_cast<size_t>(4095);
+    const size_t head = (sizeof(ShmHeader) + 4095) & ~static_cast<size_t>(4095);
+    const size_t total = head + area_bytes * static_cast<size_t>(size);
+    auto c = std::unique_ptr<ShmComm>(new ShmComm());
+    c->rank = rank;
+    c->size = size;
+    c->name = nm;
+    c->host_buffers = device < 0;
+    c->device = device;
+    int fd = -1;
+    const auto t0 = time_now();
+    if (rank == 0) {
+        fd = shm_open(nm, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) throw std::runtime_error(std::string("shm_open(create) failed: ") + std::strerror(errno));
+        c->owner = true;
+        if (ftruncate(fd, static_cast<off_t>(total)) != 0) {
+            close(fd);
+            throw std::runtime_error(std::string("ftruncate of the shared segment failed: ") + std::strerror(errno));
+        }
+    } else {
+        for (;;) {  // until rank 0 has created and sized it
+            fd = shm_open(nm, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) >= total) break;
+                close(fd);
+                fd = -1;
+            }
+            if (time_since(t0) > shm_timeout_s()) throw std::runtime_error("shared-memory group: rank 0's segment did not appear");
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    void *mp = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mp == MAP_FAILED) throw std::runtime_error(std::string("mmap of the shared segment failed: ") + std::strerror(errno));
+    c->hd = static_cast<ShmHeader *>(mp);
+    c->map_bytes = total;
+    c->base = static_cast<char *>(mp) + head;
+    if (rank == 0) {  // (a fresh segment is zero-filled: counters start at 0)
+        c->hd->area_bytes = static_cast<long>(area_bytes);
+        c->hd->size = size;
+    }
+    c->hd->attached.fetch_add(1);
+    while (c->hd->attached.load() < size || c->hd->size != size) {  // everybody has it mapped (rank 0 may unlink the name at exit)
+        if (c->hd->broken.load()) throw std::runtime_error("shared-memory group: another rank failed");
+        if (time_since(t0) > shm_timeout_s()) {
+            c->hd->broken.store(1);
+            throw std::runtime_error("shared-memory group: not every rank attached");
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (static_cast<size_t>(c->hd->area_bytes) != area_bytes) throw std::runtime_error("shared-memory group: ranks disagree on the staging size");
+    if (!c->host_buffers) {
+        HIP_CHECK(hipSetDevice(device));
+        // pinned staging: the copies run as DMA at link rate; a refusal only makes them slower
+        if (hipHostRegister(mp, total, hipHostRegisterDefault) == hipSuccess) c->registered = true;
+        else (void)hipGetLastError();
+    }
+    return c.release();
+}
+
 // One id per 128 bytes of the buffer, at most two: the second one is for the exchange stream's own communicator
 // (Solver::xcomm) -- no communicator is driven from two streams.
 void rccl_get_unique_id(void *out, size_t bytes) {
@@ -330,6 +557,13 @@ extern "C" int hprlp_extract_shard(const LP_info_cpu *model, int rank, int size,
 
 extern "C" int hprlp_dist_unique_id(void *out, int bytes) {
     try {
+        // HPRLP_DIST_TRANSPORT=shm: the id names a shared-memory segment (host-staged group of processes on one node, no RCCL)
+        const char *tr = std::getenv("HPRLP_DIST_TRANSPORT");
+        if (tr && std::strcmp(tr, "shm") == 0) {
+            if (!out) throw std::runtime_error("null id buffer");
+            shm_make_unique_id(out, static_cast<size_t>(bytes));
+            return 0;
+        }
         rccl_get_unique_id(out, static_cast<size_t>(bytes));
         return 0;
     } catch (const std::exception &e) {

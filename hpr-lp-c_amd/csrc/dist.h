@@ -44,6 +44,15 @@ struct Comm {
 Comm *make_rccl_comm(int rank, int size, const void *unique_id, size_t id_bytes, int device);
 void rccl_get_unique_id(void *out, size_t bytes);
 
+// Host-staged group of PROCESSES on one node: a POSIX shared-memory segment named by the 128-byte id (hprlp_dist_unique_id
+// under HPRLP_DIST_TRANSPORT=shm) carries a barrier, a table of posted sends and one pinned staging area per rank; a slice
+// travels device -> own area -> the reader's device.  Needs neither RCCL nor a device IPC handle: the transport of last
+// resort of bench.py's staged fallback, and the one multi-PROCESS form a one-GPU box can run (every rank on device 0).
+// device < 0: the collectives' buffers are host memory (the protocol's own test on a box without a GPU).
+bool is_shm_unique_id(const void *unique_id, size_t id_bytes);
+void shm_make_unique_id(void *out, size_t bytes);
+Comm *make_shm_comm(int rank, int size, const void *unique_id, size_t id_bytes, size_t area_bytes, int device);
+
 // In-process implementation: `size` solver instances driven by `size` host threads of ONE process
 // (all on the same GPU) exchange through device-to-device copies and host barriers.  It exists so
 // that the multi-rank solver path (shards, halo plans, reductions) can be run for real on a one-GPU

@@ -3,6 +3,7 @@
 // Every row is a pure function of (seed, row), so any rank can produce any row range on its own.
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
@@ -156,14 +157,23 @@ extern "C" int hprlp_gen_banded_csr_transposed(int m, int n, int per_row, int ba
         std::vector<Kept> kept(static_cast<size_t>(nchunks));
         std::atomic<int> next_chunk{0};
         {
+            // (an exception inside a raw thread would end the process: each thread keeps its own and the first one is rethrown here)
             std::vector<std::thread> th;
+            std::vector<std::exception_ptr> failed(static_cast<size_t>(nthreads));
             for (int t = 0; t < nthreads; ++t)
-                th.emplace_back([&]() {
-                    for (int q = next_chunk.fetch_add(1); q < nchunks; q = next_chunk.fetch_add(1))
-                        gen_rows_keep_columns(m, n, per_row, band, static_cast<uint64_t>(seed), q * chunk, std::min(m, (q + 1) * chunk), col_off,
-                                              col_off + n_loc, &kept[q]);
+                th.emplace_back([&, t]() {
+                    try {
+                        for (int q = next_chunk.fetch_add(1); q < nchunks; q = next_chunk.fetch_add(1))
+                            gen_rows_keep_columns(m, n, per_row, band, static_cast<uint64_t>(seed), q * chunk, std::min(m, (q + 1) * chunk),
+                                                  col_off, col_off + n_loc, &kept[q]);
+                    } catch (...) {
+                        failed[t] = std::current_exception();
+                        next_chunk.store(nchunks);  // the others stop at their next claim
+                    }
                 });
             for (auto &t : th) t.join();
+            for (const std::exception_ptr &e : failed)
+                if (e) std::rethrow_exception(e);
         }
         long total = 0;
         for (const Kept &k : kept) total += static_cast<long>(k.lc.size());

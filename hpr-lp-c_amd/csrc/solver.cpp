@@ -176,7 +176,9 @@ static RowCuts slab_cuts(int rows, int cols, const int *rp, ColsOf cols_of) {
                 sh.push_back(slab);
             }
         }
-        if (st.size() > 1 && len - st.back() < kSlabChunkMin) {  // a short tail joins its predecessor
+        // a short tail joins its predecessor -- unless the joined chunk would pass the split-row limit (a 4100-entry row in one
+        // eighth: [0,4096) + [4096,4100) stays two chunks)
+        if (st.size() > 1 && len - st.back() < kSlabChunkMin && len - st[st.size() - 2] <= kSplitRow) {
             st.pop_back();
             sh.pop_back();
         }
@@ -185,6 +187,48 @@ static RowCuts slab_cuts(int rows, int cols, const int *rp, ColsOf cols_of) {
         rc.share.push_back(std::move(sh));
     }
     return rc;
+}
+
+// The kernels trust the block list: every chunk slot exactly once, chunk and block sizes within what a wave handles.
+// Returns the number of chunk slots.
+static int check_row_blocks(const std::vector<int4> &b) {
+    int nslots = 0;
+    std::vector<char> seen;
+    for (const int4 &d : b) {
+        const bool vec = d.y == 0 || (d.y == 1 && d.w > kLongRow);
+        if (d.y == 0) {
+            // (chunk slots: each exactly once -- the arrangement by XCD shares moves chunks, k_long_finish adds a row's slots in order)
+            if (d.w < 1 || d.w > kSplitRow || d.x < 0) throw std::runtime_error("bad split-row block");
+            if (static_cast<size_t>(d.x) >= seen.size()) seen.resize(static_cast<size_t>(d.x) + 1, 0);
+            if (seen[d.x]++) throw std::runtime_error("bad split-row block: slot used twice");
+            ++nslots;
+        } else if (!vec && (d.w > kStreamW || d.y > kStreamRows || d.y < 1)) {
+            throw std::runtime_error("bad row block");
+        }
+    }
+    if (static_cast<size_t>(nslots) != seen.size()) throw std::runtime_error("bad split-row blocks: slots not contiguous");
+    return nslots;
+}
+
+// Host only (no device call): the stream kernel's block list of a CSR pattern as describe_when() would build it, checked.
+// out: {blocks, split rows, chunk slots, rows cut by column eighths, longest chunk, entries covered}.
+void row_block_plan_host(int rows, int cols, const int *rp, const int *ci, bool with_cuts, long out[6]) {
+    RowCuts cuts;
+    if (with_cuts) cuts = slab_cuts(rows, cols, rp, [&](int r, int *o) { std::memcpy(o, ci + rp[r], static_cast<size_t>(rp[r + 1] - rp[r]) * sizeof(int)); });
+    std::vector<int4> lr;
+    const std::vector<int4> b = build_row_blocks_cut(rows, rp, &lr, cuts.rows.empty() ? nullptr : &cuts);
+    const int nslots = check_row_blocks(b);
+    long longest = 0, covered = 0;
+    for (const int4 &d : b) {
+        if (d.y == 0) longest = std::max<long>(longest, d.w);
+        covered += d.w;
+    }
+    out[0] = static_cast<long>(b.size());
+    out[1] = static_cast<long>(lr.size());
+    out[2] = nslots;
+    out[3] = static_cast<long>(cuts.rows.size());
+    out[4] = longest;
+    out[5] = covered;
 }
 
 static int workgroup_slots() {
@@ -349,21 +393,7 @@ void DeviceMatrix::describe_when(int rows, int cols, long nnz_l, std::shared_fut
     }
     Blocks B = blocks_job.get();
     std::vector<int4> &b = B.b, &lr = B.lr;
-    int nslots = 0;
-    std::vector<char> seen;
-    for (const int4 &d : b) {
-        const bool vec = d.y == 0 || (d.y == 1 && d.w > kLongRow);
-        if (d.y == 0) {
-            // (chunk slots: each exactly once -- the arrangement by XCD shares moves chunks, k_long_finish adds a row's slots in order)
-            if (d.w < 1 || d.w > kSplitRow || d.x < 0) throw std::runtime_error("bad split-row block");
-            if (static_cast<size_t>(d.x) >= seen.size()) seen.resize(static_cast<size_t>(d.x) + 1, 0);
-            if (seen[d.x]++) throw std::runtime_error("bad split-row block: slot used twice");
-            ++nslots;
-        } else if (!vec && (d.w > kStreamW || d.y > kStreamRows || d.y < 1)) {
-            throw std::runtime_error("bad row block");
-        }
-    }
-    if (static_cast<size_t>(nslots) != seen.size()) throw std::runtime_error("bad split-row blocks: slots not contiguous");
+    const int nslots = check_row_blocks(b);
     blk.alloc(b.size());
     blk.upload(b.data(), b.size());
     pt.tick("  row blocks");

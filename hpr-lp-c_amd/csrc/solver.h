@@ -74,6 +74,8 @@ struct DeviceMatrix {
 };
 
 std::vector<int4> build_row_blocks(int rows, const int *rowptr, std::vector<int4> *longrows);
+// host only: the stream kernel's block list of a pattern, built and checked as describe_when() does (solver.cpp)
+void row_block_plan_host(int rows, int cols, const int *rp, const int *ci, bool with_cuts, long out[6]);
 
 // How one kind of gathered vector (length-m: read through the columns of the A^T shard; length-n:
 // through the columns of the A shard) reaches this rank after a half-step.  Dense coupling: one

@@ -8,6 +8,7 @@ for solves, a GPU) is missing.
 """
 import ctypes as C
 import os
+import time
 import weakref
 
 import numpy as np
@@ -261,8 +262,13 @@ class Model:
 
     def solve(self, param=None):
         cp = (param or Parameters()).to_c()
-        res = lib().solve(self._ptr, C.byref(cp))
-        return Results(res, self.m, self.n)
+        L = lib()
+        t0 = time.perf_counter()
+        res = L.solve(self._ptr, C.byref(cp))
+        wall = time.perf_counter() - t0
+        r = Results(res, self.m, self.n)
+        r.c_call_wall_s = wall  # the caller's clock around the C call alone (before the solution vectors are wrapped)
+        return r
 
     def free(self):
         if self._ptr:

@@ -30,7 +30,8 @@ const char *hprlp_last_error(void);
 const char *hprlp_backend(void); /* "hip-gfx950" */
 /* Warm-up: start the HIP runtime, create the device context and a first stream and load the library's code objects NOW instead
  * of inside the first solve of the process (0.10 s there against a 0.04 s solve of a Netlib-scale LP, profiles/r04_cold_start.txt).
- * For callers that serve many solves: call once at start-up.  Returns 0, or -1 without a usable GPU.
+ * For callers that serve many solves: call once at start-up.  Returns 0; -1 without a usable GPU or for a device
+ * outside [0, device count); -2 when a code object did not load (hprlp_last_error() says which).
  * hprlp_warmup_seconds: {runtime start-up, device context + first stream, code objects, total} of the last call. */
 int hprlp_warmup(int device);
 int hprlp_warmup_seconds(double out[4]);
@@ -146,6 +147,13 @@ void hprlp_free_shard(hprlp_shard *s);
  * for the exchange stream (exchanges that overlap the local part of a half-step), so that no communicator is driven
  * from two streams; with one id the single communicator serves both. */
 int hprlp_dist_unique_id(void *out, int bytes);
+/* HPRLP_DIST_TRANSPORT=shm in the environment of hprlp_dist_unique_id's caller: the id names a POSIX shared-memory segment and
+ * hprlp_solver_create_dist* given that id build a host-staged group of processes on ONE node (device -> pinned shared area ->
+ * the reader's device; no RCCL, no device IPC handle): the transport of last resort, and the multi-process form a one-GPU box
+ * can run.  hprlp_shm_transport_selftest: the protocol alone on host buffers (no GPU): `rounds` rounds of all-gather, scalar
+ * all-reduce and a ragged neighbour exchange, every payload checked; hang_rank >= 0 leaves half-way without a word (the others
+ * must fail after HPRLP_DIST_TIMEOUT_S seconds, default 120).  0, or -1 + hprlp_last_error(). */
+int hprlp_shm_transport_selftest(const void *unique_id, int id_bytes, int rank, int size, int rounds, int hang_rank);
 /* every rank: create the solver for its shard of `model` (param->device_number selects the GPU).
  * get_vector/run then return this rank's slices; scalars/residuals are global. */
 hprlp_solver *hprlp_solver_create_dist(const LP_info_cpu *model, const HPRLP_parameters *param, int rank, int size,
@@ -206,6 +214,10 @@ int hprlp_original_kkt(const LP_info_cpu *model, const double *x, const double *
  * like the reference's collect_solution (src/utils.cu:143-200).  out = {accepted, tiled share before, after, clusters,
  * components, seconds}. */
 int hprlp_locality_ordering(int m, int n, const int *rowptr, const int *col, int *row_new2old, int *col_new2old, double out[6]);
+/* host only: the stream kernel's row blocks of a CSR pattern, built and checked as a solver's set-up does (dense rows cut by
+ * column eighths when with_cuts != 0); out = {blocks, split rows, chunk slots, rows cut, longest chunk, entries covered};
+ * -1 + hprlp_last_error() when the block list would be refused. */
+int hprlp_row_block_plan(int m, int n, const int *rowptr, const int *col, int with_cuts, long out[6]);
 
 #ifdef __cplusplus
 }

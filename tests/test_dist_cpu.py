@@ -136,3 +136,115 @@ def test_bench_refuses_a_world_that_does_not_match_gpus():
     assert r.returncode != 0
     assert r.stdout.decode().strip() == ""
     assert "--gpus 8 but WORLD_SIZE=1" in r.stderr.decode()
+
+
+SHM_WORKER = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, {tests!r})
+from conftest import hprlp
+L = hprlp.lib()
+rank, size, rounds, hang = (int(v) for v in sys.argv[1:5])
+uid = bytes.fromhex(sys.argv[5])
+rc = L.hprlp_shm_transport_selftest(uid, len(uid), rank, size, rounds, hang)
+print("rank", rank, "rc", rc, hprlp.last_error() if rc else "ok", flush=True)
+sys.exit(0 if rc == 0 else 7)
+"""
+
+
+def _shm_id():
+    import ctypes as C
+    sys.path.insert(0, HERE)
+    from conftest import hprlp
+    L = hprlp.lib()
+    buf = (C.c_ubyte * 128)()
+    os.environ["HPRLP_DIST_TRANSPORT"] = "shm"
+    try:
+        assert L.hprlp_dist_unique_id(buf, 128) == 0, hprlp.last_error()   # (no RCCL, no GPU needed for this kind of id)
+    finally:
+        os.environ.pop("HPRLP_DIST_TRANSPORT")
+    assert bytes(buf[:8]) == b"HPRLPSHM"
+    return bytes(buf)
+
+
+def _shm_ranks(size, rounds, hang, timeout_s="120"):
+    uid = _shm_id()
+    code = SHM_WORKER.format(tests=HERE)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(size), str(rounds), str(hang), uid.hex()],
+                              env=dict(os.environ, HPRLP_DIST_TIMEOUT_S=timeout_s), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(size)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=120)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    name = uid[8:108].split(b"\0")[0].decode()
+    return procs, outs, name
+
+
+@pytest.mark.parametrize("size", [2, 5])
+def test_shared_memory_transport_protocol_between_processes(size):
+    """csrc/dist.cpp ShmComm (round 5: the staged fallback's transport of last resort): `size` PROCESSES attach to one POSIX
+    shared-memory segment and run 40 rounds of all-gather, scalar all-reduce (rank-order sum: same bits everywhere) and a ragged
+    neighbour exchange on host buffers; every payload is checked by its receiver.  The segment's name is gone afterwards."""
+    procs, outs, name = _shm_ranks(size, 40, -1)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} rc 0 ok" in out, out[-2000:]
+    assert not os.path.exists("/dev/shm" + name)
+
+
+def test_shared_memory_transport_times_out_when_a_rank_goes_missing():
+    """A rank that leaves half-way (a crashed or hung peer) must not leave the others waiting for ever: after
+    HPRLP_DIST_TIMEOUT_S they end with an error that names the barrier, and the segment is marked broken for everybody."""
+    t0 = __import__("time").time()
+    procs, outs, name = _shm_ranks(3, 20, 1, timeout_s="2")
+    assert procs[1].returncode == 0
+    for r in (0, 2):
+        assert procs[r].returncode == 7 and ("timed out" in outs[r] or "another rank failed" in outs[r]), outs[r][-2000:]
+    assert any("timed out" in o for o in outs)
+    assert __import__("time").time() - t0 < 60
+    assert not os.path.exists("/dev/shm" + name)
+
+
+def test_bench_supervisor_ends_a_hung_tier_and_falls_back_in_fresh_processes():
+    """Round 5 (bench.py: supervise / run_tier): a rank that hangs (test hook: rank 1 of tier 0 sleeps for ever in its first
+    phase, so rank 0 waits for it in a collective -- the shape of a deadlocked exchange) must not cost the run its time limit:
+    after HPRLP_BENCH_STALL_S seconds of silence the parent terminates exactly the PIDs it started and starts the next
+    transport tier in FRESH processes (new PIDs, new rendezvous port, the tier's environment).  No GPU here, so every later
+    tier ends at communicator creation and the run ends non-zero without a line, saying how each tier ended."""
+    import re
+    r = _bench(["--gpus", "2", "--workload", "c5_tiny", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-side", "--no-solve"],
+               {"HPRLP_BENCH_STALL_S": "5", "HPRLP_BENCH_TEST_HANG": "0:1:shard"})
+    err = r.stderr.decode()
+    assert r.returncode != 0 and r.stdout.decode().strip() == "", err[-3000:]
+    assert "rank 1: TEST HOOK: hanging at phase 'shard assembly'" in err
+    assert "tier 0 ended: stalled: no line from any rank for 5s (exit codes [-15, -15])" in err, err[-3000:]
+    starts = re.findall(r"tier (\d): .*started ranks as child processes \[(\d+), (\d+)\] \(127.0.0.1:(\d+)\)", err)
+    assert [int(t[0]) for t in starts] == [0, 1, 2, 3], starts
+    pids = [p for t in starts for p in t[1:3]]
+    assert len(set(pids)) == 8 and len({t[3] for t in starts}) == 4     # fresh processes, fresh ports
+    assert "1 id(s)" in err and "2 id(s)" not in err.split("tier 1:")[1]   # the fallback tiers build ONE communicator
+    assert "naming the shared-memory segment for 2 ranks" in err.split("tier 3:")[1]
+    for t in (1, 2, 3):
+        assert re.search(rf"tier {t} ended: rank \d exited with code 3", err), err[-3000:]
+    tail = err.split("no result line: every transport tier failed")[1]
+    assert "tier 0" in tail and "stalled" in tail and tail.count("exited with code 3") == 3
+
+
+def test_bench_under_a_launcher_rank0_supervises_and_the_other_copies_wait():
+    """Under `python -m torch.distributed.run --nproc-per-node N` (how the driver starts N > 1) the N copies of bench.py make
+    no HIP call: copy 0 runs the tiers with fresh rank processes on their own port, the others wait for its verdict over gloo
+    and leave with the same exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HPRLP_BENCH_STALL_S="20", HPRLP_BENCH_FIRST_TIER="3")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c5_tiny",
+                        "--steps", "2", "--warmup", "1", "--no-cpu", "--no-side", "--no-solve"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    err = r.stderr.decode()
+    assert r.returncode != 0 and r.stdout.decode().strip() == "", err[-3000:]
+    assert err.count("started ranks as child processes") == 1            # one supervisor, not two
+    assert "tier 3: host-staged shared memory" in err and "rank 1: phase shard assembly" in err
+    assert "no result line: every transport tier failed" in err

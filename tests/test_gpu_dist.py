@@ -351,3 +351,56 @@ def test_solver_from_caller_built_shards(gpu):
     assert all(e is None for e in err), err
     check_against_single(ref, out, m, n, lp["obj_star"])
     model.free()
+
+
+def process_ranks(kind, world, steps, tmp_path):
+    """`world` ranks as separate PROCESSES on the one GPU over the shared-memory transport (HPRLP_DIST_TRANSPORT=shm)."""
+    import pickle
+    import subprocess
+    import sys
+    from types import SimpleNamespace
+    here = os.path.dirname(os.path.abspath(__file__))
+    os.environ["HPRLP_DIST_TRANSPORT"] = "shm"
+    try:
+        uid = hprlp.Solver.dist_unique_id(1)
+    finally:
+        os.environ.pop("HPRLP_DIST_TRANSPORT")
+    assert bytes(uid[:8]) == b"HPRLPSHM"
+    out = str(tmp_path / "ranks")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "dist_worker_shm_gpu.py"), str(r), str(world), str(steps), bytes(uid).hex(), kind, out],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=400)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, lg) in enumerate(zip(procs, logs)):
+        assert p.returncode == 0 and f"rank {r} ok" in lg, lg[-3000:]
+    ranks = []
+    for r in range(world):
+        rec = pickle.load(open(f"{out}.{r}.pkl", "rb"))
+        rec["run"] = SimpleNamespace(**rec["run"])
+        ranks.append(rec)
+    return ranks
+
+
+@pytest.mark.parametrize("kind,world,steps", [("unstructured", 3, 37), ("banded", 4, 23)])
+def test_process_ranks_over_shared_memory_equal_single_gpu(gpu, tmp_path, kind, world, steps):
+    """Round 5 (csrc/dist.cpp ShmComm): the sharded solver with one PROCESS per rank -- the shape of `bench.py --gpus N` -- on a
+    one-GPU box: every rank on device 0, slices travelling device -> pinned shared area -> the reader's device.  All-gather
+    plan (unstructured LP) and neighbour exchange (banded LP); iterates, residuals and the whole solve against the single-GPU
+    solver, as for the thread ranks."""
+    from dist_worker_shm_gpu import make_lp
+    lp = make_lp(kind)
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    prm = hprlp.Parameters(stop_tol=1e-6, use_presolve=False)
+    ref = single(model, prm, steps)
+    ranks = process_ranks(kind, world, steps, tmp_path)
+    for o in ranks:
+        assert o["comm"]["comm_ranks"] == world and o["comm"]["xcomm_ranks"] == 0, o["comm"]
+        assert o["info"]["n_sparse"] == (1 if kind == "banded" else 0)
+    check_against_single(ref, ranks, lp["m"], lp["n"], lp["obj_star"])
+    model.free()

@@ -197,7 +197,8 @@ def test_dense_rows_of_a_large_matrix_are_cut_by_column_eighths(gpu):
     """Round 4 (solver.cpp: slab_cuts): in a matrix whose gathered vector is beyond one L2 (>= 2^19 columns, >= 2^22 entries)
     a row of 2048 entries and more is cut where its columns cross into another eighth of the vector, the chunks are pinned to
     the XCD share whose own rows read that eighth, k_long_finish adds them in order.  Rows / columns of 2048 .. 9000 entries
-    (one of them with all its entries in ONE eighth, one with a 4097-entry run in one eighth: cut again at kSplitRow) in a
+    (one of them with all its entries in ONE eighth, one with a 4097-entry run in one eighth: cut again at kSplitRow; 4100 in
+    one eighth and 4050 + 60 in two: a short tail that may not join its predecessor) in a
     block-diagonal matrix: iterates against the oracle over normal and check steps, and against the uncut form."""
     from test_gpu_kernels import NAMES_M, NAMES_N, adopt_gpu_data, run_steps
     rng = np.random.default_rng(12)
@@ -212,6 +213,10 @@ def test_dense_rows_of_a_large_matrix_are_cut_by_column_eighths(gpu):
     rows.append(np.full(2500, i1)); cols.append(3 * (n // 8) + rng.choice(n // 8 - 10, 2500, replace=False))   # all in one eighth
     i2 = int(rng.integers(0, m))
     rows.append(np.full(4500, i2)); cols.append(5 * (n // 8) + rng.choice(n // 8 - 10, 4500, replace=False))   # > kSplitRow in one eighth
+    i3, i4 = (int(x) for x in rng.choice(m, 2, replace=False))
+    rows.append(np.full(4100, i3)); cols.append(1 * (n // 8) + rng.choice(n // 8 - 10, 4100, replace=False))   # 4096 + a 4-entry tail that must NOT join
+    rows.append(np.full(4110, i4)); cols.append(np.concatenate([2 * (n // 8) + rng.choice(n // 8 - 10, 4050, replace=False),
+                                                                 6 * (n // 8) + rng.choice(n // 8 - 10, 60, replace=False)]))   # 4050 + 60: the same
     for j, L in zip(rng.choice(n, 3, replace=False), (2100, 4097, 7000)):              # dense columns (rows of A^T)
         rows.append(rng.choice(m, L, replace=False)); cols.append(np.full(L, j))
     rr, cc = np.concatenate(rows), np.concatenate(cols)
@@ -236,7 +241,7 @@ def test_dense_rows_of_a_large_matrix_are_cut_by_column_eighths(gpu):
             assert s.info()["tiled"] == 0
             d = s.describe()
             nsplit = [int(x) for x in __import__("re").findall(r"(\d+) split rows", d)]
-            assert nsplit == ([6, 3] if cut else [3, 2]), d     # cut: every row of 2048+; uncut: only rows over 4096
+            assert nsplit == ([8, 3] if cut else [5, 2]), d     # cut: every row of 2048+; uncut: only rows over 4096
             s.scale()
             if cut:
                 adopt_gpu_data(s, ref)

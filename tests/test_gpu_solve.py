@@ -83,6 +83,7 @@ def test_warmup_then_solve(gpu, model_mps_arrays):
     L = hprlp.lib()
     L.hprlp_warmup.restype = C.c_int
     assert L.hprlp_warmup(0) == 0
+    assert L.hprlp_warmup(99) == -1 and "outside" in hprlp.last_error()   # (a wrong device is refused, not mapped to 0)
     out = (C.c_double * 4)()
     assert L.hprlp_warmup_seconds(out) == 0 and out[3] > 0 and abs(out[0] + out[1] + out[2] - out[3]) <= 1e-6
     a = model_mps_arrays

@@ -54,3 +54,47 @@ def test_band_of_a_permuted_matrix_is_recovered():
     # deterministic
     ok2, _, _, r2, c2 = order(m, n, rp, ci)
     assert ok2 and np.array_equal(r, r2) and np.array_equal(c, c2)
+
+
+def block_plan(m, n, rp, ci, cuts=True):
+    L = hprlp.lib()
+    out = np.zeros(6, np.int64)
+    rc = L.hprlp_row_block_plan(m, n, rp.ctypes.data_as(hprlp.c_int_p), ci.ctypes.data_as(hprlp.c_int_p), int(cuts),
+                                out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_long)))
+    return rc, out
+
+
+def test_row_blocks_of_dense_rows_cut_by_column_eighths_stay_within_a_chunk():
+    """solver.cpp slab_cuts (round-4 advisor finding): a short last chunk joins its predecessor only while the joined chunk is
+    at most kSplitRow = 4096 entries.  Rows of 4100 entries in one column eighth ([0,4096) + a 4-entry tail) and of 4050 + 60
+    entries in two eighths used to give a 4100 / 4110-entry chunk that the set-up then refused ("bad split-row block").  A
+    sweep of random dense rows (about 1 % hit the old defect) is planned and checked on the host."""
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    W = n // 8
+    rows = []
+    rows.append(3 * W + rng.choice(W - 10, 4100, replace=False))                                             # 4096 + 4
+    rows.append(np.concatenate([2 * W + rng.choice(W - 10, 4050, replace=False), 6 * W + rng.choice(W - 10, 60, replace=False)]))
+    rows.append(5 * W + rng.choice(W - 10, 4096 + 95, replace=False))                                        # 4096 + a 95-entry tail: two chunks
+    rows.append(5 * W + rng.choice(W - 10, 4000, replace=False))                                             # one chunk
+    rows.append(np.concatenate([1 * W + rng.choice(W - 10, 3000, replace=False), 4 * W + rng.choice(W - 10, 50, replace=False)]))  # 3050: the tail joins
+    for _ in range(300):
+        L = int(rng.integers(2048, 60000))
+        k = int(rng.integers(1, 9))
+        eighths = rng.choice(8, k, replace=False)
+        parts = rng.multinomial(L, rng.dirichlet(np.ones(k)))
+        rows.append(np.concatenate([e * W + rng.choice(W - 10, p, replace=False) for e, p in zip(eighths, parts) if p > 0]))
+    rows = [np.sort(r) for r in rows]
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    ci = np.concatenate(rows).astype(np.int32)
+    m = len(rows)
+    rc, out = block_plan(m, n, rp, ci)
+    assert rc == 0, hprlp.last_error()
+    assert out[3] == m and out[1] == m and out[4] <= 4096 and out[5] == rp[-1], out
+    # the first rows one by one: chunk counts as the rule gives them
+    for i, want in enumerate((2, 2, 2, 1, 1)):
+        rc, o1 = block_plan(1, n, np.array([0, len(rows[i])], np.int32), rows[i].astype(np.int32))
+        assert rc == 0 and o1[2] == want and o1[4] <= 4096, (i, o1, hprlp.last_error())
+    # without cuts the same rows fall to kSplitRow chunks
+    rc, out = block_plan(m, n, rp, ci, cuts=False)
+    assert rc == 0 and out[3] == 0 and out[4] <= 4096 and out[5] == rp[-1]
