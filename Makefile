@@ -12,7 +12,14 @@ CPP_SRCS := $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.hip.o,$(HIP_SRCS)) $(patsubst $(CSRC)/%.cpp,$(BUILD)/%.o,$(CPP_SRCS))
 HDRS := $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
 
-all: lib/libhprlp.so lib/libhprlp.a bin/solve_mps_file $(BUILD)/solve_mps_file
+all: no-debug-variants lib/libhprlp.so lib/libhprlp.a bin/solve_mps_file $(BUILD)/solve_mps_file
+
+# The timing experiments of rounds 2-4 (HPRLP_DBG_NOFOLD / NOTILE / HALF_TILES / NOBARRIER ...: compile-time variants of the hot
+# kernels that give WRONG results by design) are no longer part of the product sources: their measurements are in profiles/ and
+# HISTORY.md, their code in the history (tree of commit b4383b4).  The build refuses sources or flags that bring one back.
+no-debug-variants:
+	@if grep -rn "HPRLP_DBG_" $(CSRC) include; then echo "error: HPRLP_DBG_* timing variants do not belong in the product sources"; exit 1; fi
+	@case "$(CXXFLAGS) $(DEFS)" in *HPRLP_DBG_*) echo "error: HPRLP_DBG_* in the compiler flags"; exit 1;; esac
 
 $(BUILD)/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
@@ -40,7 +47,7 @@ bin/solve_mps_file: tools/solve_mps_file.cpp lib/libhprlp.so include/HPRLP.h
 	g++ -O2 -std=c++11 -Iinclude -o $@ tools/solve_mps_file.cpp -Llib -lhprlp -Wl,-rpath,'$$ORIGIN/../lib'
 
 # developer variants of the library (kernel experiments, A/B on one GPU box through HPRLP_LIB=lib/variants/libhprlp_<NAME>.so):
-#   make variant NAME=noconf DEFS="-DHPRLP_DBG_NOCONFLICT=1"
+#   make variant NAME=ed3 DEFS="-DHPRLP_SWEEP_ED=3"
 variant:
 	$(MAKE) BUILD=build_variants/$(NAME) CXXFLAGS='$(CXXFLAGS) $(DEFS)' build_variants/$(NAME)/libhprlp.so
 	@mkdir -p lib/variants
@@ -51,4 +58,4 @@ $(BUILD)/libhprlp.so: $(OBJS)
 
 clean:
 	rm -rf $(BUILD) lib bin
-.PHONY: all clean variant
+.PHONY: all clean variant no-debug-variants

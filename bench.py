@@ -421,6 +421,12 @@ def predicted_scaling(iteration_ms_1gpu, ladder_out):
 FAMILY_POINTS = {"family_" + k: mk for k, mk in G.FAMILIES_LARGE.items()}
 
 
+def kernel_forms(description):
+    """hprlp_solver_describe without its tail of environment switches (csrc/env.h): the kernel forms alone, the key the counter
+    files are matched by."""
+    return description.split("; switches:")[0].split("; ignored without")[0]
+
+
 def ladder_traffic(key, kernels):
     """FETCH / WRITE counters of this ladder point (profiles/pmc_traffic.json, entry "ladder:<key>", collected by
     tools/profile_ladder.sh in separate rocprofv3 --pmc passes): carried only if they were taken on the kernel forms this run
@@ -463,7 +469,7 @@ def ladder_point(key, steps=100, warmup=20, timed=True):
     res = s.residuals(2 * steps + 41)
     x_ms, y_ms = t["xhalf_ms"] / steps, t["yhalf_ms"] / steps
     bx, by = bytes_x_half(m, n, nnz), bytes_y_half(m, n, nnz)
-    kernels = s.describe()
+    kernels = kernel_forms(s.describe())
     out = {"m": m, "n": n, "nnz": nnz, "kernels": kernels, "tiled_flags": info["tiled"], "reordered_at_setup": bool(info.get("reordered")),
            "iterations_per_s": steps / (g["total_ms"] * 1e-3), "xhalf_ms": x_ms, "yhalf_ms": y_ms,
            "xhalf_frac_of_8000": bx / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -843,7 +849,7 @@ def main():
     sc = s.scalars()
     info = s.info()
     tiled = info["tiled"]
-    kernels_desc = s.describe()
+    kernels_desc = kernel_forms(s.describe())
     if rank == 0:
         log(f"[bench] setup {time.time() - t0:.1f}s (device setup {sc['setup_time']:.2f}s, scaling {sc['scaling_time']:.2f}s, "
             f"power iteration {sc['power_time']:.2f}s / {pw_it} its, lambda_max={lam:.4g})")

@@ -9,6 +9,7 @@
 #include <iostream>
 
 #include "hprlp_amd.h"
+#include "env.h"
 #include "dist.h"
 #include "presolve.h"
 #include "reorder.h"
@@ -114,7 +115,7 @@ extern "C" int hprlp_warmup(int device) {
     g_warm_seconds[1] = std::chrono::duration<double>(t2 - t1).count();
     g_warm_seconds[2] = std::chrono::duration<double>(t3 - t2).count();
     g_warm_seconds[3] = std::chrono::duration<double>(t3 - t0).count();
-    if (std::getenv("HPRLP_TIMING"))
+    if (env_get("HPRLP_TIMING"))
         std::cerr << "[timing] warm-up: runtime start-up " << g_warm_seconds[0] << " s, device context + first stream " << g_warm_seconds[1]
                   << " s, code objects " << g_warm_seconds[2] << " s" << std::endl;
     return rc;
@@ -816,7 +817,6 @@ extern "C" long hprlp_solver_get_vector(hprlp_solver *h, const char *name, doubl
 
 extern "C" int hprlp_solver_set_vector(hprlp_solver *h, const char *name, const double *in, long len) {
     GUARD_BEGIN
-    if (h) h->s.small_resid_ready = false;
     VecRef v = find_vector(h->s, name ? name : "");
     if (v.n < 0) throw std::runtime_error(std::string("unknown vector name: ") + (name ? name : "(null)"));
     if (len != v.n) throw std::runtime_error("length mismatch");
@@ -927,16 +927,28 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
         if (t.R != kTileRows || t.T != kTileCols) d += " (" + std::to_string(t.R) + " rows, tiles of " + std::to_string(t.T) + " columns)";
         const double all = static_cast<double>(M.tiled.dense_entries) + static_cast<double>(M.tiled.n_rem);
         if (all > 0) d += ", " + std::to_string(static_cast<int>(100.0 * M.tiled.dense_entries / all + 0.5)) + " % of the entries in staged tiles";
-        if (t.rem_cap == kPbRemCap && t.rq16) d += ", 16-bit codes";
         if (t.side_nblk > 0) d += ", long rows aside (" + std::to_string(t.side_nblk) + " blocks through the stream kernel)";
         return d;
     };
     std::string d = one("A", s.A) + "; " + one("A^T", s.AT);
     if (s.use_small && !s.comm) d += "; normal iterations in the single-workgroup kernel (k_small_iterations)";
     if (!s.perm_r.empty()) d += "; locality ordering applied at set-up";
+    // (anything but the default path says so: the switches this solver was set up under, and hooks that were set but not honoured)
+    if (!s.env_at_setup.empty()) d += "; switches: " + s.env_at_setup;
+    if (!s.env_ignored_at_setup.empty()) d += "; ignored without HPRLP_TEST_HOOKS=1: " + s.env_ignored_at_setup;
     std::snprintf(buf, static_cast<size_t>(cap), "%s", d.c_str());
     return static_cast<int>(d.size());
     GUARD_END(-1)
+}
+
+// The table of environment switches (env.h) as text, one per line: "<name>\t<integrator|hook>\t<what>"; returns the length.
+extern "C" int hprlp_env_switches(char *buf, int cap) {
+    int count = 0;
+    const EnvEntry *t = env_table(&count);
+    std::string d;
+    for (int i = 0; i < count; ++i) d += std::string(t[i].name) + "\t" + (t[i].kind == EnvKind::Integrator ? "integrator" : "hook") + "\t" + t[i].what + "\n";
+    if (buf && cap > 0) std::snprintf(buf, static_cast<size_t>(cap), "%s", d.c_str());
+    return static_cast<int>(d.size());
 }
 
 extern "C" int hprlp_solver_time_iterations(hprlp_solver *h, int warmup, int steps, int mode, double *total_ms,

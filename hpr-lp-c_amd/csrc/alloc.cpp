@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "env.h"
 #include "hprlp_amd.h"
 
 namespace hprlp {
@@ -45,7 +46,7 @@ struct Cache {
     std::map<int, size_t> cap;  // per device: min(kDeviceCacheCapBytes, total memory / 3)
     bool off = false;
     Cache() {
-        const char *e = std::getenv("HPRLP_NO_ALLOC_CACHE");
+        const char *e = env_get("HPRLP_NO_ALLOC_CACHE");
         off = e && e[0] == '1';
     }
 };

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "HPRLP.h"
+#include "env.h"
 #include "solver.h"
 
 namespace hprlp {
@@ -103,10 +104,6 @@ __device__ __forceinline__ void block_store_per_problem(double (&acc)[NACC], con
 #define HPRLP_BATCH_NT 1  // 1: nontemporal loads of the panel streams (6390 -> 6800 batch-it/s on config 4); 2: also store X nontemporal (no difference)
 #endif
 constexpr bool kNtPanels = HPRLP_BATCH_NT != 0;
-// developer experiments (build/variants): where does the batched x-half spend its time
-#ifndef HPRLP_DBG_MODE  // bit 0: no panel loads, 1: no stores, 2: no gathers, 3: no SpMM loop at all (kb_half64, normal variant)
-#define HPRLP_DBG_MODE 0
-#endif
 constexpr bool kNtStoreX = HPRLP_BATCH_NT >= 2;
 
 struct HalfArgs {
@@ -132,7 +129,6 @@ __device__ __forceinline__ void half_update(const HalfArgs &a, size_t t, double 
         const double zt = xi + sig * (s - p_cost);
         const double xb = fmin(fmax(zt, p_lo), p_hi);
         const double xh = 2.0 * xb - xi;
-        if ((HPRLP_DBG_MODE & 2) && !CHECK && xh != 1.2345e300) return;
         a.P_hat[t] = xh;  // gathered by the y-half that follows: default policy
         if (kNtStoreX) __builtin_nontemporal_store(f2 * xh + f1 * p_last, a.P + t);  // next read: the next iteration's x-half
         else a.P[t] = f2 * xh + f1 * p_last;
@@ -254,9 +250,7 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             const size_t t = pidx(g, blk.chunk, rows, min(rb + i, rows - 1), lane);
-            if ((HPRLP_DBG_MODE & 1) && !CHECK) {
-                p_i[i] = 0.5, p_lo[i] = 0.0, p_hi[i] = 1.0, p_last[i] = 0.25, p_cost[i] = 0.125;
-            } else if (kNtPanels) {  // the panel streams are read once per half-step: keep them out of the gathered panel's way in the caches
+            if (kNtPanels) {  // the panel streams are read once per half-step: keep them out of the gathered panel's way in the caches
                 p_i[i] = __builtin_nontemporal_load(a.P + t), p_lo[i] = __builtin_nontemporal_load(a.lo + t);
                 p_hi[i] = __builtin_nontemporal_load(a.hi + t), p_last[i] = __builtin_nontemporal_load(a.last + t);
                 p_cost[i] = XHALF ? __builtin_nontemporal_load(a.cost + t) : 0.0;
@@ -266,14 +260,14 @@ __global__ void __launch_bounds__(256) kb_half64(int rows, const int *__restrict
             }
             s[i] = 0.0;
         }
-        const int pend = ((HPRLP_DBG_MODE & 8) && !CHECK) ? pb[0] : pb[RW];
+        const int pend = pb[RW];
         for (int p = pb[0]; p < pend; p += G) {
             double gv[G], av[G];
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 const int q = min(p + u, pend - 1);
                 av[u] = val[q];
-                gv[u] = ((HPRLP_DBG_MODE & 4) && !CHECK) ? static_cast<double>(col[q]) : V[static_cast<size_t>(col[q]) * 64];
+                gv[u] = V[static_cast<size_t>(col[q]) * 64];
             }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
@@ -616,7 +610,7 @@ void launch_half_pair(BatchWS &w, bool check) {
     } else {
         // no reduction partials in the normal variant: one pass over the rows, as many workgroups as rows need
         const int rpb = g.Bw >= 8 ? 4 * kRowsPerWave * (64 / g.Bw) : g.rows_per_block;
-        static const int grid_cap = std::getenv("HPRLP_BATCH_GRID") ? std::atoi(std::getenv("HPRLP_BATCH_GRID")) : 0;  // experiment knob
+        static const int grid_cap = env_get("HPRLP_BATCH_GRID") ? std::atoi(env_get("HPRLP_BATCH_GRID")) : 0;  // experiment knob
         auto cap = [&](int gr) { return grid_cap > 0 ? std::min(gr, grid_cap) : gr; };
         launch(T{}, F{}, dim3(cap((AT.rows + rpb - 1) / rpb) * g.nchunk), AT, xa);
         launch(F{}, F{}, dim3(cap((A.rows + rpb - 1) / rpb) * g.nchunk), A, ya);
@@ -709,7 +703,7 @@ void to_panel(const std::vector<double> &cm, int rows, int B, const Geo &g, doub
 // gathers from 1 / nchunk-th of the panel -- else 64 (a wave = one row, scalar CSR loads).  HPRLP_BATCH_CHUNK overrides.
 int choose_chunk(int m, int n, int Bp) {
     if (Bp < 64) return Bp;
-    if (const char *e = std::getenv("HPRLP_BATCH_CHUNK")) {
+    if (const char *e = env_get("HPRLP_BATCH_CHUNK")) {
         const int c = std::atoi(e);
         if (c == 8 || c == 16 || c == 32 || c == 64) return c;
     }

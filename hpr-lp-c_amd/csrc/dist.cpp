@@ -8,6 +8,7 @@
 // all-reduce of the reduction scalars per residual evaluation.  The reference has no multi-GPU
 // path at all: this file replaces nothing and is new design.
 #include "dist.h"
+#include "env.h"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -256,7 +257,7 @@ struct ShmHeader {
 };
 
 double shm_timeout_s() {
-    const char *e = std::getenv("HPRLP_DIST_TIMEOUT_S");
+    const char *e = env_get("HPRLP_DIST_TIMEOUT_S");
     const double v = e ? std::atof(e) : 120.0;
     return v > 0.0 ? v : 120.0;
 }
@@ -558,7 +559,7 @@ extern "C" int hprlp_extract_shard(const LP_info_cpu *model, int rank, int size,
 extern "C" int hprlp_dist_unique_id(void *out, int bytes) {
     try {
         // HPRLP_DIST_TRANSPORT=shm: the id names a shared-memory segment (host-staged group of processes on one node, no RCCL)
-        const char *tr = std::getenv("HPRLP_DIST_TRANSPORT");
+        const char *tr = env_get("HPRLP_DIST_TRANSPORT");
         if (tr && std::strcmp(tr, "shm") == 0) {
             if (!out) throw std::runtime_error("null id buffer");
             shm_make_unique_id(out, static_cast<size_t>(bytes));

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "env.h"
 #include "hprlp_amd.h"
 
 namespace {
@@ -58,7 +59,7 @@ inline void gen_row_columns(int m, int n, int per_row, int band, int width, doub
 
 // 5 % of a row's entries fall anywhere (BASELINE config 5); HPRLP_GEN_FAR overrides the share for kernel experiments
 double gen_far_share() {
-    static const double far_share = std::getenv("HPRLP_GEN_FAR") ? std::atof(std::getenv("HPRLP_GEN_FAR")) : 0.05;
+    static const double far_share = hprlp::env_get("HPRLP_GEN_FAR") ? std::atof(hprlp::env_get("HPRLP_GEN_FAR")) : 0.05;
     return far_share;
 }
 

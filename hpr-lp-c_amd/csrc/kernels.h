@@ -231,19 +231,8 @@ struct SmallArgs {
     const double *l, *u, *c, *last_x, *AL, *AU, *last_y;
     Ctrl *ctrl;
 };
-// Tail of a launch of the single-workgroup kernel (round 4): after the normal iterations ONE check-variant iteration
-// (reference update_zx_check_gpu / update_y_check_gpu, src/main_iterate.cu:422-432,451-462) and the residual evaluation of
-// the state it leaves (compute_residuals + the weighted norm's inner product, src/main_iterate.cu:229-309,486-515): what the
-// regular path does in eight launches per log / check event.  Vectors as the regular check kernels write them, bit for bit;
-// the eight sums in a fixed tree order (thread, wave shuffle, the 16 wave sums in order) into scal[S_CX .. S_DX2].
-struct SmallTail {
-    double *x_bar, *z_bar, *x_temp, *y_bar, *y_obj, *y_temp;
-    const double *col_norm, *row_norm;
-    double *scal;
-};
 bool small_path_fits(int m, int n, long nnz, int max_row_A, int max_row_AT);
 void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s);
-void launch_small_iterations_check(const SmallArgs &a, int count, const SmallTail &tail, hipStream_t s);
 // the whole power iteration of a small LP in one launch (small.hip): z0 = start vector (m), out = {lambda, iterations done}
 void launch_small_power(const SmallArgs &a, const double *z0, int max_iter, double tol, double *out, hipStream_t s);
 

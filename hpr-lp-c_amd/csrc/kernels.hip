@@ -268,15 +268,7 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
 // row: tiles ascending from the rotation point, then the tiles below it, remainder entries last --
 // fixed by the matrix, so results are reproducible run to run.
 // ------------------------------------------------------------------------------------------------
-#ifndef HPRLP_DBG_NOBARRIER
-#define HPRLP_DBG_NOBARRIER 0
-#endif
-#if HPRLP_DBG_NOBARRIER
-// timing experiment only (races): the waves of a workgroup never wait for each other
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 // field of sweep step r (uniform, 0..255) from the four table registers of a lane (lane l holds steps l, 64 + l, ...):
 // selects on a uniform condition, then one v_readlane -- no control flow
@@ -292,32 +284,8 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 // ED / TD: how many steps ahead the entry loads (HBM) and the tile loads (L2) are issued.  Full chip (two workgroups on
 // every CU): <2, 1> -- deeper gains nothing there, the fabric is busy (profiles/r02_pmc_summary.md).  Few workgroups
 // (the split form): a step cannot be shorter than the HBM latency / ED, so <3, 2>.
-#ifndef HPRLP_DBG_HALF_TILES
-#define HPRLP_DBG_HALF_TILES 0
-#endif
-#ifndef HPRLP_DBG_NOCONFLICT
-#define HPRLP_DBG_NOCONFLICT 0
-#endif
-#ifndef HPRLP_DBG_NOFOLD
-#define HPRLP_DBG_NOFOLD 0
-#endif
-#ifndef HPRLP_DBG_NOTILE
-#define HPRLP_DBG_NOTILE 0
-#endif
-#ifndef HPRLP_DBG_NOREM
-#define HPRLP_DBG_NOREM 0
-#endif
-#ifndef HPRLP_DBG_NOEPI
-#define HPRLP_DBG_NOEPI 0
-#endif
-#ifndef HPRLP_DBG_NOEPISTORE
-#define HPRLP_DBG_NOEPISTORE 0
-#endif
-#ifndef HPRLP_DBG_NOPUSHWORK
-#define HPRLP_DBG_NOPUSHWORK 0
-#endif
-#ifndef HPRLP_DBG_PBSTAMP
-#define HPRLP_DBG_PBSTAMP 0  // developer builds: wall-clock time of k_pb_fused's phases per workgroup (TiledDev::wgtimes, HPRLP_WG_TIMES=1 HPRLP_PB_STAMPS=1)
+#ifndef HPRLP_PB_PHASE_STAMPS
+#define HPRLP_PB_PHASE_STAMPS 0  // developer builds: wall-clock time of k_pb_fused's phases per workgroup (TiledDev::wgtimes, HPRLP_WG_TIMES=1 HPRLP_PB_STAMPS=1)
 #endif
 #ifndef HPRLP_SWEEP_ED
 #define HPRLP_SWEEP_ED 2  // fused kernel: entry loads issued this many steps ahead ...
@@ -331,9 +299,6 @@ __device__ __forceinline__ int step_field(int a0, int a1, int a2, int a3, int r)
 // 723 / 731 it/s (0) -> 735-741 (1) -> 752-761 (2) -> 722-735 (3).
 #ifndef HPRLP_EPI_NT
 #define HPRLP_EPI_NT 2
-#endif
-#ifndef HPRLP_DBG_NOBARRIER
-#define HPRLP_DBG_NOBARRIER 0
 #endif
 
 template <int ED, int TD, bool REP, bool STAMP = false, bool LOGTERM = false, int TC = kTileCols>
@@ -359,9 +324,6 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
         eb = step_field(tb0, tb1, tb2, tb3, r);
         ee = step_field(te0, te1, te2, te3, r);
     };
-#if HPRLP_DBG_NOFOLD
-    double dbg_sink = 0.0;
-#endif
     struct Ent {
         d2_t va, vb;
         uint32_t i0, i1, i2;  // four 24-bit entry codes in three words (tiled.h)
@@ -396,9 +358,6 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
             if (q != p) v.x = v.y;
             tl[2 * j] = v.x;
             tl[2 * j + 1] = v.y;
-#if HPRLP_DBG_HALF_TILES
-            if (k & 1) break;  // timing experiment only: half of the tile traffic (results are wrong)
-#endif
         }
     };
     auto store_tile = [&](const double (&tl)[TPT]) {
@@ -413,11 +372,6 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
     auto process = [&](const Ent &E, int k) {
         int col0, eb, ee_;
         getstep(k, col0, eb, ee_);
-#if HPRLP_DBG_NOFOLD
-        // timing experiment only (results are wrong): the entries are consumed without any LDS access
-        if (K * tid < ee_ - eb) dbg_sink += E.va.x + E.va.y + E.vb.x + E.vb.y + static_cast<double>(E.i0 ^ E.i1 ^ E.i2);
-        return;
-#endif
         if (K * tid < ee_ - eb) {
             const double v[K] = {E.va.x, E.va.y, E.vb.x, E.vb.y};
             const uint32_t c0 = E.i0, c1 = E.i1, c2 = E.i2;
@@ -426,14 +380,8 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
             double y[K];
 #pragma unroll
             for (int k2 = 0; k2 < K; ++k2) {
-#if HPRLP_DBG_NOCONFLICT
-                // timing experiment only (results are wrong): every 32-lane half reads / writes 32 distinct bank pairs
-                rw[k2] = ((id[k2] & (R - 1)) & ~31u) | (tid & 31u);
-                y[k2] = ytile[((id[k2] >> kTileRowBits) & ~31u) | (tid & 31u)];
-#else
                 rw[k2] = id[k2] & (R - 1);
                 y[k2] = ytile[id[k2] >> kTileRowBits];
-#endif
             }
             double a[K];
 #pragma unroll
@@ -494,14 +442,9 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
             if (!same_tile(k + TD)) issue_tile(tl, k + TD);
             if (!keep) lds_barrier();  // tile visible
         } else {
-#if HPRLP_DBG_NOTILE
-            // timing experiment only (results are wrong): no tile loads, no LDS stores of the tile (barrier kept)
-            lds_barrier();
-#else
             store_tile(tl);
             issue_tile(tl, k + TD);
             lds_barrier();  // tile visible
-#endif
         }
         process(E, k);
         issue_entries(E, k + ED);
@@ -552,9 +495,6 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
 #pragma unroll
         for (int i = 0; i < 7; ++i) stamp[i] += ph[i];
     }
-#if HPRLP_DBG_NOFOLD
-    if (dbg_sink == 1.2345e-300) acc[tid] = dbg_sink;  // keeps the loads alive
-#endif
 }
 
 // Remainder steps [smid, s1) of a super-block (propagation blocking, tiled.h): the products were written into this
@@ -569,14 +509,10 @@ __device__ __forceinline__ void tiled_sweep(const TiledDev &t, int s0, int nst, 
 // reads per entry: a matrix without column locality, 20 entries per row all in here, spent 0.28 ms on 4e7 entries.)
 // Per-row order of the additions: fixed by the matrix (chunks in order, the scan's tree inside a wave).
 // bnd: kTileThreads / 64 doubles of LDS for the values, then as many 32-bit words for the rows.
-// C16 (all-remainder copies, K = 8; tiled.h: TiledDev::rq16): the codes are 16 bits -- slot in the step (12 bits) | row minus the
-// previous entry's row (4 bits) -- in chunks of 8 that start at the step's chunk base (TileStep::col0), with the row of every
-// chunk's first entry in rhead: 2.25 instead of 4 bytes per entry, one 16-byte load per lane, no cross-lane work to get the rows.
-template <int K, bool C16 = false>
+template <int K>
 __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int s1, double *acc, double *prod, double *bnd, int tid) {
     constexpr int NT = kTileThreads, NW = kTileThreads / 64;
     static_assert(K == 4 || K == 6 || K == 8, "code loads: one or two 16-byte loads, or two 12-byte loads, per lane");
-    static_assert(!C16 || K == 8, "16-bit codes come in chunks of 8");
     if (smid >= s1) return;
     const int wave = tid >> 6, lane = tid & 63;
     double *bnd_val = bnd;
@@ -590,15 +526,6 @@ __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int
         const int last = max(z.e_end - z.e_begin - 1, 0);
 #pragma unroll
         for (int k = 0; k < K; ++k) pv[k] = __builtin_nontemporal_load(t.P + z.e_begin + min(tid + k * NT, last));  // clamped: branch-free
-        if constexpr (C16) {
-            // chunk `tid` of the step (clamped to its last chunk: branch-free), 16-byte aligned
-            typedef uint32_t u4_t __attribute__((ext_vector_type(4), aligned(16)));
-            const int ch = z.col0 + min(tid, max(last >> 3, 0));
-            const u4_t w = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(t.rq16) + ch);
-            cv[0] = w.x; cv[1] = w.y; cv[2] = w.z; cv[3] = w.w;
-            cv[4] = __builtin_nontemporal_load(t.rhead + ch);
-            return;
-        }
         // the lane's K consecutive codes in wide loads (4-byte aligned); behind the step's end the last whole chunk is read
         const int c0 = min(K * tid, max(last + 1 - K, 0));
         if constexpr (K == 6) {
@@ -628,26 +555,7 @@ __device__ __forceinline__ void remainder_steps(const TiledDev &t, int smid, int
         }
         // (a lane whose chunk crosses the step's end loaded the LAST whole chunk instead: move its codes down)
         uint32_t code[K];
-        if constexpr (C16) {
-            // slot << 16 | row, as the 32-bit codes: the rows by adding up the chunk's deltas from its head row; a delta of 15
-            // (rare: an entry behind a run of rows without an entry in this step) takes its row from the wide list
-            uint32_t r = cv[4], wide = 0;
-            {
-                const uint32_t lo = 0xf000u, hi = 0xf0000000u;  // (entry 0 of a chunk never carries a delta)
-                const bool any = ((cv[0] & hi) == hi) | ((cv[1] & lo) == lo) | ((cv[1] & hi) == hi) | ((cv[2] & lo) == lo) |
-                                 ((cv[2] & hi) == hi) | ((cv[3] & lo) == lo) | ((cv[3] & hi) == hi);
-                if (any) wide = t.rwide_ptr[st.col0 + min(tid, max((cnt - 1) >> 3, 0))];  // (position in wide_rows)
-            }
-#pragma unroll
-            for (int u = 0; u < K; ++u) {
-                const uint32_t c = (u & 1) ? (cv[u >> 1] >> 16) : (cv[u >> 1] & 0xffffu);
-                if (u > 0) {
-                    if ((c >> 12) == 15u) r = t.wide_rows[wide++];
-                    else r += c >> 12;
-                }
-                code[u] = ((c & 0xfffu) << 16) | r;
-            }
-        } else {
+        {
             const int shift = K * tid - min(K * tid, max(cnt - K, 0));  // 0 for every lane but at most one
 #pragma unroll
             for (int u = 0; u < K; ++u) code[u] = cv[u];
@@ -891,16 +799,10 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int s0 = t.sb_ptr[sb], smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
         if (s0 < smid) tiled_sweep<HPRLP_SWEEP_ED, HPRLP_SWEEP_TD, REP, false, LogTerm<Epi>::value, NARROW ? kTileColsNarrow : kTileCols>(t, s0, smid - s0, t.steps[s0].rot, smid - s0, vec, ncols, acc, ytile, tid);  // rotated sweep (tiled_build.hip, finish_schedule)
-#if !HPRLP_DBG_NOREM
         remainder_steps<kTileRemK>(t, smid, s1, acc, ytile, ytile + kTileRemCap, tid);
-#endif
         lds_barrier();
         const int r0 = sb * R;
-#if HPRLP_DBG_NOEPI
-        const int nr = min(R, A.rows - r0) > 0 && acc[tid] == 1.2345e-300 ? 1 : 0;  // timing experiment only: no epilogue traffic
-#else
         const int nr = min(R, A.rows - r0);
-#endif
         // the hand-off's list bounds travel while the epilogue runs (a uniform load waited for on the spot is one more
         // exposed trip to memory per super-block)
         int pb = 0, pe = 0;
@@ -909,7 +811,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_tiled_fused(CsrDev A, Epi e
             pe = epi.push.gptr[sb + 1];
         }
         epilogue_rows<Epi, PUSH>(epi, acc, racc, r0, nr, tid);
-        if constexpr (PUSH && !HPRLP_DBG_NOEPI && !HPRLP_DBG_NOPUSHWORK) {
+        if constexpr (PUSH) {
             // Hand-off (kernels.h: FarPush): this super-block's fresh values are the source group `sb` of the OTHER matrix'
             // remainder; write its products straight into that matrix' P -- what k_far_products would do in a launch of
             // its own after re-reading the vector from memory.  Same products bit for bit, same slots.
@@ -962,7 +864,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
 #pragma unroll
     for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) racc[i] = 0.0;
     epi.begin();
-#if HPRLP_DBG_PBSTAMP
+#if HPRLP_PB_PHASE_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64(), tk0 = tq;
 #define PB_STAMP(i) do { const unsigned long long now_ = wall_clock64(); ph[i] += now_ - tq; tq = now_; } while (0)
 #else
@@ -974,18 +876,11 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
         lds_barrier();  // the previous super-block's epilogue is done with acc
         for (int i = tid; i < R; i += NT) acc[i] = 0.0;
         const int smid = t.sb_mid[sb], s1 = t.sb_ptr[sb + 1];
-        if (!HPRLP_DBG_NOREM) {
-            if (t.rq16) remainder_steps<K, K == 8>(t, smid, s1, acc, prod, bnd, tid);
-            else remainder_steps<K>(t, smid, s1, acc, prod, bnd, tid);
-        }
+        remainder_steps<K>(t, smid, s1, acc, prod, bnd, tid);
         lds_barrier();
         PB_STAMP(4);
         const int r0 = sb * R;
-#if HPRLP_DBG_NOEPI
-        const int nr = min(R, A.rows - r0) > 0 && acc[tid] == 1.2345e-300 ? 1 : 0;  // timing experiment only: no epilogue traffic
-#else
         const int nr = min(R, A.rows - r0);
-#endif
         int pb = 0, pe = 0;
         if constexpr (PUSH) {
             pb = epi.push.gptr[sb];
@@ -993,7 +888,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
         }
         epilogue_rows<Epi, PUSH>(epi, acc, racc, r0, nr, tid);
         PB_STAMP(5);
-        if constexpr (PUSH && !HPRLP_DBG_NOEPI && !HPRLP_DBG_NOPUSHWORK) {
+        if constexpr (PUSH) {
             // hand-off (kernels.h: FarPush), as in k_tiled_fused: this super-block's fresh values are source group `sb` of the
             // other matrix' lists
             lds_barrier();
@@ -1002,7 +897,7 @@ __global__ void __launch_bounds__(kTileThreads, 4) k_pb_fused(CsrDev A, Epi epi)
         }
         PB_STAMP(6);
     }
-#if HPRLP_DBG_PBSTAMP
+#if HPRLP_PB_PHASE_STAMPS
     if (t.wgtimes && tid == 0 && PUSH && NACC == 0) {
         ph[7] = wall_clock64() - tk0;
         for (int i = 0; i < 8; ++i) t.wgtimes[blockIdx.x * 8 + i] = ph[i];
@@ -1303,9 +1198,6 @@ struct XEpi {
         const double xb = fmin(w.ui, fmax(w.li, zt));
         const double xh = 2.0 * xb - w.xi;
         const double xn = f2 * xh + f1 * w.lx;
-#if HPRLP_DBG_NOEPISTORE
-        if (xn == 1.2345e-300)  // timing experiment only: the epilogue's stores are skipped
-#endif
         {
             if constexpr (STREAMED && HPRLP_EPI_NT >= 2) __builtin_nontemporal_store(xh, x_hat + r);
             else x_hat[r] = xh;
@@ -1378,9 +1270,6 @@ struct YEpi {
         const double yb = fact2 * d;
         const double yh = 2.0 * yb - w.yi;
         const double yn = hf2 * yh + hf1 * w.ly;
-#if HPRLP_DBG_NOEPISTORE
-        if (yn == 1.2345e-300)
-#endif
         if constexpr (STREAMED && HPRLP_EPI_NT >= 2) __builtin_nontemporal_store(yn, y + r);
         else y[r] = yn;
         if constexpr (CHECK) {

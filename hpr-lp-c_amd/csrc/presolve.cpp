@@ -1,5 +1,6 @@
 // presolve.cpp -- in-process LP presolve / postsolve (design and scope: presolve.h).
 #include "presolve.h"
+#include "env.h"
 
 #include <algorithm>
 #include <chrono>
@@ -121,7 +122,7 @@ bool ReduceStage::run(const LP_info_cpu *model) {
             }
     double offset = 0.0;
     bool give_up = false;
-    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;  // section times of this stage on stderr
+    const bool timing = env_get("HPRLP_TIMING") != nullptr;  // section times of this stage on stderr
     double t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto t_mark = std::chrono::steady_clock::now();
     auto lap = [&](int k) {
@@ -132,11 +133,11 @@ bool ReduceStage::run(const LP_info_cpu *model) {
     };
     lap(0);  // transpose + working copies
     // HPRLP_PRESOLVE_OFF=slack,dualfix,parallel,forcing switches reductions off (diagnostics)
-    const char *off_env = std::getenv("HPRLP_PRESOLVE_OFF");
+    const char *off_env = env_get("HPRLP_PRESOLVE_OFF");
     const std::string off = off_env ? off_env : "";
     const bool use_slack = off.find("slack") == std::string::npos, use_dualfix = off.find("dualfix") == std::string::npos;
     const bool use_parallel = off.find("parallel") == std::string::npos, use_forcing = off.find("forcing") == std::string::npos;
-    const char *sp_env = std::getenv("HPRLP_SLACK_PIVOT");
+    const char *sp_env = env_get("HPRLP_SLACK_PIVOT");
     const double slack_pivot = sp_env ? std::atof(sp_env) : kSlackPivot;
 
     auto fix_column = [&](int j, double v, Kind kind) {

@@ -11,6 +11,7 @@
 #include <string>
 
 #include "HPRLP.h"
+#include "env.h"
 #include "common.h"
 #include "presolve.h"
 
@@ -95,7 +96,7 @@ bool DoubletonStage::run(const LP_info_cpu *model) {
     std::vector<char> row_alive(static_cast<size_t>(m), 1), col_alive(static_cast<size_t>(n), 1);
     double offset = 0.0;
 
-    const int max_elim = std::getenv("HPRLP_DTON_MAX") ? std::atoi(std::getenv("HPRLP_DTON_MAX")) : 1 << 30;  // (debugging)
+    const int max_elim = env_get("HPRLP_DTON_MAX") ? std::atoi(env_get("HPRLP_DTON_MAX")) : 1 << 30;  // (debugging)
     for (size_t h = 0; h < queue.size() && static_cast<int>(recs_.size()) < max_elim; ++h) {
         const int i = queue[h];
         if (!row_alive[i] || R[i].size() != 2 || !(fin(AL[i]) && AL[i] == AU[i])) continue;
@@ -120,7 +121,7 @@ bool DoubletonStage::run(const LP_info_cpu *model) {
         const double l_new = std::max(l[k], k_lo), u_new = std::min(u[k], k_up);
         if (l_new > u_new && l_new - u_new > rel(l_new)) return false;  // the two boxes contradict the row: the solver reports it
         Rec rec{i, j, k, aj, ak, b, l[k], u[k], l_new, std::max(u_new, l_new), cost[j], static_cast<int>(ents_.size()), 0};
-        if (std::getenv("HPRLP_DTON_TRACE"))
+        if (env_get("HPRLP_DTON_TRACE"))
             std::fprintf(stderr, "[dton %zu] row %d: %.17g x%d + %.17g x%d = %.17g; x%d in [%g, %g] (len %d), x%d in [%g, %g] (len %d) -> [%.17g, %.17g]\n",
                          recs_.size() + 1, i, aj, j, ak, k, b, j, l[j], u[j], col_cnt[j], k, l[k], u[k], col_cnt[k], rec.lk_new, rec.uk_new);
         // A merged coefficient that nearly cancels (|a_rk - (a_rj / a_j) a_k| tiny against its parts, but not rounding noise)
@@ -398,11 +399,11 @@ bool Presolve::run(const LP_info_cpu *model) {
     m_ = model->m;
     n_ = model->n;
     // HPRLP_PRESOLVE_OFF=doubleton,bounds switches the two stages off (the other names: presolve.cpp)
-    const char *off_env = std::getenv("HPRLP_PRESOLVE_OFF");
+    const char *off_env = env_get("HPRLP_PRESOLVE_OFF");
     const std::string off = off_env ? off_env : "";
     const bool use_dton = off.find("doubleton") == std::string::npos, use_bounds = off.find("bounds") == std::string::npos;
     // HPRLP_PRESOLVE_ONLY=doubleton|bounds: that stage alone on the model as given (unit tests of the stages)
-    if (const char *only = std::getenv("HPRLP_PRESOLVE_ONLY")) {
+    if (const char *only = env_get("HPRLP_PRESOLVE_ONLY")) {
         const std::string which = only;
         if (which == "doubleton") {
             auto st = std::make_unique<DoubletonStage>();
@@ -432,7 +433,7 @@ bool Presolve::run(const LP_info_cpu *model) {
     // it (PSLP likewise drops the implied bounds that stayed redundant at the end, Primal_propagation.c:786).
     bool bounds_done = false, pending = false;
     const LP_info_cpu *before_bounds = nullptr;
-    const int max_links = std::getenv("HPRLP_PRESOLVE_MAX_LINKS") ? std::atoi(std::getenv("HPRLP_PRESOLVE_MAX_LINKS")) : 1 << 20;  // (debugging)
+    const int max_links = env_get("HPRLP_PRESOLVE_MAX_LINKS") ? std::atoi(env_get("HPRLP_PRESOLVE_MAX_LINKS")) : 1 << 20;  // (debugging)
     for (int round = 0; round < kMaxRounds && !solved_ && static_cast<int>(chain_.size()) < max_links; ++round) {
         bool progress = false;
         ++stats_.rounds;

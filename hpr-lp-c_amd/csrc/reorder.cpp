@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "common.h"
+#include "env.h"
 #include "reorder.h"
 #include "tiled.h"
 
@@ -98,7 +99,7 @@ void centre_sweep(int rows, const int *rp, const int *ci, const std::vector<doub
             const int take = std::min(len, 32);
             for (int q = 0; q < take; ++q) buf[q] = src[ci[k0 + static_cast<int>(static_cast<long>(q) * len / take)]];
             std::sort(buf, buf + take);
-            static const int trim_env = std::getenv("HPRLP_REORDER_TRIM") ? std::atoi(std::getenv("HPRLP_REORDER_TRIM")) : 20;  // percent per side
+            static const int trim_env = env_get("HPRLP_REORDER_TRIM") ? std::atoi(env_get("HPRLP_REORDER_TRIM")) : 20;  // percent per side
             int lo = take * trim_env / 100, hi = take - lo;
             if (trim_env >= 50 || hi <= lo) { lo = (take - 1) / 2; hi = take / 2 + 1; }  // median
             double sum = 0.0;
@@ -358,7 +359,7 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
     ReorderStats local;
     ReorderStats &S = st ? *st : local;
     auto tphase = time_now();
-    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;
+    const bool timing = env_get("HPRLP_TIMING") != nullptr;
     auto tick = [&](const char *what) {
         if (timing) std::fprintf(stderr, "[timing]   reorder %-28s %.2f s\n", what, time_since(tphase));
         tphase = time_now();
@@ -371,7 +372,7 @@ void cluster_positions(int m, int n, const int *rp, const int *ci, const int *tr
     // about 16k nodes per cluster: a BFS ball of that size is as wide as the matrix' natural window anyway, and the
     // spectral ordering of the cluster graph (dense-ish: every cluster links to all that overlap it) stays cheap
     long per_cluster = 16384;
-    if (const char *e = std::getenv("HPRLP_REORDER_CLUSTER")) per_cluster = std::max(64L, std::atol(e));
+    if (const char *e = env_get("HPRLP_REORDER_CLUSTER")) per_cluster = std::max(64L, std::atol(e));
     const int K = static_cast<int>(std::max<long>(2, std::min<long>(65536, std::min<long>(m, N / per_cluster + 1))));
     S.clusters = K;
     std::vector<int> lab_r(static_cast<size_t>(m), -1), lab_c(static_cast<size_t>(n), -1);
@@ -534,7 +535,7 @@ bool locality_ordering(int m, int n, const int *rp, const int *ci, std::vector<i
     S = ReorderStats();
     const auto t0 = time_now();
     auto tphase = time_now();
-    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;
+    const bool timing = env_get("HPRLP_TIMING") != nullptr;
     auto tick = [&](const char *what) {
         if (timing) std::fprintf(stderr, "[timing]   reorder %-28s %.2f s\n", what, time_since(tphase));
         tphase = time_now();
@@ -555,7 +556,7 @@ bool locality_ordering(int m, int n, const int *rp, const int *ci, std::vector<i
     cluster_positions(m, n, rp, ci, trp.data(), tci.data(), &pr_, &pc_, &S);
     tphase = time_now();
     rank_normalise(pr_, T);
-    const int nsweeps = std::getenv("HPRLP_REORDER_SWEEPS") ? std::atoi(std::getenv("HPRLP_REORDER_SWEEPS")) : kReorderSweeps;
+    const int nsweeps = env_get("HPRLP_REORDER_SWEEPS") ? std::atoi(env_get("HPRLP_REORDER_SWEEPS")) : kReorderSweeps;
     for (int sweep = 0; sweep < nsweeps; ++sweep) {
         centre_sweep(n, trp.data(), tci.data(), pr_, pc_, T);
         rank_normalise(pc_, T);

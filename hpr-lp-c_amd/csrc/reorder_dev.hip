@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "env.h"
 #include "kernels.h"
 #include "reorder.h"
 
@@ -282,7 +283,7 @@ void device_cluster_positions(int m, int n, long nnz, const int *rp, const int *
     ReorderStats &S = st ? *st : local;
     const long N = static_cast<long>(m) + n;
     long per_cluster = 16384;  // reorder.cpp, cluster_positions: same sizing
-    if (const char *e = std::getenv("HPRLP_REORDER_CLUSTER")) per_cluster = std::max(64L, std::atol(e));
+    if (const char *e = env_get("HPRLP_REORDER_CLUSTER")) per_cluster = std::max(64L, std::atol(e));
     const int K = static_cast<int>(std::max<long>(2, std::min<long>(65536, std::min<long>(m, N / per_cluster + 1))));
     S.clusters = K;
     DBuf<int> lab_r(static_cast<size_t>(m)), lab_c(static_cast<size_t>(n)), changed(1);

@@ -68,8 +68,8 @@ __device__ __forceinline__ double wave_sum64(double v) {
     return v;
 }
 
-template <int KMAX, int R, bool TAIL = false>
-__global__ void __launch_bounds__(NT) k_small_iterations(SmallArgs a, int K, int count, SmallTail tl) {
+template <int KMAX, int R>
+__global__ void __launch_bounds__(NT) k_small_iterations(SmallArgs a, int K, int count) {
     static_assert(KMAX % 2 == 0, "positions are packed in pairs");
     __shared__ double prod[NT * KMAX + NT * KMAX / 32 + 1];
     __shared__ double ys[NT * R];
@@ -172,167 +172,18 @@ __global__ void __launch_bounds__(NT) k_small_iterations(SmallArgs a, int K, int
         lds_sync();
     }
 
-    if constexpr (TAIL) {
-        // ---- one check-variant iteration (iteration k0 + count) and the residuals of the state it leaves
-        const double f1 = 1.0 / (static_cast<double>(k0 + count) + 2.0), f2 = 1.0 - f1;
-        // sums: a pass's thread partials go through the wave shuffle into red[slot][wave] as soon as the pass is done (eight live
-        // accumulators across the passes spilled the 12-entries-per-thread instance); slots S_CX .. S_DX2 of kernels.h
-        __shared__ double red[8][NT / 64];
-        const int wave = t >> 6, lane = t & 63;
-        auto flush = [&](int slot, double part) {
-            const double w = wave_sum64(part);
-            if (lane == 0) red[slot][wave] = w;
-        };
-        // (values the later passes need again -- x_bar, z_bar, x_temp, y_temp -- are re-read from the vectors this thread has just
-        // stored rather than kept: twenty more registers spilled the 12-entries-per-thread instance)
-        auto products_AT = [&](const double *g) {   // A^T order: this thread's own consecutive slots
-#pragma unroll
-            for (int k = 0; k < KMAX; k += 2) {
-                const double g0 = g[fresh(ij[k]) & 0xffffu], g1 = g[fresh(ij[k + 1]) & 0xffffu];
-                const int qq = static_cast<int>(fresh(static_cast<unsigned int>(e0))) + k;
-                if (k < K) prod[pad(qq)] = v[k] * g0;
-                if (k + 1 < K) prod[pad(qq + 1)] = v[k + 1] * g1;
-            }
-        };
-        auto products_A = [&](const double *g) {    // scattered to their position in the CSR order of A
-#pragma unroll
-            for (int k = 0; k < KMAX; k += 2) {
-                const double g0 = g[fresh(ij[k]) >> 16], g1 = g[fresh(ij[k + 1]) >> 16];
-                const unsigned int pp = fresh(pa[k >> 1]);
-                prod[pad(static_cast<int>(pp & 0xffffu))] = v[k] * g0;
-                prod[pad(static_cast<int>(pp >> 16))] = v[k + 1] * g1;
-            }
-        };
-        // x-half, check variant: same operations as XEpi<true>::apply
-        products_AT(ys);
-        lds_sync();
-        double s_cx = 0.0, s_xz = 0.0, s_dx2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const double s = seq_sum(prod, static_cast<int>(xseg[q] & 0xffffu), static_cast<int>(xseg[q] >> 16));
-            const double gc = s - ci[q];
-            const double zt = xi[q] + sigma * gc;
-            const double xb = fmin(ui[q], fmax(li[q], zt));
-            const double h = 2.0 * xb - xi[q];
-            xi[q] = f2 * h + f1 * lx[q];
-            const double zb = (xb - zt) / sigma;
-            const double dx = xb - h;
-            const unsigned int j = own[q] & 0xffffu;
-            if (j != 0xffffu) {
-                xh[j] = h;
-                a.x_hat[j] = h;
-                tl.x_bar[j] = xb;
-                tl.z_bar[j] = zb;
-                tl.x_temp[j] = dx;
-                s_cx += ci[q] * xb;
-                s_xz += xb * zb;
-                s_dx2 += dx * dx;
-            }
-        }
-        flush(S_CX, s_cx);
-        flush(S_XZ, s_xz);
-        flush(S_DX2, s_dx2);
-        lds_sync();
-        // y-half, check variant: same operations as YEpi<true>::apply
-        products_A(xh);
-        lds_sync();
-        double s_yy = 0.0, s_dy2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const double s = seq_sum(prod, static_cast<int>(yseg[q] & 0xffffu), static_cast<int>(yseg[q] >> 16));
-            const double w = s - fact1 * yi[q];
-            const double d = fmax(lo[q] - w, fmin(hi[q] - w, 0.0));
-            const double yb = fact2 * d;
-            const double yh = 2.0 * yb - yi[q];
-            yi[q] = f2 * yh + f1 * ly[q];
-            const double dy = yb - yh;
-            const double yo = w + d;
-            const unsigned int i = own[q] >> 16;
-            if (i != 0xffffu) {
-                ys[i] = yb;   // y_bar: what the dual residual gathers (y itself leaves through yi)
-                tl.y_bar[i] = yb;
-                tl.y_obj[i] = yo;
-                tl.y_temp[i] = dy;
-                s_yy += yo * yb;
-                s_dy2 += dy * dy;
-            }
-        }
-        flush(S_YOBJ_Y, s_yy);
-        flush(S_DY2, s_dy2);
-        lds_sync();
-        // dual residual (RdEpi): (c - A^T y_bar - z_bar) * col_norm
-        products_AT(ys);
-        lds_sync();
-        double s_rd2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const unsigned int j = own[q] & 0xffffu;
-            const bool on = j != 0xffffu;
-            const double zbq = on ? tl.z_bar[j] : 0.0, xbq = on ? tl.x_bar[j] : 0.0, cn = on ? tl.col_norm[j] : 0.0;
-            const double s = seq_sum(prod, static_cast<int>(xseg[q] & 0xffffu), static_cast<int>(xseg[q] >> 16));
-            if (on) {
-                const double rd = (ci[q] - s - zbq) * cn;
-                s_rd2 += rd * rd;
-                xh[j] = xbq;   // x_bar: what the primal residual gathers
-            }
-        }
-        flush(S_RD2, s_rd2);
-        lds_sync();
-        // primal residual (RpEpi): max(min(AU - A x_bar, 0), AL - A x_bar) * row_norm
-        products_A(xh);
-        lds_sync();
-        double s_rp2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const unsigned int i = own[q] >> 16;
-            const double rn = i != 0xffffu ? tl.row_norm[i] : 0.0;
-            const double s = seq_sum(prod, static_cast<int>(yseg[q] & 0xffffu), static_cast<int>(yseg[q] >> 16));
-            if (i != 0xffffu) {
-                const double rp = fmax(fmin(hi[q] - s, 0.0), lo[q] - s) * rn;
-                s_rp2 += rp * rp;
-            }
-        }
-        flush(S_RP2, s_rp2);
-        lds_sync();
-        // <A x_temp, y_temp> (GapEpi)
-#pragma unroll
-        for (int q = 0; q < R; ++q)
-            if ((own[q] & 0xffffu) != 0xffffu) xh[own[q] & 0xffffu] = tl.x_temp[own[q] & 0xffffu];
-        lds_sync();
-        products_A(xh);
-        lds_sync();
-        double s_ad = 0.0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const unsigned int i = own[q] >> 16;
-            const double dyq = i != 0xffffu ? tl.y_temp[i] : 0.0;
-            const double s = seq_sum(prod, static_cast<int>(yseg[q] & 0xffffu), static_cast<int>(yseg[q] >> 16));
-            if (i != 0xffffu) s_ad += s * dyq;
-        }
-        lds_sync();
-        flush(S_ADX_DY, s_ad);
-        lds_sync();
-        // the 16 wave sums of a slot in order
-        if (t < 8) {
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < NT / 64; ++w) tot += red[t][w];
-            tl.scal[t] = tot;
-        }
-    }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
         const unsigned int j = own[q] & 0xffffu, i = own[q] >> 16;
         if (j != 0xffffu) {
             a.x[j] = xi[q];
-            if (!TAIL) a.x_hat[j] = xh[j];   // (the tail stored x_hat with the check step; xh holds x_temp by now)
+            a.x_hat[j] = xh[j];
         }
         if (i != 0xffffu) a.y[i] = yi[q];
     }
-    const int done = count + (TAIL ? 1 : 0);
-    if (t == 0 && done > 0) {
-        a.ctrl->kx = k0 + done;
-        a.ctrl->ky = k0 + done - 1;
+    if (t == 0 && count > 0) {
+        a.ctrl->kx = k0 + count;
+        a.ctrl->ky = k0 + count - 1;
     }
 }
 
@@ -483,14 +334,7 @@ void launch_power_kr(const SmallArgs &a, const double *z0, int max_iter, double 
 template <int KMAX, int R>
 void launch_kr(const SmallArgs &a, int count, hipStream_t s) {
     const int K = (a.nnz + NT - 1) / NT;
-    hipLaunchKernelGGL((k_small_iterations<KMAX, R, false>), dim3(1), dim3(NT), 0, s, a, K, count, SmallTail{});
-    HIP_CHECK(hipGetLastError());
-}
-
-template <int KMAX, int R>
-void launch_kr_check(const SmallArgs &a, int count, const SmallTail &tl, hipStream_t s) {
-    const int K = (a.nnz + NT - 1) / NT;
-    hipLaunchKernelGGL((k_small_iterations<KMAX, R, true>), dim3(1), dim3(NT), 0, s, a, K, count, tl);
+    hipLaunchKernelGGL((k_small_iterations<KMAX, R>), dim3(1), dim3(NT), 0, s, a, K, count);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -512,18 +356,6 @@ void launch_small_power(const SmallArgs &a, const double *z0, int max_iter, doub
     else launch_power_kr<12, 2>(a, z0, max_iter, tol, out, s);
 }
 
-void launch_small_iterations_check(const SmallArgs &a, int count, const SmallTail &tl, hipStream_t s) {
-    if (count < 0) count = 0;
-    const int K = (a.nnz + NT - 1) / NT;
-    const int R = (std::max(a.m, a.n) + NT - 1) / NT;
-    if (K <= 4 && R <= 1) launch_kr_check<4, 1>(a, count, tl, s);
-    else if (K <= 4) launch_kr_check<4, 2>(a, count, tl, s);
-    else if (K <= 8 && R <= 1) launch_kr_check<8, 1>(a, count, tl, s);
-    else if (K <= 8) launch_kr_check<8, 2>(a, count, tl, s);
-    else if (R <= 1) launch_kr_check<12, 1>(a, count, tl, s);
-    else launch_kr_check<12, 2>(a, count, tl, s);
-}
-
 void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s) {
     if (count <= 0) return;
     // instantiated by entries / rows per thread so that small problems do not carry the registers of big ones
@@ -541,7 +373,7 @@ void launch_small_iterations(const SmallArgs &a, int count, hipStream_t s) {
 // of at the first launch of one of its kernels
 void warm_small_tu() {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>((&k_small_iterations<4, 1, false>)));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>((&k_small_iterations<4, 1>)));
 }
 
 }  // namespace hprlp

@@ -5,6 +5,7 @@
 // update, reference src/utils.cu:65-69).  Normal iterations between two residual evaluations are
 // replayed from captured hipGraphs of 2 launches per iteration.
 #include "solver.h"
+#include "env.h"
 
 #include <algorithm>
 #include <cmath>
@@ -47,8 +48,8 @@ static std::vector<int4> build_row_blocks_cut(int rows, const int *rowptr, std::
     // measured (tools/latency_probe.py, config 3): launch-latency-bound matrices run 9 % faster with twice
     // as many, half as long blocks (256: 15.9 us/iteration, 512: 17.4, 128: 16.0); large ones stream best at 512
     int cap_rows = kStreamRows, cap_nnz = (rows > 0 && rowptr[rows] < (1 << 22)) ? kStreamW / 2 : kStreamW;
-    if (const char *e = std::getenv("HPRLP_STREAM_ROWS")) cap_rows = std::min(kStreamRows, std::max(1, std::atoi(e)));
-    if (const char *e = std::getenv("HPRLP_STREAM_NNZ")) cap_nnz = std::min(kStreamW, std::max(16, std::atoi(e)));
+    if (const char *e = env_get("HPRLP_STREAM_ROWS")) cap_rows = std::min(kStreamRows, std::max(1, std::atoi(e)));
+    if (const char *e = env_get("HPRLP_STREAM_NNZ")) cap_nnz = std::min(kStreamW, std::max(16, std::atoi(e)));
     int r = 0, slots = 0;
     while (r < rows) {
         const int len = rowptr[r + 1] - rowptr[r];
@@ -244,7 +245,7 @@ constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of
 struct PhaseTimer {
     bool on;
     clock_type::time_point t0;
-    PhaseTimer() : on(std::getenv("HPRLP_TIMING") != nullptr), t0(time_now()) {}
+    PhaseTimer() : on(env_get("HPRLP_TIMING") != nullptr), t0(time_now()) {}
     void tick(const char *what) {
         if (on) std::cerr << "[timing] " << what << ": " << time_since(t0) << " s" << std::endl;
         t0 = time_now();
@@ -257,8 +258,8 @@ struct PhaseTimer {
 // sleep the waiting thread gets its turn (measured on config 5, warm process: set-up of A 89 -> 67 ms; 16 / 32 / 64 MB pieces
 // with 30 / 100 us equal within 3 ms).  HPRLP_COPY_PIECE_MB / HPRLP_COPY_PAUSE_US: for measurements.
 static hipError_t copy_in_pieces(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t cs) {
-    static const size_t kPiece = size_t(std::getenv("HPRLP_COPY_PIECE_MB") ? std::max(1, std::atoi(std::getenv("HPRLP_COPY_PIECE_MB"))) : 64) << 20;
-    static const int pause_us = std::getenv("HPRLP_COPY_PAUSE_US") ? std::atoi(std::getenv("HPRLP_COPY_PAUSE_US")) : 100;
+    static const size_t kPiece = size_t(env_get("HPRLP_COPY_PIECE_MB") ? std::max(1, std::atoi(env_get("HPRLP_COPY_PIECE_MB"))) : 64) << 20;
+    static const int pause_us = env_get("HPRLP_COPY_PAUSE_US") ? std::atoi(env_get("HPRLP_COPY_PAUSE_US")) : 100;
     for (size_t off = 0; off < bytes; off += kPiece) {
         const size_t len = std::min(kPiece, bytes - off);
         hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len, kind, cs);
@@ -298,7 +299,7 @@ void DeviceMatrix::upload(int rows, int cols, const int *rp, const int *ci, cons
     // travels on a copy stream of its own, driven by a helper thread, beside the host-side row blocks and the device build
     // of the tiled copy, which work on the index arrays (config 5: 27 ms of 1.6 GB hidden).
     std::future<void> val_job;
-    if (nnz > 4000000 && std::getenv("HPRLP_NO_SETUP_OVERLAP") == nullptr) {
+    if (nnz > 4000000 && env_get("HPRLP_NO_SETUP_OVERLAP") == nullptr) {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         double *dst = val.p;
@@ -354,7 +355,7 @@ void DeviceMatrix::describe_when(int rows, int cols, long nnz_l, std::shared_fut
         HIP_CHECK(hipSetDevice(dev));
         const int *rp = rp_ready.get();
         RowCuts cuts;
-        const char *noslab = std::getenv("HPRLP_NO_SLAB_CUTS");
+        const char *noslab = env_get("HPRLP_NO_SLAB_CUTS");
         if (cols >= (1 << 19) && nnz >= (1 << 22) && !(noslab && noslab[0] == '1')) {
             cuts = slab_cuts(rows, cols, rp, [&](int r, int *out) {
                 const size_t len = static_cast<size_t>(rp[r + 1] - rp[r]);
@@ -366,7 +367,7 @@ void DeviceMatrix::describe_when(int rows, int cols, long nnz_l, std::shared_fut
         out.b = build_row_blocks_cut(rows, rp, &out.lr, cuts.rows.empty() ? nullptr : &cuts);
         return out;
     };
-    const bool overlap = rows > 100000 && std::getenv("HPRLP_NO_SETUP_OVERLAP") == nullptr;
+    const bool overlap = rows > 100000 && env_get("HPRLP_NO_SETUP_OVERLAP") == nullptr;
     std::future<Blocks> blocks_job = std::async(overlap ? std::launch::async : std::launch::deferred, make_blocks);
     view.rows = rows;
     view.cols = cols;
@@ -376,7 +377,7 @@ void DeviceMatrix::describe_when(int rows, int cols, long nnz_l, std::shared_fut
     view.val = val.p;
     // nontemporal matrix loads only when the matrix cannot stay in the eight 4 MiB L2s anyway
     view.nt = static_cast<size_t>(nnz) * 12 > (static_cast<size_t>(16) << 20);
-    if (const char *e = std::getenv("HPRLP_NT")) view.nt = std::atoi(e) != 0;
+    if (const char *e = env_get("HPRLP_NT")) view.nt = std::atoi(e) != 0;
     try {
         longest_row = 0;
         if (rows > 100000) {  // (from the device copy: the host row pointers of A^T may still be on their way)
@@ -414,12 +415,12 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                                     double min_dense_override, const std::function<void()> &join_values, PhaseTimer &pt) {
     // column-tiled copy: only for matrices with at least one 8192-row super-block per CU
     // and with enough column locality (HPRLP_NO_TILED=1 disables; thresholds overridable for tests)
-    const char *no = std::getenv("HPRLP_NO_TILED");
+    const char *no = env_get("HPRLP_NO_TILED");
     // (a stream of its own for the build was measured: the stall beside the value upload is the runtime's lock, not a stream wait)
     const hipStream_t bs = nullptr;
     if (!(no && no[0] == '1')) {
-        const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
-        const char *md = std::getenv("HPRLP_TILED_MIN_DENSE");
+        const char *mr = env_get("HPRLP_TILED_MIN_ROWS");
+        const char *md = env_get("HPRLP_TILED_MIN_DENSE");
         // measured on shard-shaped matrices of the banded benchmark: 305 super-blocks 0.31 ms tiled vs
         // 0.38 ms stream, 153 super-blocks 0.21 ms both -> one super-block per CU is the break-even
         // (round 2: matrices with fewer super-blocks than CUs run the split form -- several workgroups per super-block)
@@ -436,7 +437,7 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         //  * no long rows: a row's entries beyond four per tile go to the remainder list, where ONE lane adds a row's
         //    consecutive products (two dependent LDS reads each): five rows of 3000 entries took that launch from 31 to 203
         //    us.  Such matrices keep the stream kernel, which spreads a long row over a wave or several.
-        const char *mc = std::getenv("HPRLP_TILED_MIN_COLS");
+        const char *mc = env_get("HPRLP_TILED_MIN_COLS");
         const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (short_form ? (1 << 19) : 800000));  // (800 k: as kPbMinCols, a vector beyond one L2)
         const int longest = longest_row;  // (describe_when)
         declined_shape = cols < min_cols || longest > kTileMaxRow;
@@ -457,18 +458,18 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // all-remainder form that used to follow took 0.138 / 0.149; grid PDE-control LP (0.11 / 0.20): stream 0.0245 against
         // 0.0361 ms in the lowered fused form.  From 0.37 lines per entry on (band 4000) the fused tiled form wins (0.089 / 0.124).
         declined_coalesced = false;
-        if (!declined_shape && line_density <= kStreamLineDensity && !mr && min_dense_override < 0.0 && std::getenv("HPRLP_TILED_ANYWAY") == nullptr)
+        if (!declined_shape && line_density <= kStreamLineDensity && !mr && min_dense_override < 0.0 && env_get("HPRLP_TILED_ANYWAY") == nullptr)
             declined_shape = declined_coalesced = true;
         if (!declined_shape && rb == kTileRows && (rows + rb - 1) / rb < workgroup_slots() && xcd_gather_bytes > 0.0 &&
-            xcd_gather_bytes <= kStreamL2Bytes && std::getenv("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
+            xcd_gather_bytes <= kStreamL2Bytes && env_get("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
             declined_shape = declined_l2 = true;
         }
-        const char *ht = std::getenv("HPRLP_HOST_TILING");
+        const char *ht = env_get("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
         // A FEW long rows (dense LP columns / rows) do not have to cost the matrix the tiled kernel: they are left out of the
         // tiled copy and summed by the stream kernel's vector / split-row mode into a base vector that every tiled launch
         // adds (tiled.h: TiledDev::side_*).  At most 0.1 % of the rows (and 64) and a fifth of the nonzeros.
-        const char *nside = std::getenv("HPRLP_NO_LONG_SIDE");
+        const char *nside = env_get("HPRLP_NO_LONG_SIDE");
         if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && !host_tiling && !(nside && nside[0] == '1')) {
             const int *rp = host_rp();
             std::vector<int> long_rows;
@@ -517,7 +518,7 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                 std::cerr << "[timing]   tiled copy (device build): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, "
                           << tiled.n_steps << " steps, " << tiled.dense_entries << " entries in tiles + " << tiled.padding
                           << " padding, " << tiled.n_rem << " in the remainder list" << std::endl;
-            const char *chk = std::getenv("HPRLP_TILING_CHECK");
+            const char *chk = env_get("HPRLP_TILING_CHECK");
             if (chk && chk[0] == '1' && ci) {
                 TiledHost th;
                 const bool hok = build_tiled(rows, cols, host_rp(), ci, &th, min_rows, min_dense, rb, tile_cols, rem_cap);
@@ -602,17 +603,18 @@ void Solver::alloc_work() {
     part_y.alloc_zero(static_cast<size_t>(2) * stride_y);
     part_r.alloc_zero(static_cast<size_t>(2) * std::max(stride_x, stride_y));
     part_v.alloc_zero(static_cast<size_t>(2) * kReduceBlocks);
-    const char *ng = std::getenv("HPRLP_NO_GRAPH");
+    const char *ng = env_get("HPRLP_NO_GRAPH");
     use_graph = !(ng && ng[0] == '1') && comm == nullptr;
-    const char *no = std::getenv("HPRLP_NO_OVERLAP");
+    const char *no = env_get("HPRLP_NO_OVERLAP");
     overlap_enabled = comm != nullptr && comm->size > 1 && !(no && no[0] == '1');
     // HPRLP_OVERLAP_COMM_FIRST=1 (tests): take RCCL's launch order with the in-process group too
-    overlap_spmv_first = comm != nullptr && comm->host_blocking() && !std::getenv("HPRLP_OVERLAP_COMM_FIRST");
+    overlap_spmv_first = comm != nullptr && comm->host_blocking() && !env_get("HPRLP_OVERLAP_COMM_FIRST");
 }
 
 void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     const auto t0 = time_now();
     prm = *param;
+    env_at_setup = env_in_effect(&env_ignored_at_setup);
     HIP_CHECK(hipSetDevice(prm.device_number));
     HIP_CHECK(hipStreamCreate(&stream));
     m = m_loc = model->m;
@@ -675,8 +677,8 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
         };
         auto ht = std::make_shared<HostT>();
         std::vector<int> &trp = ht->trp, &tci = ht->tci;
-        const char *hostt = std::getenv("HPRLP_HOST_TRANSPOSE");
-        const char *dmin = std::getenv("HPRLP_DEVICE_TRANSPOSE_MIN");  // nonzero threshold (tests lower it)
+        const char *hostt = env_get("HPRLP_HOST_TRANSPOSE");
+        const char *dmin = env_get("HPRLP_DEVICE_TRANSPOSE_MIN");  // nonzero threshold (tests lower it)
         if (nnz > (dmin ? std::atol(dmin) : 4000000L) && !(hostt && hostt[0] == '1')) {
             // large matrix: transpose on the device (transpose.hip), bring the index arrays back for the host-side
             // consumers (tiled build, row statistics)
@@ -702,7 +704,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             // thread, while the tiled copy of A^T is built from the device arrays (describe_when)
             int dev = 0;
             HIP_CHECK(hipGetDevice(&dev));
-            const bool overlap_setup = std::getenv("HPRLP_NO_SETUP_OVERLAP") == nullptr;
+            const bool overlap_setup = env_get("HPRLP_NO_SETUP_OVERLAP") == nullptr;
             const int *d_trp = AT.rowptr.p;
             const int n_rows_t = n;
             std::shared_future<const int *> trp_ready =
@@ -717,7 +719,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
                     return ht->trp.data();
                 }).share();
             // the column indices of A^T are only needed on the host by the host tiled builder (or its check)
-            const char *htile = std::getenv("HPRLP_HOST_TILING"), *chk = std::getenv("HPRLP_TILING_CHECK");
+            const char *htile = env_get("HPRLP_HOST_TILING"), *chk = env_get("HPRLP_TILING_CHECK");
             const bool need_tci = (htile && htile[0] == '1') || (chk && chk[0] == '1');
             if (need_tci) {
                 tci.resize(static_cast<size_t>(nnz));
@@ -739,7 +741,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
         pt.tick("A^T upload total");
         max_row_A = std::max(max_row_A, A.longest_row);  // (describe_when; a renumbering does not change the longest row)
         max_row_AT = std::max(max_row_AT, AT.longest_row);
-        const char *ns = std::getenv("HPRLP_NO_SMALL");
+        const char *ns = env_get("HPRLP_NO_SMALL");
         use_small = !(ns && ns[0] == '1') && small_path_fits(m, n, nnz, max_row_A, max_row_AT);
         if (use_small) {
             auto by_length = [](int rows, const int *rp, DBuf<int> &out) {
@@ -794,16 +796,16 @@ constexpr long kPbMinCols = 800000;  // (round 4, tools/unstructured_ab.py with 
 constexpr double kNarrowTilesFrom = 1.2;  // choose_sb_rows: entries of a row per 2048-column tile from which the copy gets 1024-column tiles
 
 bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
-    const char *no = std::getenv("HPRLP_NO_PB_FALLBACK");
+    const char *no = env_get("HPRLP_NO_PB_FALLBACK");
     if (no && no[0] == '1') return false;
-    const char *nt = std::getenv("HPRLP_NO_TILED");
+    const char *nt = env_get("HPRLP_NO_TILED");
     if (nt && nt[0] == '1') return false;
-    static const long min_cols = std::getenv("HPRLP_PB_MIN_COLS") ? std::atol(std::getenv("HPRLP_PB_MIN_COLS")) : kPbMinCols;
-    static const long min_nnz = std::getenv("HPRLP_PB_MIN_NNZ") ? std::atol(std::getenv("HPRLP_PB_MIN_NNZ")) : 4000000L;  // (tests lower it)
+    static const long min_cols = env_get("HPRLP_PB_MIN_COLS") ? std::atol(env_get("HPRLP_PB_MIN_COLS")) : kPbMinCols;
+    static const long min_nnz = env_get("HPRLP_PB_MIN_NNZ") ? std::atol(env_get("HPRLP_PB_MIN_NNZ")) : 4000000L;  // (tests lower it)
     // a pattern whose rows stay near a diagonal keeps the stream kernel: each XCD's eighth of the rows gathers from a window of the
     // vector that its L2 holds (Solver::choose_sb_rows: xcd_gather_bytes; 0 = not estimated).  1M x 1M, band 2000, 20 per row (the
     // tiled build declines it: too many entries of a row per tile): stream 0.107 ms per half-step, all-remainder form 0.149.
-    const bool in_l2 = M.xcd_gather_bytes > 0.0 && M.xcd_gather_bytes <= kStreamL2Bytes && std::getenv("HPRLP_PB_MIN_COLS") == nullptr;
+    const bool in_l2 = M.xcd_gather_bytes > 0.0 && M.xcd_gather_bytes <= kStreamL2Bytes && env_get("HPRLP_PB_MIN_COLS") == nullptr;
     return !comm && !M.view.tiled.valid && M.declined_sparse && !in_l2 && M.view.cols >= min_cols && M.view.nnz >= min_nnz;
 }
 
@@ -834,7 +836,7 @@ static int whole_rounds_height(int rows, int slots) {
 void Solver::choose_pb_rows(DeviceMatrix &M, DeviceMatrix &other, int rows, int other_rows) {
     M.rem_cap = kTileRemCap;
     if (comm) return;
-    if (!std::getenv("HPRLP_TILE_ROWS")) {
+    if (!env_get("HPRLP_TILE_ROWS")) {
         const int slots = workgroup_slots();
         // at most kPbRowsMax rows (the all-remainder kernel's accumulators, kernels.hip: k_pb_fused): larger matrices take more rounds
         auto height = [&](int nrows) {
@@ -848,8 +850,8 @@ void Solver::choose_pb_rows(DeviceMatrix &M, DeviceMatrix &other, int rows, int 
         if (!other.view.tiled.valid) other.sb_rows = M.far_group = height(other_rows);
     }
     // (HPRLP_NO_PB_KERNEL, A/B runs: the all-remainder copy through k_tiled_fused's remainder steps, as in round 3)
-    if (M.sb_rows <= kPbRowsMax && !std::getenv("HPRLP_NO_PB_KERNEL")) M.rem_cap = kPbRemCap;
-    if (std::getenv("HPRLP_TIMING"))
+    if (M.sb_rows <= kPbRowsMax && !env_get("HPRLP_NO_PB_KERNEL")) M.rem_cap = kPbRemCap;
+    if (env_get("HPRLP_TIMING"))
         std::cerr << "[timing] no column locality: all-remainder form with super-blocks of " << M.sb_rows << " rows, remainder steps of " << M.rem_cap
                   << " entries" << std::endl;
 }
@@ -858,10 +860,10 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     A.sb_rows = A.far_group = AT.sb_rows = AT.far_group = kTileRows;
     A.tile_cols = AT.tile_cols = kTileCols;
     A.xcd_gather_bytes = AT.xcd_gather_bytes = 0.0;
-    if (const char *force = std::getenv("HPRLP_TILE_COLS")) {  // tests / A/B runs: one tile width for both matrices
+    if (const char *force = env_get("HPRLP_TILE_COLS")) {  // tests / A/B runs: one tile width for both matrices
         A.tile_cols = AT.tile_cols = std::atoi(force) <= kTileColsNarrow ? kTileColsNarrow : kTileCols;
     }
-    if (const char *force = std::getenv("HPRLP_TILE_ROWS")) {  // tests / A/B runs: one height for both matrices
+    if (const char *force = env_get("HPRLP_TILE_ROWS")) {  // tests / A/B runs: one height for both matrices
         const int R = std::max(64, std::min(kTileRows, std::atoi(force) / 64 * 64));
         A.sb_rows = A.far_group = AT.sb_rows = AT.far_group = R;
         return;
@@ -899,12 +901,12 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
     // columns holds d T / w of them on average; from about 1.2 on, segments of five and more are common (1M x 1M, band 1e4,
     // d = 19: 1.95 per 2048-column tile, 10.5 % of the entries in such segments; 1024 columns: 1.2 %).  Narrow tiles halve
     // the staged bytes per step and leave the number of steps about the same (the wide tiles of such a matrix take two).
-    if (!std::getenv("HPRLP_TILE_COLS")) {
+    if (!env_get("HPRLP_TILE_COLS")) {
         const double per_tile_a = static_cast<double>(nnz) / m * kTileCols / w_a;
         const double per_tile_at = static_cast<double>(nnz) / n * kTileCols / std::max(w_a / slope, 1.0);
         if (per_tile_a > kNarrowTilesFrom) A.tile_cols = kTileColsNarrow;
         if (per_tile_at > kNarrowTilesFrom) AT.tile_cols = kTileColsNarrow;
-        if (std::getenv("HPRLP_TIMING"))
+        if (env_get("HPRLP_TIMING"))
             std::cerr << "[timing] entries of a row per 2048-column tile: " << per_tile_a << " (A), " << per_tile_at << " (A^T) -> tiles of "
                       << A.tile_cols << " / " << AT.tile_cols << " columns" << std::endl;
     }
@@ -926,7 +928,7 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
         A.sb_rows = AT.far_group = ra;
         AT.sb_rows = A.far_group = rat;
     }
-    if (std::getenv("HPRLP_TIMING"))
+    if (env_get("HPRLP_TIMING"))
         std::cerr << "[timing] super-block heights for whole rounds of " << slots << " slots: " << ra << " (A), " << rat << " (A^T); median row span " << w_a
                   << " columns, tile bytes / entry bytes " << ratio_a << ", " << ratio_at << " -> " << (ok ? "lowered" : "full height (8192)") << std::endl;
 }
@@ -936,11 +938,11 @@ void Solver::choose_sb_rows(const LP_info_cpu *model) {
 // arrays hold P A Q, A is re-described (row blocks, tiled copy) and perm_r / perm_c are set.
 bool Solver::try_reorder(const LP_info_cpu *model) {
     if (!allow_reorder) return false;
-    const char *no = std::getenv("HPRLP_NO_REORDER");
+    const char *no = env_get("HPRLP_NO_REORDER");
     if (no && no[0] == '1') return false;
-    const char *nt = std::getenv("HPRLP_NO_TILED");
+    const char *nt = env_get("HPRLP_NO_TILED");
     if (nt && nt[0] == '1') return false;
-    const char *mr = std::getenv("HPRLP_TILED_MIN_ROWS");
+    const char *mr = env_get("HPRLP_TILED_MIN_ROWS");
     const int min_rows = mr ? std::atoi(mr) : 32 * kTileRows;
     if (comm || A.view.tiled.valid || A.declined_shape || m < min_rows || n < min_rows) return false;
     const auto t0 = time_now();
@@ -949,9 +951,9 @@ bool Solver::try_reorder(const LP_info_cpu *model) {
     ReorderStats st;
     // everything but the spectral ordering of the (small) cluster graph runs on the device, on the patterns of A and A^T
     // that are resident already; HPRLP_REORDER_HOST=1 keeps the clustering on the host (reorder.cpp, the reference form)
-    const char *hostc = std::getenv("HPRLP_REORDER_HOST");
+    const char *hostc = env_get("HPRLP_REORDER_HOST");
     const bool host_clusters = hostc && hostc[0] == '1';
-    const bool timing = std::getenv("HPRLP_TIMING") != nullptr;
+    const bool timing = env_get("HPRLP_TIMING") != nullptr;
     auto tphase = time_now();
     auto tick = [&](const char *what) {
         if (timing) std::cerr << "[timing]   reorder " << what << " " << time_since(tphase) << " s" << std::endl;
@@ -980,7 +982,7 @@ bool Solver::try_reorder(const LP_info_cpu *model) {
     st.fraction_after = device_tiling_dense_fraction(m, n, nnz, A.rowptr.p, A.col.p, d_r.p, d_c.p, stream);
     reorder_after = st.fraction_after;
     tick("tiling test (permuted)");
-    if (verbose || std::getenv("HPRLP_TIMING"))
+    if (verbose || env_get("HPRLP_TIMING"))
         std::cerr << "[reorder] tiled share of the entries " << st.fraction_before << " -> " << st.fraction_after << " (" << st.clusters
                   << " clusters, " << st.components << " components, " << st.bfs_levels << " BFS levels, " << time_since(t0) << " s)" << std::endl;
     if (st.fraction_after < 0.5) {
@@ -1025,6 +1027,7 @@ void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int c
     const auto t0 = time_now();
     prm = *param;
     comm = comm_;
+    env_at_setup = env_in_effect(&env_ignored_at_setup);
     HIP_CHECK(hipSetDevice(prm.device_number));
     HIP_CHECK(hipStreamCreate(&stream));
     m = m_glob; n = n_glob;
@@ -1091,7 +1094,7 @@ void HaloPlan::build(Comm *comm, const int *cols, long nnz, int total, int chunk
     for (double v : cnt) total_requests += static_cast<long>(v);
     const double dense = static_cast<double>(P - 1) * static_cast<double>(total);
     sparse = static_cast<double>(total_requests) <= 0.5 * dense;
-    if (const char *e = std::getenv("HPRLP_DIST_EXCHANGE")) {  // "sparse" / "allgather": same value on every rank
+    if (const char *e = env_get("HPRLP_DIST_EXCHANGE")) {  // "sparse" / "allgather": same value on every rank
         if (e[0] == 's') sparse = true;
         if (e[0] == 'a') sparse = false;
     }
@@ -1151,7 +1154,7 @@ void Solver::gather_on(double *gbuf, bool is_m, hipStream_t s) {
 // length at set-up and keeps a transport problem from turning into silently wrong iterates.
 void Solver::verify_exchange() {
     if (!comm || comm->size <= 1) return;
-    const bool inject = std::getenv("HPRLP_DIST_SELFTEST_FAIL") != nullptr;  // tests: first verdict reads "failed"
+    const bool inject = env_get("HPRLP_DIST_SELFTEST_FAIL") != nullptr;  // tests: first verdict reads "failed"
     DBuf<double> flag(1);
     // with a second communicator both transports are tested: passes 0, 1 through comm on the solver stream, passes 2, 3
     // through xcomm on the exchange stream
@@ -1237,7 +1240,6 @@ static double bnorm_sq(Solver *s) {
 // that the column-side scaling of each stored matrix can index the full vector.
 // ------------------------------------------------------------------------------------------------
 void Solver::scale() {
-    small_resid_ready = false;
     invalidate_far();
     const auto t0 = time_now();
     overlap_ready = false;  // the split copies of the shards carry matrix values
@@ -1246,7 +1248,7 @@ void Solver::scale() {
     // Every matrix-scaling pass that a Ruiz pass follows also leaves that pass's row norms (max |a| of the scaled rows, kernels.hip:
     // k_scale_matrix<.., NEXT>) in a second pair of gathered vectors, so the norm passes over the matrices are not run; the pairs
     // change roles pass by pass.  HPRLP_NO_FUSED_NORMS=1: separate norm passes (A/B runs, tests).
-    const bool fuse_norms = prm.use_Ruiz_scaling && std::getenv("HPRLP_NO_FUSED_NORMS") == nullptr;
+    const bool fuse_norms = prm.use_Ruiz_scaling && env_get("HPRLP_NO_FUSED_NORMS") == nullptr;
     DBuf<double> gsm2, gsn2;
     if (fuse_norms) {
         gsm2.alloc(static_cast<size_t>(m_pad));
@@ -1273,7 +1275,7 @@ void Solver::scale() {
         struct LogValues {
             DBuf<double> tile, far;
         } logA, logAT;
-        const bool tiled_cr = std::getenv("HPRLP_NO_TILED_CR") == nullptr;
+        const bool tiled_cr = env_get("HPRLP_NO_TILED_CR") == nullptr;
         auto log_values = [&](DeviceMatrix &M, LogValues &lv) {
             if (!tiled_cr || !cr_runs_tiled(M.view)) return;
             lv.tile.alloc(static_cast<size_t>(std::max<long>(M.tiled.n_tile, 1)));
@@ -1368,7 +1370,7 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
     double *q = gsm.p + row_off, *ATq = gsn.p + col_off, *z = sm1.p;
     // large vectors in the caller's numbering are filled on the device (last-place differences from the host's libm are
     // possible there; below the threshold the start vector is the oracle's bit for bit)
-    const bool host_start = std::getenv("HPRLP_HOST_POWER_START") != nullptr;  // (tests)
+    const bool host_start = env_get("HPRLP_HOST_POWER_START") != nullptr;  // (tests)
     if (m_loc > kDeviceStartRows && perm_r.empty() && !host_start) {
         launch_pw_start(m_loc, 1ULL, row_off, z, stream);
     } else {
@@ -1382,7 +1384,7 @@ double Solver::power_iteration(int max_iter, double tol, int *iters) {
         HIP_CHECK(hipMemcpyAsync(z, z0.data(), sizeof(double) * m_loc, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
-    const bool no_small_power = std::getenv("HPRLP_NO_SMALL_POWER") != nullptr;  // tests: the regular kernels instead
+    const bool no_small_power = env_get("HPRLP_NO_SMALL_POWER") != nullptr;  // tests: the regular kernels instead
     if (use_small && !comm && !no_small_power) {
         // Netlib-scale LP: the whole power iteration in one launch of the single-workgroup kernel (small.hip), stopping test on
         // the device; the host waits once
@@ -1494,7 +1496,7 @@ void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
 }
 
 void Solver::refresh_bound_codes() {
-    static const bool off = std::getenv("HPRLP_NO_BOUND_CODES") != nullptr;  // A/B runs: always read l and u
+    static const bool off = env_get("HPRLP_NO_BOUND_CODES") != nullptr;  // A/B runs: always read l and u
     if (off) return;
     if (n_loc > 0) {
         if (lu_code.n != static_cast<size_t>(n_loc)) lu_code.alloc(static_cast<size_t>(n_loc));
@@ -1510,7 +1512,6 @@ void Solver::refresh_bound_codes() {
 // (bench.py: the timed iterations and the solve to tolerance of a multi-GPU run use ONE solver -- a second one would need a
 // second set of communicators.)  Call init_iteration_state() / set_sigma_lambda() afterwards, as after create.
 void Solver::reset_iterates() {
-    small_resid_ready = false;
     if (y_exchange_pending) throw std::runtime_error("reset_iterates: an exchange is still pending");
     invalidate_far();
     auto zero = [&](double *p, size_t n) {
@@ -1581,7 +1582,7 @@ void Solver::prepare_overlap() {
 // The hand-off needs the PRODUCER to run the fused tiled kernel on one GPU (a super-block's rows = one source group of
 // the consumer's remainder) and the consumer to have remainder lists; HPRLP_NO_FAR_PUSH=1 keeps the pre-pass (A/B runs).
 FarPush Solver::push_into(const DeviceMatrix &consumer, const DeviceMatrix &producer) const {
-    static const bool off = std::getenv("HPRLP_NO_FAR_PUSH") && std::getenv("HPRLP_NO_FAR_PUSH")[0] == '1';
+    static const bool off = env_get("HPRLP_NO_FAR_PUSH") && env_get("HPRLP_NO_FAR_PUSH")[0] == '1';
     const TiledDev &pt = producer.view.tiled;
     if (off || comm || !pt.valid || pt.n_pieces > 0) return FarPush{};
     if (consumer.view.tiled.valid && consumer.view.tiled.G != pt.R) return FarPush{};  // a source group must be ONE super-block of the producer
@@ -1589,7 +1590,7 @@ FarPush Solver::push_into(const DeviceMatrix &consumer, const DeviceMatrix &prod
 }
 
 int Solver::x_mode_of(int i, int count) const {
-    static const bool off = std::getenv("HPRLP_STORE_X") != nullptr;  // A/B runs: every x-half reads and stores x
+    static const bool off = env_get("HPRLP_STORE_X") != nullptr;  // A/B runs: every x-half reads and stores x
     if (off || overlap_enabled || !AT.view.tiled.valid) return 0;
     return (i > 0 ? kXRebuild : 0) | (i + 1 < count ? kXNoStore : 0);
 }
@@ -1651,7 +1652,6 @@ void Solver::launch_normal_pair(bool more_follow, hipEvent_t *ev, int x_mode) {
 }
 
 void Solver::step(bool check) {
-    small_resid_ready = false;
     finish_tiling();
     if (!check) {
         launch_normal_pair();
@@ -1702,7 +1702,6 @@ hipGraphExec_t Solver::graph_for(int len) {
 
 void Solver::run_normal(int count) {
     if (count <= 0) return;
-    small_resid_ready = false;
     finish_tiling();
     if (use_small && !comm) {
         // Netlib-scale LP: all `count` iterations in one single-workgroup launch, matrices in registers (small.hip)
@@ -1725,26 +1724,10 @@ void Solver::run_normal(int count) {
 }
 
 void Solver::run_normal_then_check(int count) {
-    // Built and measured in round 4, NOT the default: the check step + the residual sums as one single-workgroup launch are bit
-    // for bit the regular kernels' vectors (tests/test_gpu_small.py), but one CU walking five SpMV passes in a row is no
-    // faster than the eight small launches it replaces, which overlap on the chip (config 2: loop 0.0300 s with it, 0.0290 s
-    // without, profiles/r04_small_check.txt).  HPRLP_SMALL_CHECK=1 switches it on.
-    const char *on = std::getenv("HPRLP_SMALL_CHECK");
-    if (!(use_small && !comm) || !(on && on[0] == '1')) {
-        run_normal(count);
-        step(true);
-        return;
-    }
-    finish_tiling();
+    // (a fused single-workgroup check + residual launch for Netlib-scale LPs was built and measured in round 4 -- no faster than
+    // the eight small launches it replaced, profiles/r04_small_check.txt -- and taken out again in round 5)
     run_normal(count);
-    // (a launch of its own: fused into the iterations' kernel the tail cost that kernel's 12-entries-per-thread instance a
-    // scratch reload per iteration)
-    const SmallArgs a{m, n, A.view.nnz, A.view.rowptr, AT.view.rowptr, AT.view.val, small_ij.p, small_posA.p,
-                      small_order_x.p, small_order_y.p, x.p, x_hat, y, l.p, u.p, c.p, last_x.p, AL.p, AU.p, last_y.p, ctrl.p};
-    const SmallTail tl{x_bar, z_bar.p, x_temp, y_bar, y_obj.p, y_temp.p, col_norm.p, row_norm.p, scal.p};
-    launch_small_iterations_check(a, 0, tl, stream);
-    invalidate_far();
-    small_resid_ready = true;
+    step(true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1768,21 +1751,6 @@ static double weighted_norm_from(Solver *s, double dot_adx_dy, double dy2, doubl
 }
 
 void Solver::compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs) {
-    if (small_resid_ready && iter != 0) {
-        // the check step's launch has left the eight sums of this state in scal[S_CX .. S_DX2] (run_normal_then_check)
-        small_resid_ready = false;
-        fetch_scalars();
-        const double obj_scale = b_scale * c_scale;
-        r->primal_obj = obj_scale * scal_h[S_CX] + obj_constant;
-        r->dual_obj = obj_scale * (scal_h[S_YOBJ_Y] + scal_h[S_XZ]) + obj_constant;
-        r->rel_gap = std::abs(r->primal_obj - r->dual_obj) / (1.0 + std::abs(r->primal_obj) + std::abs(r->dual_obj));
-        r->err_Rd = c_scale * std::sqrt(scal_h[S_RD2]) / norm_c_org;
-        r->err_Rp = b_scale * std::sqrt(scal_h[S_RP2]) / norm_b_org;
-        r->kkt = std::max(std::max(r->err_Rd, r->err_Rp), r->rel_gap);
-        if (compute_gap && rs) rs->current_gap = weighted_norm_from(this, scal_h[S_ADX_DY], scal_h[S_DY2], scal_h[S_DX2]);
-        return;
-    }
-    small_resid_ready = false;
     invalidate_far();  // the residual SpMVs refill the remainder buffers for x_bar / y_bar
     finish_tiling();
     const int gx = AT.view.grid(), gyy = A.view.grid();
@@ -1853,7 +1821,6 @@ static void check_restart(RestartState *rs, int iter, int check_iter, double sig
 
 void Solver::update_sigma_and_restart(RestartState *rs, const Residuals &r) {
     if (rs->flag <= 0) return;
-    small_resid_ready = false;
     // movement x_bar - last_x, y_bar - last_y and their norms (update_sigma, main_iterate.cu:367-404)
     launch_movement(n_loc, m_loc, x_bar, last_x.p, x_temp, y_bar, last_y.p, y_temp.p, part_v.p, kReduceBlocks,
                     kReduceBlocks, stream);
@@ -1976,7 +1943,7 @@ void Solver::solve_loop(HPRLP_results *out) {
         rs.inner += next - iter;
         iter = next;
     }
-    if (std::getenv("HPRLP_TIMING"))
+    if (env_get("HPRLP_TIMING"))
         std::cerr << "[timing] loop: " << time_since(t_loop) << " s, " << iter << " iterations; " << fetches << " scalar fetches: enqueue "
                   << fetch_enqueue_s << " s, wait " << fetch_wait_s << " s" << std::endl;
     std::strncpy(out->status, status.c_str(), sizeof(out->status) - 1);

@@ -3,12 +3,15 @@
 // (reference include/structs.h:127-277) without vendor-library handles.
 #pragma once
 
+#include <string>
+
 #include <functional>
 #include <future>
 #include <map>
 #include <memory>
 
 #include "common.h"
+#include "env.h"
 #include "dist.h"
 #include "kernels.h"
 
@@ -179,11 +182,7 @@ struct Solver {
     void reset_iterates();                                          // all iterates back to zero (as after create + scale + power iteration)
     void step(bool check);                                          // one HPR iteration
     void run_normal(int count);                                     // count normal iterations (graph replay)
-    // count normal iterations, then one check-variant iteration.  Netlib-scale LPs on one GPU: the check iteration AND the
-    // residual evaluation of the state it leaves in ONE launch of the single-workgroup kernel (small.hip: SmallTail) -- the
-    // next compute_residuals() only fetches the sums (small_resid_ready).  Everything else: run_normal + step(true).
-    void run_normal_then_check(int count);
-    bool small_resid_ready = false;
+    void run_normal_then_check(int count);                          // count normal iterations, then one check-variant iteration
     void fetch_scalars();
     void compute_residuals(int iter, bool compute_gap, Residuals *r, RestartState *rs);  // main_iterate.cu:229-309
     double weighted_norm_after_restart();                           // main_iterate.cu:486-515
@@ -206,6 +205,8 @@ struct Solver {
     std::unique_ptr<SplitShard> ovA, ovAT;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done_x = nullptr, ev_done_y = nullptr;
+    // the environment switches in effect when this solver was set up (env.h), and the test hooks found set but ignored
+    std::string env_at_setup, env_ignored_at_setup;
     bool overlap_enabled = false, overlap_ready = false, y_exchange_pending = false;
     bool overlap_spmv_first = false;  // launch order of the local SpMV and the exchange (launch_normal_pair)
     void prepare_overlap();

@@ -1,5 +1,6 @@
 // tiled.cpp -- host-side construction of the column-tiled matrix copy (see tiled.h).
 #include "tiled.h"
+#include "env.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -175,7 +176,7 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
     // 16: a GPU's usual share of the host's cores (measured on the 16-CPU quota of the test box: 8 threads 1.01 s
     // of set-up, 16 0.69 s, 32 0.73 s, 64 0.70 s)
     int nt = static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
-    if (const char *e = std::getenv("HPRLP_TILE_THREADS")) nt = std::max(1, std::atoi(e));
+    if (const char *e = env_get("HPRLP_TILE_THREADS")) nt = std::max(1, std::atoi(e));
     nt = std::min(nt, std::max(1, nsb / 4));
     std::vector<Local> loc(static_cast<size_t>(nt));
     std::vector<std::thread> th;

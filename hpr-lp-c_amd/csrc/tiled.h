@@ -167,14 +167,6 @@ struct TiledDev {
     // pre-pass of this launch) and rq[e_begin..e_end): the step's entries in (row, CSR) order, slot in P << 16 | local row
     double *P = nullptr;
     const uint32_t *rq = nullptr;
-    // all-remainder copies (round 4, build_far): the same codes in 16 bits -- slot (12 bits) | row - previous entry's row (4 bits) --
-    // in chunks of 8 entries per step, step s starting at chunk steps[s].col0; rhead: local row of a chunk's first entry; a delta
-    // of 15 says "my row is the next one of this chunk in wide_rows" (an entry behind more than 14 rows that have no entry in this
-    // step), rwide_ptr[chunk] = where the chunk's wide rows start.  Built with HPRLP_PB_CODES16=1 only (measured: no net gain), else null.
-    const uint16_t *rq16 = nullptr;
-    const uint16_t *rhead = nullptr;
-    const uint32_t *rwide_ptr = nullptr;
-    const uint16_t *wide_rows = nullptr;
     // remainder entries, source side (grouped by column / kFarGroup, ascending P position inside a group)
     int n_groups = 0;
     const int *f_gptr = nullptr;      // n_groups + 1
@@ -227,8 +219,6 @@ struct DeviceTiled {
     DBuf<double> tval;
     DBuf<double> P, f_val;
     DBuf<uint32_t> rq;
-    DBuf<uint16_t> rq16, rhead, wide_rows;
-    DBuf<uint32_t> rwide_ptr;
     DBuf<int> f_gptr, f_pos, f_perm;
     DBuf<int> f_rptr, f_rk, f_rp;
     DBuf<uint16_t> f_lcol;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.h"
+#include "env.h"
 #include "kernels.h"
 #include "tiled.h"
 
@@ -341,7 +342,7 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
     // a lowered super-block height (tiled.h) was chosen so that the slots get whole super-blocks: pieces only below one per CU
     if (view.R < kTileRows && nsb >= cus) want = 0;
     if (view.rem_cap != kTileRemCap) want = 0;  // (k_tiled_part adds remainder steps of kTileRemCap entries; the all-remainder form has its own fused kernel)
-    if (const char *e = std::getenv("HPRLP_TILE_PIECES")) want = std::max(0, std::atoi(e));
+    if (const char *e = env_get("HPRLP_TILE_PIECES")) want = std::max(0, std::atoi(e));
     if (want > 0 && nsb > 0) {
         std::vector<int> h_ptr(static_cast<size_t>(nsb) + 1), h_mid(static_cast<size_t>(nsb));
         sb_ptr.download(h_ptr.data(), h_ptr.size());
@@ -401,12 +402,12 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
         view.slot_ptr = slot_ptr.p;
         view.segs = segs.p;
         view.parts = parts.p;
-        if (const char *e = std::getenv("HPRLP_TILE_STAMPS"); e && e[0] == '1' && !view.repeats) {
+        if (const char *e = env_get("HPRLP_TILE_STAMPS"); e && e[0] == '1' && !view.repeats) {
             stamps.alloc_zero(static_cast<size_t>(np) * 16);
             view.stamps = stamps.p;
         }
     }
-    if (const char *e = std::getenv("HPRLP_WG_TIMES"); e && (e[0] == '1' || e[0] == '2') && view.grid > 0) {
+    if (const char *e = env_get("HPRLP_WG_TIMES"); e && (e[0] == '1' || e[0] == '2') && view.grid > 0) {
         wgtimes.alloc_zero(static_cast<size_t>(view.grid) * 8);
         view.wgtimes = wgtimes.p;
         view.wg_filter = e[0] == '2';
@@ -423,7 +424,7 @@ void DeviceTiled::finish_schedule(hipStream_t s) {
         if (h[1] > 0) rot_period = static_cast<int>((h[0] + h[1] - 1) / h[1]);
         view.repeats = h[2] > 0;
     }
-    if (const char *e = std::getenv("HPRLP_TILE_ROT")) rot_period = std::atoi(e);
+    if (const char *e = env_get("HPRLP_TILE_ROT")) rot_period = std::atoi(e);
     if (rot_period > 0) hipLaunchKernelGGL(k_rotation, dim3(grid_for(nsb)), dim3(kThreads), 0, s, nsb, rot_period, view.T, sb_ptr.p, sb_mid.p, steps.p);
     HIP_CHECK(hipStreamSynchronize(s));
 }
@@ -651,54 +652,6 @@ __global__ void __launch_bounds__(kThreads) k_far_fill_q(int n, const unsigned l
     rq[i] = (static_cast<uint32_t>(slot) << 16) | static_cast<uint32_t>(rrow[e]);
 }
 
-// key[i] = step of entry i << 32 for every remainder entry (one workgroup per super-block), the form k_far_fill_q16 reads
-__global__ void __launch_bounds__(kThreads) k_far_step_keys(int nsb, const int *__restrict__ sb_ptr, const int *__restrict__ sb_mid,
-                                                           const TileStep *__restrict__ steps, unsigned long long *__restrict__ key) {
-    const int sb = blockIdx.x;
-    if (sb >= nsb) return;
-    for (int s = sb_mid[sb]; s < sb_ptr[sb + 1]; ++s) {
-        const TileStep st = steps[s];
-        for (int e = st.e_begin + threadIdx.x; e < st.e_end; e += kThreads) key[e] = static_cast<unsigned long long>(s) << 32;
-    }
-}
-
-// 16-bit codes of an all-remainder copy from its 32-bit ones (tiled.h: TiledDev::rq16): entry i of step `step` is entry
-// j = i - e_begin of the step, chunk j / 8 from the step's chunk base (TileStep::col0).  A row gap of more than 14 inside a chunk
-// (a step holds about one entry per row: runs of rows without one are rare but do occur) is written as 15 = "take the next row of
-// this chunk from the wide list".  Pass 1 writes the codes, the head rows and a flag per wide entry; after a scan of the flags pass 2
-// files the wide rows in entry order and gives every chunk the list position of its first one.
-__global__ void __launch_bounds__(kThreads) k_far_fill_q16(int n, const unsigned long long *__restrict__ skey, const TileStep *__restrict__ steps,
-                                                          const uint32_t *__restrict__ rq, uint16_t *__restrict__ rq16,
-                                                          uint16_t *__restrict__ rhead, int *__restrict__ wide_flag, int *__restrict__ over) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const TileStep st = steps[static_cast<int>(skey[i] >> 32)];
-    const int j = i - st.e_begin, chunk = st.col0 + (j >> 3);
-    const uint32_t c = rq[i], row = c & 0xffffu, slot = c >> 16;
-    uint32_t delta = 0;
-    if (j & 7) {
-        delta = row - (rq[i - 1] & 0xffffu);
-        if (delta > 14u) delta = 15;
-    } else {
-        rhead[chunk] = static_cast<uint16_t>(row);
-    }
-    wide_flag[i] = delta == 15u;
-    if (slot > 0xfffu) atomicOr(over, 1);
-    rq16[static_cast<size_t>(st.col0) * 8 + j] = static_cast<uint16_t>((slot & 0xfffu) | (delta << 12));
-}
-
-__global__ void __launch_bounds__(kThreads) k_far_fill_wide(int n, const unsigned long long *__restrict__ skey, const TileStep *__restrict__ steps,
-                                                           const uint32_t *__restrict__ rq, const int *__restrict__ wide_flag,
-                                                           const int *__restrict__ wide_pos, uint16_t *__restrict__ wide_rows,
-                                                           uint32_t *__restrict__ rwide_ptr) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const TileStep st = steps[static_cast<int>(skey[i] >> 32)];
-    const int j = i - st.e_begin;
-    if (wide_flag[i]) wide_rows[wide_pos[i]] = static_cast<uint16_t>(rq[i] & 0xffffu);
-    if ((j & 7) == 0) rwide_ptr[st.col0 + (j >> 3)] = static_cast<uint32_t>(wide_pos[i]);
-}
-
 __global__ void __launch_bounds__(kThreads) k_far_key_f(int n, int G, const int *__restrict__ e_of_p, const int *__restrict__ rcol,
                                                        unsigned long long *__restrict__ key, int *__restrict__ val) {
     const int p = blockIdx.x * kThreads + threadIdx.x;
@@ -792,9 +745,9 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
     const int n = static_cast<int>(n_rem), nsb = view.nsb;
     const int ngroups = (cols + G - 1) / G;
     DBuf<int> step_of(static_cast<size_t>(n)), sb_of(static_cast<size_t>(n));
-    const char *no2 = std::getenv("HPRLP_NO_REM2");  // diagnostic: long runs of the remainder added by one lane, as before
+    const char *no2 = env_get("HPRLP_NO_REM2");  // diagnostic: long runs of the remainder added by one lane, as before
     hipLaunchKernelGGL(k_far_step_of, dim3(nsb), dim3(kThreads), 0, s, nsb, sb_ptr.p, sb_mid.p, steps.p, rrow.p, step_of.p, sb_of.p, !(no2 && no2[0] == '1'));
-    if (std::getenv("HPRLP_TIMING")) {
+    if (env_get("HPRLP_TIMING")) {
         std::vector<TileStep> hs(static_cast<size_t>(n_steps));
         std::vector<int> hp(static_cast<size_t>(nsb) + 1), hm(static_cast<size_t>(nsb));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -872,64 +825,9 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
             view.f_rp = f_rp.p;
             view.f_maxruns = h_mx;
         }
-        if (std::getenv("HPRLP_TIMING"))
+        if (env_get("HPRLP_TIMING"))
             std::fprintf(stderr, "[timing]   source-side run tables: %d runs of %d entries (%.1f per run), most in one group %d%s\n", nruns, n,
                          static_cast<double>(n) / std::max(nruns, 1), h_mx, view.f_rk ? "" : " -- not used (too many for the producers' LDS table)");
-    }
-    view.rq16 = nullptr;
-    view.rhead = nullptr;
-    view.rwide_ptr = nullptr;
-    view.wide_rows = nullptr;
-    // (opt-in, HPRLP_PB_CODES16=1: built, tested against the oracle and measured same-box -- uniform random 2M x 2M: x-half +1.8 %,
-    // y-half -2.3 %; config-3 recipe x 30: +2 % / 0 -- the steps of the all-remainder form are bound by their LDS work, not by bytes)
-    if (const char *c16 = std::getenv("HPRLP_PB_CODES16"); view.rem_cap == kPbRemCap && kPbRemK == 8 && c16 && c16[0] == '1') {
-        // chunk bases of the steps (on the host: a few ten thousand steps), every entry's step (kin: free by now), then the codes
-        std::vector<TileStep> hs(static_cast<size_t>(n_steps));
-        steps.download(hs.data(), hs.size());
-        long chunks = 0;
-        for (auto &st : hs) {
-            st.col0 = static_cast<int>(chunks);
-            chunks += (st.e_end - st.e_begin + 7) / 8;
-        }
-        steps.upload(hs.data(), hs.size());
-        rq16.alloc_zero(static_cast<size_t>(chunks) * 8 + 8);
-        rhead.alloc_zero(static_cast<size_t>(chunks) + 8);
-        rwide_ptr.alloc_zero(static_cast<size_t>(chunks) + 8);
-        DBuf<int> over, wide_flag(static_cast<size_t>(n)), wide_pos(static_cast<size_t>(n));
-        over.alloc_zero(1);  // a slot over 4095 (cannot happen with steps of kPbRemCap entries: checked, not assumed)
-        hipLaunchKernelGGL(k_far_step_keys, dim3(view.nsb), dim3(kThreads), 0, s, view.nsb, sb_ptr.p, sb_mid.p, steps.p, kin.p);
-        hipLaunchKernelGGL(k_far_fill_q16, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kin.p, steps.p, rq.p, rq16.p, rhead.p, wide_flag.p, over.p);
-        {
-            size_t bytes = 0;
-            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, wide_flag.p, wide_pos.p, n, s));
-            DBuf<char> tmp(bytes + 16);
-            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, wide_flag.p, wide_pos.p, n, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-        }
-        int last_pos = 0, last_flag = 0, h_over = 0;
-        HIP_CHECK(hipMemcpy(&last_pos, wide_pos.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&last_flag, wide_flag.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&h_over, over.p, sizeof(int), hipMemcpyDeviceToHost));
-        const int n_wide = last_pos + last_flag;
-        wide_rows.alloc_zero(static_cast<size_t>(n_wide) + 8);
-        hipLaunchKernelGGL(k_far_fill_wide, dim3(grid_for(n)), dim3(kThreads), 0, s, n, kin.p, steps.p, rq.p, wide_flag.p, wide_pos.p, wide_rows.p, rwide_ptr.p);
-        HIP_CHECK(hipStreamSynchronize(s));
-        const int h_ov[2] = {h_over, n_wide};
-        if (!h_over) {
-            view.rq16 = rq16.p;
-            view.rhead = rhead.p;
-            view.rwide_ptr = rwide_ptr.p;
-            view.wide_rows = wide_rows.p;
-            rq.release();
-        } else {
-            rq16.release();
-            rhead.release();
-            rwide_ptr.release();
-            wide_rows.release();
-        }
-        if (std::getenv("HPRLP_TIMING"))
-            std::fprintf(stderr, "[timing]   remainder codes: %s (%d entries behind a run of more than 14 rows without an entry in their step)\n",
-                         h_over ? "32 bits" : "16 bits (slot | row delta), chunks of 8", h_ov[1]);
     }
     rcol.release(); rrow.release(); rperm.release();
     view.P = P.p;
@@ -1025,7 +923,7 @@ void DeviceTiled::dump_wgtimes() const {
         t0 = std::min(t0, h[w * 8]);
         t1 = std::max(t1, h[w * 8 + 7]);
     }
-    if (std::getenv("HPRLP_PB_STAMPS")) {  // developer build -DHPRLP_DBG_PBSTAMP=1: the slots hold phase durations of k_pb_fused (100 MHz ticks)
+    if (env_get("HPRLP_PB_STAMPS")) {  // developer build -DHPRLP_PB_PHASE_STAMPS=1: the slots hold phase durations of k_pb_fused (100 MHz ticks)
         double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int cnt = 0;
         for (int w = 0; w < view.grid; ++w) {
@@ -1044,7 +942,7 @@ void DeviceTiled::dump_wgtimes() const {
         return;
     }
     if (t1 == 0) return;
-    if (const char *f = std::getenv("HPRLP_WG_TIMES_DUMP")) {
+    if (const char *f = env_get("HPRLP_WG_TIMES_DUMP")) {
         // raw table for tools/wgtimes_analyze.py: workgroup, XCC, CU key (SE/SH/CU bits of HW_ID), start, up to 5 super-block ends, end [us]
         if (FILE *fp = std::fopen(f, "a")) {
             std::fprintf(fp, "# launch grid %d\n", view.grid);

@@ -93,6 +93,10 @@ int hprlp_last_solve_phases(double out[8]);
 /* Human-readable: which kernel form runs on A and on A^T (stream / tiled fused / tiled pieces), super-blocks, steps, share of the
  * entries in staged tiles, long rows kept aside, small-LP kernel, locality ordering.  Returns the length (truncated to cap). */
 int hprlp_solver_describe(hprlp_solver *s, char *buf, int cap);
+/* Every environment switch the library reads, one per line: "<name>\t<integrator|hook>\t<what>" (returns the text's length; buf
+ * may be NULL).  "integrator" switches are always honoured; "hook" switches (tests, measurements) only when HPRLP_TEST_HOOKS=1 is
+ * set too.  hprlp_solver_describe ends with the switches a solver was set up under, so a non-default path is never silent. */
+int hprlp_env_switches(char *buf, int cap);
 
 /* Timed normal iterations for bench.py.  mode 0: graph replay as the product runs it; wall time by
  * HIP events around the whole batch.  mode 1: eager launches with an event pair around every kernel

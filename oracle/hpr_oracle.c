@@ -585,6 +585,7 @@ int orc_solve(int m, int n, int nnz, const int *Arp, const int *Aci, const doubl
                 t->err_Rp = r.err_Rp; t->err_Rd = r.err_Rd; t->primal_obj = r.pobj; t->dual_obj = r.dobj;
                 t->gap = r.gap; t->kkt = r.kkt; t->sigma = w.sigma; t->current_gap = rs.current_gap;
                 t->lambda_max = w.lambda_max;
+                t->last_gap = rs.last_gap; t->save_gap = rs.save_gap; t->inner = (double)rs.inner;
             }
         }
         /* check_stopping, src/main_iterate.cu:406-420 (max_iter: see DESIGN.md, reference is UB) */

@@ -44,6 +44,10 @@ typedef struct {
     int iter;
     int restart_flag;
     double err_Rp, err_Rd, primal_obj, dual_obj, gap, kkt, sigma, current_gap, lambda_max;
+    /* what the restart test of this row compares current_gap with (src/main_iterate.cu:341-351), as they stand BEFORE the test:
+     * the weighted norm after the last restart, the previous check's gap, inner iterations since the restart -- the decision
+     * margins of tests/fuzz_parity.py: acceptable() */
+    double last_gap, save_gap, inner;
 } orc_trace_row;
 
 typedef struct {

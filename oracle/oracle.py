@@ -44,7 +44,8 @@ class ScalingScalars(C.Structure):
 class TraceRow(C.Structure):
     _fields_ = [("iter", C.c_int), ("restart_flag", C.c_int)] + [
         (k, C.c_double)
-        for k in ("err_Rp", "err_Rd", "primal_obj", "dual_obj", "gap", "kkt", "sigma", "current_gap", "lambda_max")
+        for k in ("err_Rp", "err_Rd", "primal_obj", "dual_obj", "gap", "kkt", "sigma", "current_gap", "lambda_max",
+                  "last_gap", "save_gap", "inner")
     ]
 
 

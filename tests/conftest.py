@@ -7,6 +7,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The parity tests force kernel forms and thresholds through the library's TEST HOOKS (csrc/env.h): honoured only with this set.
+# With no hook set the library runs its default path, as in production (tests/test_gpu_edge.py checks that a hook WITHOUT this
+# is ignored and reported).
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -1,7 +1,10 @@
 """Randomised parity sweep (run by hand / by tests/test_gpu_fuzz.py): planted LPs of many shapes through the whole GPU
-solve and through the oracle's solve; same status and iteration count (up to a rare restart fork), objective within
-10*tol of the planted optimum.  Shapes cover the small-LP kernel, the stream kernel with long rows, and the tiled
-kernel (forced)."""
+solve and through the oracle's solve; same status and iteration count, objective within 100*tol of the planted optimum.
+Shapes cover the small-LP kernel, the stream kernel with long rows, and the tiled kernel (forced).
+
+A run whose iteration count differs from the oracle's passes only as a FORK, decided by a rule (round 5; rounds 2-4 accepted
+|d iter| <= 0.1 iter + 150 and followed the outliers by hand with tools/fork_trace.py): the two logs of check steps -- the
+GPU's (hprlp_solver_run) and the oracle's -- are compared row by row, see fork_verdict()."""
 import os
 import sys
 
@@ -12,21 +15,126 @@ sys.path.insert(0, HERE)
 from conftest import hprlp, lpgen  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
+# fork_verdict(): the rule's constants
+EARLY_ROWS = 10        # the first rows of the two logs ...
+EARLY_TOL = 1e-9       # ... agree to this (relative; sigma, KKT error, restart gap)
+GROWTH_FLOOR = 1e-13   # differences below this are rounding noise: growth is measured from here
+GROWTH_MAX = 1e4       # a new largest difference may exceed the previous largest by at most this factor per check row (largest seen
+                       # on 72 intact runs, profiles/r05_fuzz_parity_seed*.txt: 1.6e3; a defect in a path taken later jumps from 1e-13 to 1e-8 and more)
+MARGIN_FACTOR = 10.0   # the oracle's decision margin at the fork must be below this many times the logs' difference there
 
-def one(m, n, nnz, seed, tol, env, max_iter=200000):
+
+def _rel(a, b):
+    if a == b or (not np.isfinite(a) and not np.isfinite(b)):
+        return 0.0
+    if not np.isfinite(a) or not np.isfinite(b):
+        return float("inf")
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def row_difference(a, b):
+    return max(_rel(a["sigma"], b["sigma"]), _rel(a["kkt"], b["kkt"]), _rel(a["current_gap"], b["current_gap"]))
+
+
+def fork_verdict(gpu_trace, orc_trace, tol):
+    """Is a differing iteration count a fork of an ill-conditioned trajectory at a thresholded decision, or a defect?
+
+    (i)  Along the common prefix of the two logs (rows with the same iteration and the same restart decision) the relative
+         difference of sigma / KKT error / restart gap is at most EARLY_TOL on the first EARLY_ROWS rows, and from there it
+         GROWS: every new largest difference is at most GROWTH_MAX times the largest before it (floor GROWTH_FLOOR).  A kernel
+         that drops or misplaces an entry differs at once; a defect in a path taken later (check variant, restart copy) shows
+         as a jump.
+    (ii) At the first row where the logs part, the oracle's own decision was CLOSE: the smallest of |gap - 0.2 last_gap|,
+         |gap - 0.6 last_gap|, |gap - previous gap| (the restart tests, reference src/main_iterate.cu:341-351), relative to
+         last_gap -- or |KKT - tol| / tol when one log stops there and the other goes on -- is below MARGIN_FACTOR times
+         the logs' difference at that row.
+    Returns (ok, reason, details)."""
+    k = min(len(gpu_trace), len(orc_trace))
+    prefix, d = k, []
+    for i in range(k):
+        a, b = gpu_trace[i], orc_trace[i]
+        if a["iter"] != b["iter"] or a["restart_flag"] != b["restart_flag"]:
+            prefix = i
+            break
+        d.append(row_difference(a, b))
+    info = {"prefix_rows": prefix, "rows": (len(gpu_trace), len(orc_trace))}
+    if prefix < EARLY_ROWS:
+        return False, f"the logs part after {prefix} rows (fewer than {EARLY_ROWS})", info
+    early = max(d[:EARLY_ROWS])
+    info["early_max"] = early
+    if not early <= EARLY_TOL:
+        return False, f"the first {EARLY_ROWS} rows differ by {early:.2e} (more than {EARLY_TOL:.0e})", info
+    largest, worst_ratio, worst_row = max(d[0], GROWTH_FLOOR), 0.0, -1
+    for i in range(1, prefix):
+        if d[i] > largest:
+            ratio = d[i] / largest
+            if ratio > worst_ratio:
+                worst_ratio, worst_row = ratio, i
+            largest = d[i]
+    info.update(largest_difference=largest if prefix else 0.0, worst_growth=worst_ratio, worst_growth_row=worst_row)
+    if worst_ratio > GROWTH_MAX:
+        return False, (f"jump: the difference grows {worst_ratio:.1e}-fold in one check row (row {worst_row}, iteration "
+                       f"{gpu_trace[worst_row]['iter']})"), info
+    last = d[prefix - 1]
+    if prefix == k and len(gpu_trace) == len(orc_trace):
+        return True, "no fork: the two logs make the same decisions at the same iterations throughout", info
+    if prefix < k:
+        a, b = gpu_trace[prefix], orc_trace[prefix]
+        if a["iter"] != b["iter"]:
+            return False, f"row {prefix}: iterations {a['iter']} / {b['iter']} differ although every decision before was the same", info
+        here = max(last, row_difference(a, b))
+        lg, cg, sg = b["last_gap"], b["current_gap"], b["save_gap"]
+        margins = [abs(cg - 0.2 * lg), abs(cg - 0.6 * lg)] + ([abs(cg - sg)] if np.isfinite(sg) else [])
+        margin = min(margins) / max(abs(lg), 1e-300)
+        what = f"restart decision {a['restart_flag']} / {b['restart_flag']} at iteration {b['iter']}"
+    else:   # one log ends where the other goes on: the stopping test
+        b = orc_trace[k - 1]
+        here = max(last, row_difference(gpu_trace[k - 1], b))
+        margin = abs(b["kkt"] - tol) / tol
+        what = f"stopping decision at iteration {b['iter']}"
+    info.update(fork=what, margin=margin, difference_at_fork=here)
+    if not margin <= MARGIN_FACTOR * here:
+        return False, f"{what}: the oracle's margin {margin:.2e} is not within {MARGIN_FACTOR:g} x the logs' difference {here:.2e}", info
+    return True, f"fork at a close decision ({what}: margin {margin:.2e}, difference {here:.2e})", info
+
+
+def gpu_trace_of(lp, tol, max_iter):
+    """The GPU's log of check steps for the same solve (step-level ABI: scale, power iteration, run)."""
+    model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+    s = hprlp.Solver(model, hprlp.Parameters(stop_tol=tol, use_presolve=False, max_iter=max_iter))
+    s.scale()
+    lam, _ = s.power_iteration()
+    s.init(-1.0, lam * 1.01)
+    r = s.run(max_trace=8192)
+    s.close()
+    model.free()
+    return r
+
+
+def one(m, n, nnz, seed, tol, env, max_iter=200000, perturb=None):
+    """perturb (tests of the rule itself): a function lp -> lp applied to the GPU's copy of the LP only -- what a kernel that
+    drops or misreads an entry amounts to."""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         lp = lpgen.planted_lp(m, n, nnz, seed, dense_col_frac=0.02 if seed % 2 else 0.0, free_frac=0.1 if seed % 3 == 0 else 0.0)
-        model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"],
-                                     lp["l"], lp["u"], lp["c"])
+        glp = perturb(lp) if perturb else lp
+        model = hprlp.Model.from_csr(glp["m"], glp["n"], glp["rowptr"], glp["colind"], glp["values"], glp["AL"], glp["AU"],
+                                     glp["l"], glp["u"], glp["c"])
         r = model.solve(hprlp.Parameters(stop_tol=tol, use_presolve=False, max_iter=max_iter))
         ref = O.solve(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
-                      params=O.Params.default(stop_tol=tol, max_iter=max_iter))
+                      params=O.Params.default(stop_tol=tol, max_iter=max_iter), max_trace=8192)
         model.free()
         rel = abs(r.primal_obj - lp["obj_star"]) / (1 + abs(lp["obj_star"]))
-        return dict(shape=(m, n, nnz, seed), status=(r.status, ref["status"]), iters=(r.iter, ref["iter"]), rel=rel,
-                    dobj=abs(r.primal_obj - ref["primal_obj"]) / (1 + abs(ref["primal_obj"])))
+        out = dict(shape=(m, n, nnz, seed), status=(r.status, ref["status"]), iters=(r.iter, ref["iter"]), rel=rel,
+                   dobj=abs(r.primal_obj - ref["primal_obj"]) / (1 + abs(ref["primal_obj"])))
+        if r.iter != ref["iter"] or r.status != ref["status"] or os.environ.get("FUZZ_TRACE_ALL"):   # (FUZZ_TRACE_ALL: calibration of the rule)
+            g = gpu_trace_of(glp, tol, max_iter)
+            if (g.status, g.iter) != (r.status, r.iter):
+                out["fork"] = (False, f"solve() and hprlp_solver_run disagree: {r.status} {r.iter} / {g.status} {g.iter}", {})
+            else:
+                out["fork"] = fork_verdict(g.trace, ref["trace"], tol)
+        return out
     finally:
         for k, v in old.items():
             if v is None:
@@ -35,7 +143,7 @@ def one(m, n, nnz, seed, tol, env, max_iter=200000):
                 os.environ[k] = v
 
 
-def sweep(count=36, tol=1e-6, max_iter=200000, seed0=2026):
+def sweep_cases(count=36, seed0=2026):
     rng = np.random.default_rng(seed0)
     out = []
     for t in range(count):
@@ -51,15 +159,24 @@ def sweep(count=36, tol=1e-6, max_iter=200000, seed0=2026):
             env = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "0.0"}
             if (t // 3) % 2 == 1:
                 env.update({"HPRLP_TILE_ROWS": str(64 * int(rng.integers(4, 33))), "HPRLP_TILE_PIECES": "0"})
-        out.append(one(m, n, nnz, (100 if seed0 == 2026 else seed0) + t, tol, env, max_iter))
+        out.append((m, n, nnz, (100 if seed0 == 2026 else seed0) + t, env))
     return out
 
 
+def sweep(count=36, tol=1e-6, max_iter=200000, seed0=2026):
+    return [one(m, n, nnz, seed, tol, env, max_iter) for (m, n, nnz, seed, env) in sweep_cases(count, seed0)]
+
+
 def acceptable(r, tol):
-    """Same status, iteration counts equal up to a late restart fork, same objective as the oracle, and an OPTIMAL
-    objective within 100*tol of the planted one (the stopping test bounds the relative KKT error, not this)."""
-    same = r["status"][0] == r["status"][1] and abs(r["iters"][0] - r["iters"][1]) <= 0.1 * r["iters"][1] + 150
-    return same and (r["status"][0] != "OPTIMAL" or (r["rel"] <= 100 * tol and r["dobj"] <= 100 * tol))
+    """Same status and iteration count as the oracle -- or a fork by fork_verdict()'s rule -- and an OPTIMAL objective within
+    100*tol of the planted one (the stopping test bounds the relative KKT error, not this); with the oracle's count also the
+    oracle's objective."""
+    same = r["status"][0] == r["status"][1] and r["iters"][0] == r["iters"][1]
+    if not same and not ("fork" in r and r["fork"][0]):
+        return False
+    if r["status"][0] != "OPTIMAL":
+        return same
+    return r["rel"] <= 100 * tol and (not same or r["dobj"] <= 100 * tol)
 
 
 if __name__ == "__main__":
@@ -70,5 +187,7 @@ if __name__ == "__main__":
         ok = acceptable(r, 1e-6)
         bad += not ok
         print(("ok  " if ok else "BAD ") + str(r), file=sys.stderr)
-    print(f"{len(res) - bad}/{len(res)} ok, identical iteration counts: {sum(r['iters'][0] == r['iters'][1] for r in res)}", file=sys.stderr)
+    forks = [r for r in res if "fork" in r]
+    print(f"{len(res) - bad}/{len(res)} ok, identical iteration counts: {sum(r['iters'][0] == r['iters'][1] for r in res)}, "
+          f"forks accepted by the rule: {sum(1 for r in forks if r['fork'][0])} of {len(forks)} differing runs", file=sys.stderr)
     sys.exit(1 if bad else 0)

@@ -209,3 +209,33 @@ def test_device_block_cache_is_keyed_by_the_owning_device():
     L = hprlp.lib()
     L.hprlp_alloc_cache_selftest.restype = C.c_int
     assert L.hprlp_alloc_cache_selftest() == 0
+
+
+def test_environment_switches_all_go_through_one_table():
+    """csrc/env.h (round 5): every HPRLP_* variable the library reads is an entry of env.cpp's table -- at most ten
+    integrator-facing ones, always honoured; the rest test hooks, honoured only under HPRLP_TEST_HOOKS=1 -- and no source
+    reads the environment past it.  hprlp_env_switches() lists the table; INTEGRATION.md carries the same names."""
+    import ctypes as C
+    import glob
+    import re
+    L = hprlp.lib()
+    n = L.hprlp_env_switches(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    assert L.hprlp_env_switches(buf, n + 1) == n
+    rows = [ln.split("\t") for ln in buf.value.decode().splitlines()]
+    assert all(len(r) == 3 and r[0].startswith("HPRLP_") and r[1] in ("integrator", "hook") and r[2] for r in rows), rows[:3]
+    table = {r[0]: r[1] for r in rows}
+    assert len(table) == len(rows)
+    assert sum(1 for k in table.values() if k == "integrator") <= 10
+    assert table["HPRLP_TEST_HOOKS"] == "integrator" and table["HPRLP_TIMING"] == "integrator" and table["HPRLP_TILE_ROWS"] == "hook"
+    used = set()
+    for f in glob.glob(os.path.join(ROOT, "hpr-lp-c_amd", "csrc", "*")):
+        src = open(f).read()
+        if not f.endswith("env.cpp"):
+            assert not re.search(r'getenv\s*\(', src), f"{f} reads the environment past env_get()"
+        used |= set(re.findall(r'env_(?:get|on)\("(HPRLP_[A-Z0-9_]+)"\)', src))
+    assert used and used <= set(table), used - set(table)
+    assert set(table) - used <= {"HPRLP_TEST_HOOKS"}, set(table) - used          # no dead entries
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [k for k in table if k not in doc]
+    assert not missing, missing

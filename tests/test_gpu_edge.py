@@ -399,3 +399,32 @@ def test_matrix_without_entries_is_refused_like_the_reference(gpu):
     with pytest.raises(Exception):
         hprlp.Model.from_csr(3, 4, np.zeros(4, np.int32), np.zeros(0, np.int32), np.zeros(0), [-1, 0, -INF], [1, 0, 2], [0, -1, 0, 2],
                              [1, 1, 5, 3], [1, -2, 0, 3])
+
+
+def test_a_test_hook_without_the_gate_is_ignored_and_reported(gpu, model_mps_arrays):
+    """csrc/env.h (round 5): HPRLP_NO_SMALL=1 (a test hook) in the environment of a process that has NOT set HPRLP_TEST_HOOKS=1
+    changes nothing -- the Netlib-scale LP still runs the single-workgroup kernel -- and hprlp_solver_describe says that the
+    variable was seen and ignored; with the gate the hook acts and the description names it.  An integrator-facing switch
+    (HPRLP_NO_GRAPH) is honoured either way."""
+    a = model_mps_arrays
+    model = hprlp.Model.from_csr(a["m"], a["n"], a["rowptr"], a["colind"], a["values"], a["AL"], a["AU"], a["l"], a["u"], a["c"])
+    saved = {k: os.environ.get(k) for k in ("HPRLP_TEST_HOOKS", "HPRLP_NO_SMALL", "HPRLP_NO_GRAPH")}
+    try:
+        os.environ["HPRLP_NO_SMALL"] = "1"
+        os.environ["HPRLP_NO_GRAPH"] = "1"
+        os.environ.pop("HPRLP_TEST_HOOKS", None)
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        d = s.describe()
+        assert s.info()["tiled"] & 4 and "single-workgroup kernel" in d                       # the hook did nothing
+        assert "switches: HPRLP_NO_GRAPH=1" in d and "ignored without HPRLP_TEST_HOOKS=1: HPRLP_NO_SMALL=1" in d, d
+        s.close()
+        os.environ["HPRLP_TEST_HOOKS"] = "1"
+        s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+        d = s.describe()
+        assert not (s.info()["tiled"] & 4) and "single-workgroup kernel" not in d
+        assert "HPRLP_NO_SMALL=1" in d.split("switches:")[1] and "ignored" not in d, d
+        s.close()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    model.free()

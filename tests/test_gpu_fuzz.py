@@ -11,3 +11,48 @@ def test_random_lps_follow_the_oracle(gpu):
     res = F.sweep(count=18, tol=1e-5, max_iter=40000)
     assert all(F.acceptable(r, 1e-5) for r in res), res
     assert sum(r["iters"][0] == r["iters"][1] for r in res) >= 15
+
+
+@pytest.mark.parametrize("case", [1, 2, 5])   # stream kernel, tiled kernel (8192-row super-blocks), tiled with a lowered height
+def test_fork_rule_rejects_a_solve_with_one_entry_dropped(gpu, case):
+    """The rule that accepts a differing iteration count (fuzz_parity.fork_verdict) must not wave a defect through: the GPU
+    solves an LP in which ONE matrix entry is dropped (what a kernel that loses a remainder entry computes: one in the middle
+    of the matrix, one at the end of the longest row), and its log is held against the oracle's log of the intact LP --
+    rejected on the first rows.  (A single entry misread by 1e-6 is below what a trajectory can show; the element-wise kernel
+    tests are what bound that.)  The
+    intact LP's log agrees with the oracle's to 1e-9 on those rows and passes the growth test along the whole common prefix."""
+    import os
+    import numpy as np
+    from oracle import oracle as O
+    m, n, nnz, seed, env = F.sweep_cases(count=6)[case]
+    tol, max_iter = 1e-5, 40000
+    lp = F.lpgen.planted_lp(m, n, nnz, seed, dense_col_frac=0.02 if seed % 2 else 0.0, free_frac=0.1 if seed % 3 == 0 else 0.0)
+    ref = O.solve(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"],
+                  params=O.Params.default(stop_tol=tol, max_iter=max_iter), max_trace=8192)
+    k = len(lp["values"]) // 2
+
+    def dropped(lp):
+        v = lp["values"].copy(); v[k] = 0.0
+        return dict(lp, values=v)
+
+    def dropped_at_row_end(lp):   # the last entry of the longest row (a chunk / segment boundary)
+        i = int(np.argmax(np.diff(lp["rowptr"])))
+        v = lp["values"].copy(); v[lp["rowptr"][i + 1] - 1] = 0.0
+        return dict(lp, values=v)
+
+    old = {q: os.environ.get(q) for q in env}
+    os.environ.update(env)
+    try:
+        good = F.gpu_trace_of(lp, tol, max_iter)
+        bad1 = F.gpu_trace_of(dropped(lp), tol, max_iter)
+        bad2 = F.gpu_trace_of(dropped_at_row_end(lp), tol, max_iter)
+    finally:
+        for q, v in old.items():
+            os.environ.pop(q, None) if v is None else os.environ.__setitem__(q, v)
+    ok, why, info = F.fork_verdict(good.trace, ref["trace"], tol)
+    assert info["prefix_rows"] >= F.EARLY_ROWS and info["early_max"] <= F.EARLY_TOL and info.get("worst_growth", 0.0) <= F.GROWTH_MAX, (why, info)
+    assert good.iter == ref["iter"] or ok, (why, info)
+    for bad in (bad1, bad2):
+        ok, why, info = F.fork_verdict(bad.trace, ref["trace"], tol)
+        assert not ok, (why, info)
+        assert "rows differ" in why or "fewer than" in why or "jump" in why, why

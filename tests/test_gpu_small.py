@@ -28,7 +28,6 @@ def iterate_states(model, prm, plan, no_small):
     # (what is compared bit for bit are the ITERATION kernels: lambda_max comes from the regular power iteration in both runs;
     # the single-launch one adds its dot products in another order -- test_small_power_iteration_matches_... below)
     os.environ["HPRLP_NO_SMALL_POWER"] = "1"
-    os.environ["HPRLP_SMALL_CHECK"] = "1"   # the fused check + residual launch (off by default: measured no faster)
     try:
         s = hprlp.Solver(model, prm)
         assert bool(s.info()["tiled"] & 4) == (not no_small)
@@ -44,15 +43,13 @@ def iterate_states(model, prm, plan, no_small):
             out.append({k: s.get(k) for k in VECS + (CHECK_VECS if check else ())})
             out[-1]["k"] = (s.scalars()["kx"], s.scalars()["ky"])
             if check:
-                # right behind a check step: on the small path the step's own launch has formed the sums (small.hip: SmallTail),
-                # the call only fetches them; otherwise the regular residual kernels run
+                # right behind a check step: the regular residual kernels on the state the check step left
                 res_after_check.append(s.residuals(done, True))
         res = s.residuals(done, True)
         s.close()
         return out, res, res_after_check
     finally:
         os.environ.pop("HPRLP_NO_SMALL_POWER", None)
-        os.environ.pop("HPRLP_SMALL_CHECK", None)
         if old is None:
             os.environ.pop("HPRLP_NO_SMALL", None)
         else:
@@ -96,13 +93,10 @@ def test_small_kernel_equals_regular_kernels_bit_for_bit(gpu, shape):
     model.free()
 
 
-@pytest.mark.parametrize("fused_check", [False, True])
 @pytest.mark.parametrize("dense", [0.0, 0.01])
-def test_small_kernel_matches_oracle(gpu, dense, fused_check, monkeypatch):
+def test_small_kernel_matches_oracle(gpu, dense):
     """Normal steps by the single-workgroup kernel, check steps by the regular kernels, against the oracle: bit for bit when no
     row has more than 64 entries (kLongRow: the regular kernels add longer rows wave-wide), to rounding otherwise."""
-    if fused_check:   # check step + residual sums in one single-workgroup launch (small.hip: SmallTail)
-        monkeypatch.setenv("HPRLP_SMALL_CHECK", "1")
     m, n = 400, 650
     lp = lpgen.planted_lp(m, n, 4000, 8, dense_col_frac=dense)
     model = make(lp)

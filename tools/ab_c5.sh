@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of library variants on a bench workload: tools/ab_c5.sh "default head default head" [workload]
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 libs=${1:-default}
 wl=${2:-c5}
 for l in $libs; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B over (library variant, environment) pairs: usage  bash tools/ab_env.sh "w1 w2" "name|ENV1=.. ENV2=.." ...   (name: base or a variant)
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 wls=$1; shift
 for w in $wls; do
   for spec in "$@"; do

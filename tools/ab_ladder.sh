@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of library variants (lib/variants/libhprlp_<name>.so, `make variant`) on ladder points: half-step times per variant.
 # usage: bash tools/ab_ladder.sh "default norem nopush" "unstructured_4e7 band_2e7"
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 libs=${1:-default}
 points=${2:-unstructured_4e7}
 for p in $points; do

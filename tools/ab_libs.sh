@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of developer variants of the library (make variant NAME=..): usage  bash tools/ab_libs.sh "w1 w2" base name1 name2 ...
 # ("base" = lib/libhprlp.so); prints it/s and the half-step times per workload and variant
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 wls=$1; shift
 for w in $wls; do
   for v in "$@"; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Config 4 per chunk width of the batched panels (HPRLP_BATCH_CHUNK): kernel times of the half-step kernels (rocprofv3 kernel trace)
 # and their HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes).  usage (inside one gpurun call):  bash tools/c4_chunks.sh "64 8"
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 export TMPDIR=/tmp
 for c in $1; do
   out=/tmp/c4c_$c; rm -rf $out

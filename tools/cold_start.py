@@ -7,6 +7,8 @@ environment adds the set-up phases on stderr.  Run it in a fresh process:
 """
 import ctypes as C
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import sys
 import time
 

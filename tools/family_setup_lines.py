@@ -2,6 +2,8 @@
 """Set-up decisions of the library (HPRLP_TIMING=1 lines: heights, tile widths, line density, forms) for ladder points / families.
 usage: python tools/family_setup_lines.py POINT [POINT ...]   (bench.py: LADDER_POINTS / FAMILY_POINTS keys)"""
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["HPRLP_TIMING"] = "1"

@@ -3,6 +3,8 @@ single-workgroup kernels off (regular kernels), and at a higher iteration limit 
 fork at a thresholded restart decision that every summation order takes differently?
 usage: python tools/fork_case.py m n nnz seed [max_iter]"""
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import fuzz_parity as F  # noqa: E402

@@ -13,6 +13,8 @@ import datetime
 import glob
 import json
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import subprocess
 import sys
 

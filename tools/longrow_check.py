@@ -3,6 +3,8 @@
 the iterates of the tiled path (long rows aside, hand-off on) against those of the stream kernel on the same model.
 usage: python tools/longrow_check.py [rows_in_millions]   (developer check)"""
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import sys
 
 import numpy as np

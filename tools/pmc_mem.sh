@@ -2,6 +2,7 @@
 # Memory-path counters (L1 <-> L2 latency, TLB, L2 -> fabric queues, TA stalls) of the tiled kernels for one library variant, in
 # separate rocprofv3 --pmc passes (the TA_* set is split over two passes: in one, rocprofv3 aborted with "Request exceeds the
 # capabilities of the hardware to collect" -- round 3, gpurun_out/pmcmem_*/p7.err).  usage (inside one gpurun call, repo root):  bash tools/pmc_mem.sh NAME [workload]   (NAME: base | variant)
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 name=${1:-base}; wl=${2:-c5}
 if [ "$name" = base ]; then lib=$PWD/lib/libhprlp.so; else lib=$PWD/lib/variants/libhprlp_$name.so; fi
 out=$PWD/gpurun_out/pmcmem_$name

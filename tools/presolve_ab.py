@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Iterations of solve() on one test LP with the presolve stages switched on and off (developer check)."""
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 # Collects, on the GPU box, what profiles/ holds for config 5: the rocprofv3 kernel-trace statistics of the bench command and the
 # FETCH_SIZE / WRITE_SIZE counters in separate passes (gpurun refuses counter passes combined with other trace domains).
 # usage (from the repo root, inside one gpurun call):  bash tools/profile_c5.sh v7   ->  gpurun_out/prof_v7/
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 set -e
 tag=${1:-run}
 out=$PWD/gpurun_out/prof_$tag

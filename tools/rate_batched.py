@@ -2,6 +2,8 @@
 """Config 4 (bench.py's recipe: config-3 matrix, 64 perturbed members) at a fixed 1500 iterations: batch-iterations/s, three
 runs.  Developer A/B of the batched kernels (HPRLP_LIB picks the library, HPRLP_BATCH_CHUNK the chunk width)."""
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import sys
 
 import numpy as np

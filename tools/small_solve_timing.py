@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where the wall time of a whole solve() goes on the small configs (2 and 3): phases from HPRLP_TIMING.  Developer check."""
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import sys
 import time
 

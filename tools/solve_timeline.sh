@@ -3,6 +3,7 @@
 # rocprofv3 --kernel-trace, consecutive launches of one kernel folded into a line (count, busy time, idle gaps before / inside),
 # beside the library's own phase table (HPRLP_TIMING=1).  usage (repo root, inside one gpurun call):
 #   bash tools/solve_timeline.sh TAG [workload]   ->  gpurun_out/timeline_TAG.txt
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 tag=${1:-run}; wl=${2:-c5}
 out=$PWD/gpurun_out/timeline_$tag
 mkdir -p "$out"

@@ -1,3 +1,4 @@
+export HPRLP_TEST_HOOKS=1  # the switches below are test hooks (csrc/env.h)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 bash tools/ktrace.sh c5e --no-cpu --no-side --no-solve --steps 50 --warmup 10 --workload c5_eighth 2>&1 | head -12
 for sp in 1 2 3 6 8; do

@@ -3,6 +3,8 @@
 requirement (every entry through the propagation-blocking remainder).  Finds the column count from which the latter wins
 (Solver::pb_fallback_wanted).  usage: python tools/unstructured_ab.py [rows_in_millions ...]"""
 import os
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
 import subprocess
 import sys
 
