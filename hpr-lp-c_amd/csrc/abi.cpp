@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <iomanip>
 #include <iostream>
 
@@ -120,6 +121,35 @@ extern "C" int hprlp_warmup(int device) {
                   << " s, code objects " << g_warm_seconds[2] << " s" << std::endl;
     return rc;
 }
+
+// The drop-in path (round 5).  A caller that comes through the reference's unchanged bindings cannot call hprlp_warmup(): the
+// model constructors do the process-wide part on the CALLING thread, once -- runtime start-up, device 0's context and first
+// stream, and the two code objects every solve launches from (kernels.hip, small.hip; the others load with their first kernel:
+// a Netlib-scale solve never pays for the tiled builders).  Quiet: a host without a GPU builds models as before (solves fail
+// loudly later).  The cost moves from the first solve() to the first create_model_* (profiles/r05_cold_start.txt); the
+// background-thread form of round 4 stays rejected (a context first touched by another thread cost the solver more).
+namespace hprlp {
+void warm_for_first_solve() {
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const auto t0 = time_now();
+        int count = 0;
+        if (hipInit(0) != hipSuccess || hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            (void)hipGetLastError();
+            return;
+        }
+        hipStream_t s = nullptr;
+        if (hipSetDevice(0) == hipSuccess && hipFree(nullptr) == hipSuccess && hipStreamCreate(&s) == hipSuccess) (void)hipStreamDestroy(s);
+        try {
+            warm_kernels_tu();
+            warm_small_tu();
+        } catch (...) {
+        }
+        (void)hipGetLastError();
+        if (env_get("HPRLP_TIMING")) std::cerr << "[timing] warm-up at model creation: " << time_since(t0) << " s" << std::endl;
+    });
+}
+}  // namespace hprlp
 
 extern "C" int hprlp_warmup_seconds(double out[4]) {
     if (!out) return -1;
@@ -914,7 +944,9 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
         std::string d = std::string(name) + ": ";
         if (!t.valid) {
             d += "stream kernel (k_spmv_fused, " + std::to_string(M.view.nblk) + " row blocks, " + std::to_string(M.view.nlong) + " split rows)";
-            if (M.declined_coalesced) d += " [tiled form not attempted: neighbouring rows gather from the same lines]";
+            if (M.declined_skew) d += " [tiled form not attempted: too many entries in long rows]";
+            else if (M.declined_imbalance) d += " [tiled form not attempted: unbalanced row blocks]";
+            else if (M.declined_coalesced) d += " [tiled form not attempted: neighbouring rows gather from the same lines]";
             else if (M.declined_l2) d += " [tiled piece form not attempted: the stream kernel's gathers stay in one L2]";
             else if (M.declined_shape) d += " [tiled form not attempted: shape]";
             else if (M.declined_sparse) d += " [tiled form declined: too few entries in dense tiles]";

@@ -151,4 +151,7 @@ int log_step(int iter);
 
 void free_lp_info_cpu_members(LP_info_cpu *model);
 
+// once per process, on the calling thread: HIP runtime, device 0's context, the code objects every solve needs (abi.cpp)
+void warm_for_first_solve();
+
 }  // namespace hprlp

@@ -228,9 +228,13 @@ extern "C" LP_info_cpu *create_model_from_arrays(int m, int n, int nnz, const in
             std::vector<int> rp, ci;
             std::vector<double> v;
             csr_transpose_host(n, m, nnz, rowPtr, colIndex, values, rp, ci, v);
-            return model_from_csr(m, n, nnz, rp.data(), ci.data(), v.data(), AL, AU, l, u, c, 0.0);
+            LP_info_cpu *mt = model_from_csr(m, n, nnz, rp.data(), ci.data(), v.data(), AL, AU, l, u, c, 0.0);
+            warm_for_first_solve();
+            return mt;
         }
-        return model_from_csr(m, n, nnz, rowPtr, colIndex, values, AL, AU, l, u, c, 0.0);
+        LP_info_cpu *mo = model_from_csr(m, n, nnz, rowPtr, colIndex, values, AL, AU, l, u, c, 0.0);
+        warm_for_first_solve();  // (abi.cpp: the process-wide part of the first solve, on the calling thread, once)
+        return mo;
     } catch (const std::exception &e) {
         std::cerr << "[error] Failed to build model: " << e.what() << std::endl;
         return nullptr;

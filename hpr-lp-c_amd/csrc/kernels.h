@@ -194,7 +194,10 @@ bool cr_runs_tiled(const CsrDev &M);
 void launch_exp_clamp(double *v, int n, hipStream_t s);
 void launch_row_norm(const CsrDev &M, double *result, int norm, hipStream_t s);
 double launch_line_density(const int *rowptr, const int *col, int rows, hipStream_t s);  // distinct 64-byte lines gathered per entry, sampled (synchronises)
-int launch_longest_row(const int *rowptr, int rows, hipStream_t s);  // max_i rowptr[i+1] - rowptr[i] (synchronises the stream)
+// max_i rowptr[i+1] - rowptr[i] (synchronises the stream); entries_in_long (optional): the entries in rows of more than `limit` entries
+int launch_longest_row(const int *rowptr, int rows, hipStream_t s, int limit = 0, long *entries_in_long = nullptr);
+// the most entries any block of `height` consecutive rows holds (synchronises the stream)
+int launch_heaviest_block(const int *rowptr, int rows, int height, hipStream_t s);
 // val = op(op(val, first), second) where first/second are the row vector or the gathered column vector
 void launch_scale_matrix(const CsrDev &M, const double *rowvec, const double *colvec_full, bool row_first,
                          bool divide, hipStream_t s, double *next_max_norm = nullptr);

@@ -1992,21 +1992,59 @@ double launch_line_density(const int *rowptr, const int *col, int rows, hipStrea
     return h[1] ? static_cast<double>(h[0]) / static_cast<double>(h[1]) : 1.0;
 }
 
-__global__ void __launch_bounds__(kThreads) k_longest_row(const int *__restrict__ rowptr, int rows, int *out) {
+__global__ void __launch_bounds__(kThreads) k_longest_row(const int *__restrict__ rowptr, int rows, int limit, int *out, unsigned long long *in_long) {
     int best = 0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < rows; i += gridDim.x * kThreads) best = max(best, rowptr[i + 1] - rowptr[i]);
+    unsigned long long lg = 0;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < rows; i += gridDim.x * kThreads) {
+        const int len = rowptr[i + 1] - rowptr[i];
+        best = max(best, len);
+        if (len > limit) lg += static_cast<unsigned long long>(len);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        best = max(best, __shfl_xor(best, off));
+        lg += __shfl_xor(lg, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (best > 0) atomicMax(out, best);
+        if (lg > 0) atomicAdd(in_long, lg);
+    }
+}
+
+// entries of the longest row; entries_in_long (optional): the entries that lie in rows of more than `limit` entries
+int launch_longest_row(const int *rowptr, int rows, hipStream_t s, int limit, long *entries_in_long) {
+    if (entries_in_long) *entries_in_long = 0;
+    if (rows <= 0) return 0;
+    DBuf<unsigned long long> out;
+    out.alloc(2);
+    HIP_CHECK(hipMemsetAsync(out.p, 0, 2 * sizeof(unsigned long long), s));
+    const int grid = std::min((rows + kThreads - 1) / kThreads, 2048);
+    hipLaunchKernelGGL(k_longest_row, dim3(grid), dim3(kThreads), 0, s, rowptr, rows, limit, reinterpret_cast<int *>(out.p), out.p + 1);
+    unsigned long long h[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (entries_in_long) *entries_in_long = static_cast<long>(h[1]);
+    return static_cast<int>(h[0] & 0xffffffffull);
+}
+
+// the most entries any block of `height` consecutive rows holds (the heaviest super-block of a tiled copy of that height)
+__global__ void __launch_bounds__(kThreads) k_heaviest_block(const int *__restrict__ rowptr, int rows, int height, int *out) {
+    const int nb = (rows + height - 1) / height;
+    int best = 0;
+    for (int b = blockIdx.x * kThreads + threadIdx.x; b < nb; b += gridDim.x * kThreads)
+        best = max(best, rowptr[min(rows, (b + 1) * height)] - rowptr[b * height]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
     if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
 }
 
-int launch_longest_row(const int *rowptr, int rows, hipStream_t s) {
-    if (rows <= 0) return 0;
+int launch_heaviest_block(const int *rowptr, int rows, int height, hipStream_t s) {
+    if (rows <= 0 || height <= 0) return 0;
     DBuf<int> out;
     out.alloc(1);
     HIP_CHECK(hipMemsetAsync(out.p, 0, sizeof(int), s));
-    const int grid = std::min((rows + kThreads - 1) / kThreads, 2048);
-    hipLaunchKernelGGL(k_longest_row, dim3(grid), dim3(kThreads), 0, s, rowptr, rows, out.p);
+    const int nb = (rows + height - 1) / height;
+    hipLaunchKernelGGL(k_heaviest_block, dim3(std::min((nb + kThreads - 1) / kThreads, 1024)), dim3(kThreads), 0, s, rowptr, rows, height, out.p);
     int h = 0;
     HIP_CHECK(hipMemcpyAsync(&h, out.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));

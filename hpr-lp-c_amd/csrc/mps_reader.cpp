@@ -292,8 +292,10 @@ extern "C" LP_info_cpu *create_model_from_mps(const char *mps_file_path) {
             return nullptr;
         }
         std::cout << "problem information: nRow = " << m << ", nCol = " << n << ", nnz A = " << nnz << std::endl << std::endl;
-        return model_from_csr(m, n, nnz, rp.data(), ci.data(), v.data(), P.lcon.data(), P.ucon.data(), P.lvar.data(),
-                              P.uvar.data(), P.c.data(), P.c0);
+        LP_info_cpu *mo = model_from_csr(m, n, nnz, rp.data(), ci.data(), v.data(), P.lcon.data(), P.ucon.data(), P.lvar.data(),
+                                         P.uvar.data(), P.c.data(), P.c0);
+        hprlp::warm_for_first_solve();  // (abi.cpp: the process-wide part of the first solve, on the calling thread, once)
+        return mo;
     } catch (const std::exception &e) {
         std::cerr << "[error] Failed to read MPS file: " << e.what() << std::endl;
         return nullptr;

@@ -238,7 +238,14 @@ static int workgroup_slots() {
     return cus * kTileResidentPerCu;
 }
 
+constexpr int kSkewRow = 256;              // build_tiled_copy: rows longer than this count as long ...
+constexpr double kMaxLongRowShare = 0.2;   // ... and a matrix with more than this share of its entries in them keeps the stream kernel
+constexpr double kMaxBlockLoad = 4.0;      // build_tiled_copy: heaviest block of sb_rows rows / mean, above which the fused tiled forms are declined
+constexpr double kPiecesMinDense = 0.75;   // build_tiled_copy: share of the entries in staged tiles below which the PIECE form is declined
 constexpr double kStreamLineDensity = 0.25;  // build_tiled_copy: at most this many 64-byte lines gathered per entry -> stream kernel
+constexpr double kStreamL2LineDensity = 0.6;  // ... and only while neighbouring rows still share lines: with a line per entry the L2 holds the window but every gather
+                                              // misses the L1 (1.5M x 1.5M, band 75 000, 0.93 lines per entry: stream 0.177 ms per half-step, pieces 0.128; the
+                                              // multicommodity-flow LP the rule was made for: 0.35 / 0.15)
 constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of the gathered vector that one 4 MiB L2 keeps beside the matrix stream
 
 // HPRLP_TIMING=1: wall time of the set-up phases on stderr
@@ -380,8 +387,11 @@ void DeviceMatrix::describe_when(int rows, int cols, long nnz_l, std::shared_fut
     if (const char *e = env_get("HPRLP_NT")) view.nt = std::atoi(e) != 0;
     try {
         longest_row = 0;
+        long_row_share = 0.0;
         if (rows > 100000) {  // (from the device copy: the host row pointers of A^T may still be on their way)
-            longest_row = launch_longest_row(rowptr.p, rows, nullptr);
+            long in_long = 0;
+            longest_row = launch_longest_row(rowptr.p, rows, nullptr, kSkewRow, &in_long);
+            long_row_share = nnz > 0 ? static_cast<double>(in_long) / nnz : 0.0;
         } else {
             const int *rp = host_rp();
             for (int i = 0; i < rows; ++i) longest_row = std::max(longest_row, rp[i + 1] - rp[i]);
@@ -449,6 +459,11 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // 40 diagonal blocks: y-half 64.9 us (512 pieces of 66 super-blocks) against 22.4 us, 10.1 k -> 18.0 k iterations/s.
         // Config 5's quarter shard (window 4.0 MB: pieces 0.31 ms, stream 0.38) keeps the pieces.
         declined_l2 = false;
+        // bytes of the vector tiles a FULL-height super-block stages against the bytes of its entries (the row span back out of
+        // Solver::choose_sb_rows' estimate): above 1 the piece form moves more tile bytes than matrix bytes (staircase LP of 12 stages,
+        // 8 entries per row, span 2.4e5 columns: pieces 0.086 ms per half-step, stream kernel 0.068)
+        const double span_est = xcd_gather_bytes > 0.0 ? std::max(0.0, xcd_gather_bytes / 8.0 - cols / 8.0) : 0.0;
+        const double tile_share_full = rows > 0 && nnz > 0 ? (span_est + static_cast<double>(kTileRows) * cols / rows) * 8.0 / (static_cast<double>(nnz) / rows * kTileRows * 11.0) : 0.0;
         line_density = (rows > 100000 && nnz > 1000000) ? launch_line_density(rowptr.p, col.p, rows, nullptr) : 1.0;
         if (pt.on) std::cerr << "[timing]   gathered 64-byte lines per entry (sampled 64-row windows): " << line_density << std::endl;
         // Rows whose neighbours gather from the same 64-byte lines (stencil rows, incidence matrices, bands a few hundred columns
@@ -461,16 +476,40 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         if (!declined_shape && line_density <= kStreamLineDensity && !mr && min_dense_override < 0.0 && env_get("HPRLP_TILED_ANYWAY") == nullptr)
             declined_shape = declined_coalesced = true;
         if (!declined_shape && rb == kTileRows && (rows + rb - 1) / rb < workgroup_slots() && xcd_gather_bytes > 0.0 &&
-            xcd_gather_bytes <= kStreamL2Bytes && env_get("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
+            xcd_gather_bytes <= kStreamL2Bytes && (line_density <= kStreamL2LineDensity || tile_share_full > 1.0) && env_get("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
             declined_shape = declined_l2 = true;
         }
         const char *ht = env_get("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
+        // Round 5, from the form-regret corpus (tools/form_regret.py, profiles/r05_form_regret.txt) -- two properties of the ROW
+        // LENGTHS that the tiled forms do not survive, whatever the columns look like:
+        //  * skew: a matrix with a fifth of its entries in rows of more than kSkewRow entries (R-MAT / Kronecker graphs: 40 %).  A
+        //    long row's entries beyond four per tile all go through the remainder steps of ONE super-block; the stream kernel
+        //    gives such a row a wave of its own.  Kronecker 2^20 x 2^20, 7.5e6 entries, y-half: piece form 0.67 ms, lowered fused
+        //    0.54-0.58, all-remainder 0.71, stream kernel 0.076.
+        //  * imbalance: the heaviest block of sb_rows consecutive rows holds more than kMaxBlockLoad times the mean (a few hundred
+        //    coupling rows at the end of a block-diagonal model).  A fused launch ends when its heaviest super-block does:
+        //    block-diagonal 1M x 1.2M with 300 rows of 900 entries behind it, y-half 0.295 ms (1984-row super-blocks) against
+        //    0.066 with the stream kernel.  (The piece form cuts its work evenly and is exempt.)
+        declined_skew = declined_imbalance = false;
+        if (!mr && min_dense_override < 0.0 && env_get("HPRLP_TILED_ANYWAY") == nullptr) {
+            if (long_row_share > kMaxLongRowShare) {   // (also for a matrix whose longest rows would be kept aside, below)
+                declined_shape = declined_skew = true;
+            } else if (!declined_shape && rows > 100000) {
+                const int nsb = (rows + rb - 1) / rb;
+                const bool pieces_expected = rb == kTileRows && nsb <= workgroup_slots();
+                const int heaviest = pieces_expected ? 0 : launch_heaviest_block(rowptr.p, rows, rb, nullptr);
+                if (static_cast<double>(heaviest) > kMaxBlockLoad * static_cast<double>(nnz) / nsb) declined_shape = declined_imbalance = true;
+            }
+            if (pt.on && (declined_skew || declined_imbalance))
+                std::cerr << "[timing]   tiled forms declined for the row lengths: " << (declined_skew ? "skew" : "imbalance") << " (share of the entries in rows over "
+                          << kSkewRow << ": " << long_row_share << ")" << std::endl;
+        }
         // A FEW long rows (dense LP columns / rows) do not have to cost the matrix the tiled kernel: they are left out of the
         // tiled copy and summed by the stream kernel's vector / split-row mode into a base vector that every tiled launch
         // adds (tiled.h: TiledDev::side_*).  At most 0.1 % of the rows (and 64) and a fifth of the nonzeros.
         const char *nside = env_get("HPRLP_NO_LONG_SIDE");
-        if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && !host_tiling && !(nside && nside[0] == '1')) {
+        if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && !host_tiling && !(nside && nside[0] == '1') && !declined_skew) {
             const int *rp = host_rp();
             std::vector<int> long_rows;
             long long_nnz = 0;
@@ -493,7 +532,15 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                 if (pt.on)
                     std::cerr << "[timing]   tiled copy without " << long_rows.size() << " long rows (" << long_nnz << " entries, longest " << longest
                               << "): " << (ok ? "" : "declined; ") << tiled.view.nsb << " super-blocks, " << tiled.n_steps << " steps" << std::endl;
-                if (ok) {
+                bool ok_kept = ok;
+                if (ok && tiled.view.n_pieces > 0 && !mr && !md && env_get("HPRLP_PIECES_ANYWAY") == nullptr) {   // (as below: kPiecesMinDense)
+                    const double staged = static_cast<double>(tiled.dense_entries) / std::max(1.0, static_cast<double>(tiled.dense_entries) + static_cast<double>(tiled.n_rem));
+                    if (staged < kPiecesMinDense) {
+                        tiled = DeviceTiled();
+                        ok_kept = false;
+                    }
+                }
+                if (ok_kept) {
                     tiled.build_far(cols, bs, gb);
                     tiled.compose_perms(map_c.p, bs);
                     tiled.set_side(rows, rp, long_rows);
@@ -504,7 +551,7 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                     declined_shape = false;
                 }
                 pt.tick("  build tiled copy (device, long rows aside)");
-                if (ok) return;
+                if (ok_kept) return;
             }
         }
         if (declined_shape) {
@@ -525,7 +572,21 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                 if (hok != ok) throw std::runtime_error("tiling check: host and device builders disagree on acceptance");
                 if (ok) tiled.compare_with(th);
             }
-            if (ok) {
+            // Round 5 (form-regret corpus): the PIECE form of a copy that stages only about half of its entries is the worst of both
+            // worlds -- every super-block's remainder steps stay with one piece, the partial sums go through memory.  Uniform random
+            // 1.2M x 1.2M, 16 per row (51 % in tiles): 0.55 ms per iteration against 0.27 in the all-remainder form; band + 30 % far
+            // entries (53 %): 0.39 against 0.28.  Such a copy is handed back as "too few entries in dense tiles": the
+            // all-remainder form follows where the matrix is large enough for it (Solver::pb_fallback_wanted), else the stream kernel.
+            if (ok && tiled.view.n_pieces > 0 && !mr && !md && min_dense_override < 0.0 && env_get("HPRLP_PIECES_ANYWAY") == nullptr) {
+                const double staged = static_cast<double>(tiled.dense_entries) / std::max(1.0, static_cast<double>(tiled.dense_entries) + static_cast<double>(tiled.n_rem));
+                if (staged < kPiecesMinDense) {
+                    if (pt.on) std::cerr << "[timing]   piece form with " << staged << " of the entries in staged tiles: declined" << std::endl;
+                    tiled = DeviceTiled();
+                    declined_sparse = true;
+                }
+            }
+            const bool kept = ok && tiled.view.valid;
+            if (kept) {
                 tiled.build_far(cols, bs, gb);  // consumes the remainder lists the check above compares
                 view.tiled = tiled.view;
                 join_values();

@@ -70,6 +70,9 @@ struct DeviceMatrix {
     bool declined_shape = false;   // ... not attempted: too few columns for staging to pay, or rows too long for the remainder list
     bool declined_l2 = false;      // ... not attempted (a case of declined_shape): piece form against a stream kernel whose gathers stay in one L2
     bool declined_coalesced = false;  // ... not attempted (a case of declined_shape): neighbouring rows gather from the same lines
+    bool declined_skew = false;       // ... not attempted (a case of declined_shape): too many of the entries in long rows
+    bool declined_imbalance = false;  // ... not attempted (a case of declined_shape): one block of sb_rows rows holds several times the mean
+    double long_row_share = 0.0;      // share of the entries in rows of more than kSkewRow entries (describe_when; 0 for small matrices)
     double line_density = 1.0;     // distinct 64-byte lines of the gathered vector per entry (kernels.hip: launch_line_density)
     double xcd_gather_bytes = 0.0; // estimate by Solver::choose_sb_rows: bytes of the gathered vector an XCD's eighth of the rows reads (0: unknown)
     void finish_tiling(hipStream_t s);  // wait for the job, upload the copy, fill its values from the CSR values

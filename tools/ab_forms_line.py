@@ -2,7 +2,7 @@
 import json
 import sys
 
-label = "stream" if sys.argv[1] == "1" else "chosen"
+label = {"1": "stream", "0": "chosen"}.get(sys.argv[1], sys.argv[1])
 for k, v in json.load(sys.stdin).items():
     a = v["kernels"].split("; A^T:")[0]
     print("%-24s %-7s x %.4f ms (%.3f)  y %.4f ms (%.3f)  %6.0f it/s | %s" % (

@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Regret of the kernel-form selection on patterns its rules were NOT tuned on.
+
+The library picks ONE kernel form per matrix from properties of its pattern.  This tool builds a corpus of
+generated patterns -- power-law row lengths, arrowhead borders, block-diagonal with coupling rows, 2-D and 3-D stencils in
+natural and random order, Kronecker graphs, staircases with dense columns, bands of 0.1 % .. 20 % width at 6 .. 60 entries per
+row, rectangular bands, 1e6 .. 6e7 entries -- and runs every one as chosen and with every form forced (test hooks, csrc/env.h);
+the table is chosen / best per pattern: iteration time = x-half + y-half launch windows (hprlp_solver_time_iterations mode 1).
+
+    python tools/form_regret.py [--only NAME[,NAME..]] [--list] [--steps 40] > table        (GPU box; ~10 minutes)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+from scipy import sparse
+
+os.environ.setdefault("HPRLP_TEST_HOOKS", "1")  # the HPRLP_* switches used here are test hooks (csrc/env.h)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+H, G = bench.H, bench.G
+
+
+# ---- patterns: name -> function returning a scipy CSR matrix (values filled in later) -----------------------------------------
+def _csr(rows, cols, m, n):
+    A = sparse.csr_matrix((np.ones(len(rows), np.float64), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def band(m, n, per_row, frac, seed=1):
+    """per_row entries per row within +- frac * n / 2 of the diagonal (no far entries)."""
+    rng = np.random.default_rng(seed)
+    half = max(1, int(frac * n / 2))
+    r = np.repeat(np.arange(m), per_row)
+    c = (r * (n / m)).astype(np.int64) + rng.integers(-half, half + 1, size=len(r))
+    c = np.abs(c)                                   # reflected at the edges (clipping would pile a dense column up there)
+    c = np.where(c > n - 1, 2 * (n - 1) - c, c)
+    return _csr(r, c, m, n)
+
+
+def power_law(m, n, mean, seed=2, local=False):
+    rng = np.random.default_rng(seed)
+    lens = np.minimum((rng.pareto(1.6, size=m) + 1.0) * mean * 0.4, 900).astype(np.int64) + 1
+    r = np.repeat(np.arange(m), lens)
+    if local:   # hubs read their neighbourhood
+        c = (r + rng.integers(-20000, 20001, size=len(r))) % n
+    else:
+        c = rng.integers(0, n, size=len(r))
+    return _csr(r, c, m, n)
+
+
+def arrowhead(m, n, per_row, frac, border, seed=3):
+    rng = np.random.default_rng(seed)
+    A = band(m, n, per_row, frac, seed)
+    rb = np.repeat(np.arange(m - border, m), 800)          # dense last rows
+    cb = rng.integers(0, n, size=len(rb))
+    cb2 = np.repeat(np.arange(n - border, n), 800)         # dense last columns
+    rb2 = rng.integers(0, m, size=len(cb2))
+    B = _csr(np.concatenate([rb, rb2]), np.concatenate([cb, cb2]), m, n)
+    return ((A + B) > 0).astype(np.float64).tocsr()
+
+
+def block_diag_coupled(blocks, bm, bn, per_row, coupling_rows, coupling_len, seed=4):
+    rng = np.random.default_rng(seed)
+    m, n = blocks * bm + coupling_rows, blocks * bn
+    r = np.repeat(np.arange(blocks * bm), per_row)
+    c = (r // bm) * bn + rng.integers(0, bn, size=len(r))
+    rc = np.repeat(np.arange(blocks * bm, m), coupling_len)
+    cc = rng.integers(0, n, size=len(rc))
+    return _csr(np.concatenate([r, rc]), np.concatenate([c, cc]), m, n)
+
+
+def stencil2d(N, nine=False, seed=None):
+    idx = np.arange(N * N).reshape(N, N)
+    offs = [(0, 0), (0, 1), (0, -1), (1, 0), (-1, 0)] + ([(1, 1), (1, -1), (-1, 1), (-1, -1)] if nine else [])
+    rs, cs = [], []
+    for di, dj in offs:
+        src = idx[max(0, -di):N - max(0, di), max(0, -dj):N - max(0, dj)]
+        dst = idx[max(0, di):N - max(0, -di), max(0, dj):N - max(0, -dj)]
+        rs.append(src.ravel()); cs.append(dst.ravel())
+    A = _csr(np.concatenate(rs), np.concatenate(cs), N * N, N * N)
+    return _shuffle(A, seed)
+
+
+def stencil3d(N, seed=None):
+    idx = np.arange(N ** 3).reshape(N, N, N)
+    rs, cs = [idx.ravel()], [idx.ravel()]
+    for ax in range(3):
+        a = [slice(None)] * 3; b = [slice(None)] * 3
+        a[ax] = slice(0, N - 1); b[ax] = slice(1, N)
+        rs += [idx[tuple(a)].ravel(), idx[tuple(b)].ravel()]
+        cs += [idx[tuple(b)].ravel(), idx[tuple(a)].ravel()]
+    return _shuffle(_csr(np.concatenate(rs), np.concatenate(cs), N ** 3, N ** 3), seed)
+
+
+def _shuffle(A, seed):
+    if seed is None:
+        return A
+    rng = np.random.default_rng(seed)
+    pr, pc = rng.permutation(A.shape[0]), rng.permutation(A.shape[1])
+    B = A[pr][:, pc].tocsr()
+    B.sort_indices()
+    return B
+
+
+def kronecker(scale, edge_factor, seed=5):
+    """R-MAT (a, b, c, d) = (0.57, 0.19, 0.19, 0.05)."""
+    rng = np.random.default_rng(seed)
+    n = 1 << scale
+    ne = edge_factor * n
+    r = np.zeros(ne, np.int64); c = np.zeros(ne, np.int64)
+    for _ in range(scale):
+        q = rng.random(ne)
+        r = 2 * r + (q >= 0.76).astype(np.int64)
+        q2 = rng.random(ne)
+        c = 2 * c + np.where(q < 0.76, q2 >= 0.75, q2 >= 0.79).astype(np.int64)   # (0.57 / 0.76, 0.19 / 0.24)
+    A = _csr(r, c, n, n)
+    # a row of more than 1024 entries keeps a matrix out of the tiled forms altogether: cap the hubs (they stay the longest rows)
+    lens = np.diff(A.indptr)
+    keep = np.ones(A.nnz, bool)
+    for i in np.nonzero(lens > 1000)[0]:
+        keep[A.indptr[i] + 1000:A.indptr[i + 1]] = False
+    rr = np.repeat(np.arange(n), lens)[keep]
+    return _csr(rr, A.indices[keep], n, n)
+
+
+def staircase_dense_cols(stages, rows, cols, per_row, dense_cols, seed=6):
+    rng = np.random.default_rng(seed)
+    m, n = stages * rows, stages * cols
+    r = np.repeat(np.arange(m), per_row)
+    st = r // rows
+    own = rng.random(len(r)) < 0.7
+    c = np.where(own, st * cols, np.maximum(st - 1, 0) * cols) + rng.integers(0, cols, size=len(r))
+    cd = np.repeat(rng.choice(n, dense_cols, replace=False), 900)
+    rd = rng.integers(0, m, size=len(cd))
+    return _csr(np.concatenate([r, rd]), np.concatenate([c, cd]), m, n)
+
+
+CORPUS = {
+    # bands of 0.1 % .. 20 % width, 6 .. 60 per row
+    "band_0.1pct_20": lambda: band(1_000_000, 1_000_000, 20, 0.001),
+    "band_0.4pct_20": lambda: band(1_000_000, 1_000_000, 20, 0.004),
+    "band_0.6pct_20": lambda: band(1_000_000, 1_000_000, 20, 0.006),
+    "band_0.8pct_20": lambda: band(1_000_000, 1_000_000, 20, 0.008),
+    "band_2pct_20": lambda: band(1_000_000, 1_000_000, 20, 0.02),
+    "band_5pct_20": lambda: band(1_500_000, 1_500_000, 20, 0.05),
+    "band_20pct_20": lambda: band(1_500_000, 1_500_000, 20, 0.2),
+    "band_0.5pct_6": lambda: band(2_000_000, 2_000_000, 6, 0.005),
+    "band_3pct_6": lambda: band(2_000_000, 2_000_000, 6, 0.03),
+    "band_1pct_60": lambda: band(600_000, 600_000, 60, 0.01),
+    "band_4pct_60": lambda: band(600_000, 600_000, 60, 0.04),
+    "band_1.3pct_40": lambda: band(600_000, 600_000, 40, 0.0133),
+    "band_6.7pct_40": lambda: band(600_000, 600_000, 40, 0.067),
+    "band_tall_1pct_12": lambda: band(3_000_000, 1_000_000, 12, 0.01),
+    "band_wide_1pct_30": lambda: band(700_000, 2_800_000, 30, 0.01),
+    "band_big_1pct_20": lambda: band(3_000_000, 3_000_000, 20, 0.01),
+    # power-law row lengths
+    "powerlaw_random_8": lambda: power_law(1_500_000, 1_500_000, 8),
+    "powerlaw_random_20": lambda: power_law(1_000_000, 1_000_000, 20),
+    "powerlaw_local_12": lambda: power_law(1_500_000, 1_500_000, 12, local=True),
+    # arrowhead / dense borders
+    "arrowhead_1pct": lambda: arrowhead(1_000_000, 1_000_000, 16, 0.01, 40),
+    "arrowhead_5pct": lambda: arrowhead(1_200_000, 1_200_000, 12, 0.05, 60),
+    # block-diagonal with coupling rows
+    "blockdiag_200x5000": lambda: block_diag_coupled(200, 5000, 6000, 12, 300, 900),
+    "blockdiag_40x50000": lambda: block_diag_coupled(40, 50_000, 40_000, 10, 500, 900),
+    "blockdiag_2000x800": lambda: block_diag_coupled(2000, 800, 1000, 8, 200, 900),
+    # stencils
+    "stencil2d_5pt_natural": lambda: stencil2d(1500),
+    "stencil2d_5pt_random": lambda: stencil2d(1500, seed=11),
+    "stencil2d_9pt_natural": lambda: stencil2d(1400, nine=True),
+    "stencil2d_9pt_random": lambda: stencil2d(1400, nine=True, seed=12),
+    "stencil3d_7pt_natural": lambda: stencil3d(130),
+    "stencil3d_7pt_random": lambda: stencil3d(130, seed=13),
+    # Kronecker graphs
+    "kronecker_20_8": lambda: kronecker(20, 8),
+    "kronecker_21_8": lambda: kronecker(21, 8),
+    "kronecker_20_16": lambda: kronecker(20, 16),
+    # staircases with dense columns
+    "staircase_60_dense": lambda: staircase_dense_cols(60, 20_000, 24_000, 10, 30),
+    "staircase_400_dense": lambda: staircase_dense_cols(400, 3000, 3500, 12, 50),
+    "staircase_12_dense": lambda: staircase_dense_cols(12, 100_000, 120_000, 8, 20),
+    # the families of the ladder at other sizes, and uniformly random patterns at sizes between the tuned points
+    "uniform_1.2M_16": lambda: band(1_200_000, 1_200_000, 16, 1.0, seed=21),
+    "uniform_4M_8": lambda: band(4_000_000, 4_000_000, 8, 1.0, seed=22),
+    "uniform_rect_3Mx1M_10": lambda: band(3_000_000, 1_000_000, 10, 1.0, seed=23),
+    "expander_x12": lambda: sparse.csr_matrix(_lp_matrix(bench.scaled_c3_lp(12, seed=31))),
+    "expander_x60": lambda: sparse.csr_matrix(_lp_matrix(bench.scaled_c3_lp(60, seed=32))),
+    "banded_far_10pct": lambda: _gen_far(1_000_000, 20, 5_000, 0.10),
+    "banded_far_30pct": lambda: _gen_far(1_000_000, 20, 5_000, 0.30),
+}
+
+
+def _lp_matrix(lp):
+    return sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(lp["m"], lp["n"]))
+
+
+def _gen_far(m, per_row, band_, far, seed=41):
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(m), per_row)
+    is_far = rng.random(len(r)) < far
+    near = np.abs(r + rng.integers(-band_, band_ + 1, size=len(r)))
+    c = np.where(is_far, rng.integers(0, m, size=len(r)), np.where(near > m - 1, 2 * (m - 1) - near, near))
+    return _csr(r, c, m, m)
+
+
+def forms(m, n):
+    low = lambda rows: str(max(1024, min(8192, (rows // 512) // 64 * 64)))
+    tiled = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "0.0", "HPRLP_TILED_ANYWAY": "1", "HPRLP_PIECES_ANYWAY": "1"}
+    return {
+        "chosen": {},
+        "stream": {"HPRLP_NO_TILED": "1"},
+        "tiled_8192": dict(tiled, HPRLP_TILE_ROWS="8192"),
+        "tiled_low": dict(tiled, HPRLP_TILE_ROWS=low(min(m, n))),
+        "tiled_low_1024": dict(tiled, HPRLP_TILE_ROWS=low(min(m, n)), HPRLP_TILE_COLS="1024"),
+        "all_remainder": {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "1.01", "HPRLP_PB_MIN_COLS": "1", "HPRLP_PB_MIN_NNZ": "1"},
+    }
+
+
+def short(desc):
+    d = desc.split("; switches:")[0]
+    out = []
+    for part in d.split("; ")[:2]:
+        if "piece form" in part: out.append("pieces" + ("+side" if "long rows aside" in part else ""))
+        elif "all-remainder" in part: out.append("all-rem")
+        elif "tiled, fused" in part:
+            import re
+            mm = re.search(r"\((\d+) rows, tiles of (\d+)", part)
+            out.append("tiled" + (f"[{mm.group(1)}x{mm.group(2)}]" if mm else "") + ("+side" if "long rows aside" in part else ""))
+        elif "stream kernel" in part: out.append("stream")
+        else: out.append("?")
+    return "/".join(out) + (" +reorder" if "locality ordering" in d else "")
+
+
+def measure(lp, env, steps):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        model = H.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+        t0 = time.time()
+        s = H.Solver(model, H.Parameters(stop_tol=1e-4, use_presolve=False))
+        setup = time.time() - t0
+        s.scale()
+        lam, _ = s.power_iteration(max_iter=20)
+        s.init(-1.0, lam * 1.01)
+        t = s.time_iterations(10, steps, 1)
+        desc = s.describe()
+        s.iterate(0, True)
+        ok = bool(np.isfinite(s.residuals(steps + 11)["kkt"]))
+        s.close(); model.free()
+        return {"x_ms": t["xhalf_ms"] / steps, "y_ms": t["yhalf_ms"] / steps, "form": short(desc), "setup_s": setup, "finite": ok}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:200]}
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--list", action="store_true")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--json", default=None, help="also write the raw records here")
+    args = ap.parse_args()
+    names = list(CORPUS) if not args.only else args.only.split(",")
+    if args.list:
+        print("\n".join(names)); return
+    sys.stdout.flush()
+    real = os.dup(1); os.dup2(2, 1)   # (the library's banner goes to the C-level stdout)
+    out = lambda s: os.write(real, (s + "\n").encode())
+    out("%-26s %9s %9s | %-28s %8s | %-14s %8s | %6s | per form: iteration ms" % ("pattern", "rows", "nnz", "chosen form", "ms", "best form", "ms", "regret"))
+    records = {}
+    for name in names:
+        t0 = time.time()
+        A = CORPUS[name]().tocsr()
+        A.sort_indices()
+        rng = np.random.default_rng(7)
+        A.data = rng.normal(size=A.nnz)
+        m, n = A.shape
+        lp = bench.planted_on(m, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64))
+        bx, by = bench.bytes_x_half(m, n, A.nnz), bench.bytes_y_half(m, n, A.nnz)
+        rec = {"m": m, "n": n, "nnz": int(A.nnz), "longest_row": int(np.diff(A.indptr).max()), "gen_s": time.time() - t0, "forms": {}}
+        for fname, env in forms(m, n).items():
+            r = measure(lp, env, args.steps)
+            if "error" not in r:
+                r["it_ms"] = r["x_ms"] + r["y_ms"]
+                r["x_frac"], r["y_frac"] = bx / (r["x_ms"] * 1e-3) / 8e12, by / (r["y_ms"] * 1e-3) / 8e12
+            rec["forms"][fname] = r
+        ok = {k: v for k, v in rec["forms"].items() if "it_ms" in v and v["finite"]}
+        ch = rec["forms"]["chosen"]
+        if "it_ms" not in ch:
+            out(f"{name:26s} chosen form failed: {ch}")
+            records[name] = rec
+            continue
+        best = min(ok, key=lambda k: ok[k]["it_ms"])
+        rec["regret"] = ch["it_ms"] / ok[best]["it_ms"]
+        per = "  ".join("%s %.4f" % (k, v["it_ms"]) if "it_ms" in v else "%s -" % k for k, v in rec["forms"].items() if k != "chosen")
+        out("%-26s %9d %9d | %-28s %8.4f | %-14s %8.4f | %6.3f | %s   [x %.3f y %.3f of 8 TB/s]" % (
+            name, m, A.nnz, ch["form"][:28], ch["it_ms"], best, ok[best]["it_ms"], rec["regret"], per, ch["x_frac"], ch["y_frac"]))
+        records[name] = rec
+    reg = sorted(v["regret"] for v in records.values() if "regret" in v)
+    if reg:
+        out("patterns %d; regret (chosen / best): median %.3f, 90th percentile %.3f, worst %.3f; within 10 %% of the best form: %d of %d" % (
+            len(reg), reg[len(reg) // 2], reg[int(0.9 * (len(reg) - 1))], reg[-1], sum(r <= 1.10 for r in reg), len(reg)))
+    if args.json:
+        json.dump(records, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
