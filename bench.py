@@ -396,6 +396,45 @@ LADDER_POINTS = {
 SHARD_POINTS = {2: "c5_shard_of_2", 4: "c5_shard_of_4", 8: "c5_shard_of_8"}
 
 
+def thread_rank_rehearsal(model, world, steps, lam):
+    """The sharded solver's REAL code path at `world` ranks -- shard extraction, halo plans, split local / remote launches, pack /
+    scatter, the exchange itself as device copies -- with the ranks as threads of this process time-sharing the ONE GPU
+    (hprlp_solver_create_local; tools/dist_rehearsal.py is the stand-alone form).  Wall time of `steps` iterations of all ranks
+    together; / world = GPU time per rank and iteration, host barriers of the in-process exchange included: an upper bound of
+    what a rank of a `world`-GPU run needs per iteration, not a measurement of one."""
+    import threading
+    group = H.Solver.local_group(world)
+    out, err = [None] * world, [None] * world
+    prm = H.Parameters(stop_tol=1e-4, use_presolve=False)
+
+    def work(rank):
+        try:
+            s = H.Solver.create_local(model, prm, rank, world, group)
+            s.scale()
+            s.init(-1.0, lam * 1.01)
+            s.iterate(5)
+            t = time.time()
+            s.iterate(steps)
+            s.residuals(steps + 6, True)   # (ends with a fetch: everything has run)
+            out[rank] = (time.time() - t, s.dist_info(), s.describe())
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            err[rank] = repr(e)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    H.Solver.free_local_group(group)
+    if any(err):
+        return {"error": str([e for e in err if e][0])[:300]}
+    ms_all = 1e3 * max(o[0] for o in out) / steps
+    mid = out[world // 2]
+    return {"ms_per_iteration_all_ranks_on_one_gpu": ms_all, "gpu_ms_per_rank_iteration": ms_all / world, "steps": steps,
+            "middle_rank_entries_received_per_iteration": mid[1]["m_received"] + mid[1]["n_received"], "middle_rank_kernels": kernel_forms(mid[2])}
+
+
 def predicted_scaling(iteration_ms_1gpu, ladder_out):
     """What the first N > 1 record can be held against: per-rank kernel time at P ranks = 2 x the y-half of the rank's shard
     (the x-half runs the same shape: rows of A^T, by the band's symmetry), x 1.05 for the split into a local-column and a
@@ -975,6 +1014,7 @@ def main():
         if out is not None:
             out["time_to_tol"] = ttt
     s.close()
+    rehearsal = None
     if rank == 0 and world == 1:
         if model is not None:
             # the metric's second half: wall time of a whole solve() to 1e-4 on the same LP (model already on the host;
@@ -998,6 +1038,14 @@ def main():
                                       "phases_s": ph}
             except Exception as e:
                 out["time_to_tol"] = {"error": str(e)}
+            if args.workload == "c5" and not args.no_ladder and not args.no_side:
+                # (while the model is still on the host) the sharded code path at 4 and 8 ranks as threads on this one GPU
+                rehearsal = {}
+                for P in (4, 8):
+                    try:
+                        rehearsal[P] = thread_rank_rehearsal(model, P, 30, lam)
+                    except Exception as e:  # noqa: BLE001
+                        rehearsal[P] = {"error": str(e)[:300]}
             model.free()
         if not args.no_side:  # before the CPU leg: its OpenMP team keeps spinning for a while and disturbs the
             try:              # latency-bound small solves
@@ -1011,6 +1059,11 @@ def main():
                 out["ladder"] = {"error": str(e)}
             if args.workload == "c5":
                 out["predicted_scaling"] = predicted_scaling(out["ms_per_step"], out["ladder"])
+                if rehearsal is not None:
+                    out["predicted_scaling"]["thread_rank_rehearsal"] = rehearsal
+                    for P, r in rehearsal.items():
+                        if "gpu_ms_per_rank_iteration" in r and f"P{P}" in out["predicted_scaling"]:
+                            out["predicted_scaling"][f"P{P}"]["speedup_bound_from_rehearsal"] = out["ms_per_step"] / r["gpu_ms_per_rank_iteration"]
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload)
