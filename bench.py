@@ -494,6 +494,21 @@ def ladder_point(key, steps=100, warmup=20, timed=True):
         lp = banded_lp(rows_, rows_, per_row_, band_)
     else:
         lp = (LADDER_POINTS.get(key) or FAMILY_POINTS[key])()
+    # A rank's two matrices are both shard-shaped and both run the tiled piece form, the x-half handing the y-half's remainder
+    # products over.  The stand-alone LP of a shard point has the (m / P) x n matrix as A only -- its A^T (n rows, most of them
+    # nearly empty) is declined by the row-block balance rule and would leave the y-half its own pre-pass: the point forces the
+    # tiled form on both (test hook), which is what a rank runs.
+    hooks = {"HPRLP_TEST_HOOKS": "1", "HPRLP_TILED_ANYWAY": "1"} if key in SHARD_POINTS.values() else {}
+    saved = {k: os.environ.get(k) for k in hooks}
+    os.environ.update(hooks)
+    try:
+        return _ladder_point_of(key, lp, steps, warmup, timed)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def _ladder_point_of(key, lp, steps, warmup, timed):
     m, n, nnz = lp["m"], lp["n"], len(lp["values"])
     model = H.Model.from_csr(m, n, lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
     del lp
