@@ -315,3 +315,62 @@ print("OK", m, n, A.nnz)
                HPRLP_NO_REORDER="1", HPRLP_NO_SMALL="1", HPRLP_TILED_MIN_DENSE="1.01")   # (1.01: the staged-tile form always declines)
     r = subprocess.run([sys.executable, "-c", code, str(seed)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_row_length_rules_keep_skewed_and_unbalanced_patterns_on_the_stream_kernel(gpu):
+    """Round 5 (solver.cpp: build_tiled_copy; profiles/r05_form_regret.txt).  Two patterns whose COLUMNS invite the tiled forms and
+    whose ROW LENGTHS do not survive them: a graph with hub rows (a third of the entries in rows of more than 256: 'too many
+    entries in long rows') and a narrow band with 300 rows of 900 entries behind it (the last block of rows holds 12 x the
+    mean: 'unbalanced row blocks').  Both keep the stream kernel, say why, and a band without the coupling rows still takes the
+    tiled form; the iterates of the declined form equal those of the forced tiled form to rounding (another summation order)."""
+    import bench_helpers as bh
+    rng = np.random.default_rng(3)
+    m = n = 1_000_000
+
+    def lp_of(A):
+        A = sparse.csr_matrix(A); A.sum_duplicates(); A.sort_indices()
+        A.data = rng.uniform(0.5, 1.5, size=A.nnz) * rng.choice([-1.0, 1.0], size=A.nnz)
+        x0 = rng.uniform(0, 1, A.shape[1]); b = A @ x0
+        return dict(m=A.shape[0], n=A.shape[1], rowptr=A.indptr.astype(np.int32), colind=A.indices.astype(np.int32), values=A.data.copy(),
+                    AL=b - 0.5, AU=b + 0.5, l=np.zeros(A.shape[1]), u=np.full(A.shape[1], 2.0), c=rng.uniform(-1, 1, A.shape[1]))
+
+    def describe(lp, env=None):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            model = hprlp.Model.from_csr(lp["m"], lp["n"], lp["rowptr"], lp["colind"], lp["values"], lp["AL"], lp["AU"], lp["l"], lp["u"], lp["c"])
+            s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+            d = s.describe()
+            s.scale(); s.init(0.7, 1.2); s.iterate(6, True)
+            st = {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar")}
+            s.close(); model.free()
+            return d, st
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+    # band of 0.8 %, 20 per row: the lowered fused tiled form (control; tools/form_regret.py: band_0.8pct_20)
+    r = np.repeat(np.arange(m), 20)
+    c = np.abs(r + rng.integers(-4000, 4001, size=len(r))); c = np.where(c > n - 1, 2 * (n - 1) - c, c)
+    band = sparse.csr_matrix((np.ones(len(r)), (r, c)), shape=(m, n))
+    d0, _ = describe(lp_of(band))
+    assert d0.startswith("A: tiled, fused"), d0
+    # the same band with 300 rows of 900 entries at the end
+    rc = np.repeat(np.arange(m - 300, m), 900); cc = rng.integers(0, n, size=len(rc))
+    coupled = band + sparse.csr_matrix((np.ones(len(rc)), (rc, cc)), shape=(m, n))
+    lp1 = lp_of(coupled)
+    d1, s1 = describe(lp1)
+    assert d1.startswith("A: stream kernel") and "unbalanced row blocks" in d1.split("; A^T:")[0], d1
+    d1f, s1f = describe(lp1, {"HPRLP_TILED_ANYWAY": "1"})
+    assert d1f.startswith("A: tiled"), d1f
+    for k in s1:
+        np.testing.assert_allclose(s1[k], s1f[k], rtol=1e-9, atol=1e-11, err_msg=k)
+    # hub rows: 2000 rows of 300-900 entries hold a third of the entries of an otherwise 4-per-row band
+    r = np.repeat(np.arange(m), 4)
+    c = np.abs(r + rng.integers(-6000, 6001, size=len(r))); c = np.where(c > n - 1, 2 * (n - 1) - c, c)
+    hubs = rng.choice(m, 3500, replace=False)
+    lens = rng.integers(300, 900, size=len(hubs))
+    rh = np.repeat(hubs, lens); ch = rng.integers(0, n, size=len(rh))
+    A = sparse.csr_matrix((np.ones(len(r) + len(rh)), (np.concatenate([r, rh]), np.concatenate([c, ch]))), shape=(m, n))
+    d2, _ = describe(lp_of(A))
+    assert d2.startswith("A: stream kernel") and "too many entries in long rows" in d2.split("; A^T:")[0], d2
