@@ -187,7 +187,8 @@ if __name__ == "__main__":
         ok = acceptable(r, 1e-6)
         bad += not ok
         print(("ok  " if ok else "BAD ") + str(r), file=sys.stderr)
-    forks = [r for r in res if "fork" in r]
-    print(f"{len(res) - bad}/{len(res)} ok, identical iteration counts: {sum(r['iters'][0] == r['iters'][1] for r in res)}, "
-          f"forks accepted by the rule: {sum(1 for r in forks if r['fork'][0])} of {len(forks)} differing runs", file=sys.stderr)
+    traced = [r for r in res if "fork" in r]
+    parted = [r for r in traced if not r["fork"][1].startswith("no fork")]   # logs that make another decision somewhere
+    print(f"{len(res) - bad}/{len(res)} ok, identical iteration counts: {sum(r['iters'][0] == r['iters'][1] for r in res)}; logs compared: {len(traced)}, "
+          f"of which {len(parted)} part from the oracle's, {sum(1 for r in parted if r['fork'][0])} of them forks by the rule", file=sys.stderr)
     sys.exit(1 if bad else 0)

@@ -4,6 +4,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -248,3 +249,28 @@ def test_bench_under_a_launcher_rank0_supervises_and_the_other_copies_wait():
     assert err.count("started ranks as child processes") == 1            # one supervisor, not two
     assert "tier 3: host-staged shared memory" in err and "rank 1: phase shard assembly" in err
     assert "no result line: every transport tier failed" in err
+
+
+def test_predicted_scaling_model_from_shard_points():
+    """bench.py: predicted_scaling() -- the model the first N > 1 record is held against: 2 x the shard's y-half x 1.05 + the exposed
+    part of the exchange, from the ladder points of the same run; a point that failed is reported as such, not guessed."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ladder = {"c5_shard_of_2": {"yhalf_ms": 0.36, "yhalf_frac_of_8000": 0.52, "kernels": "A: tiled, fused (k_tiled_fused, grid 512); A^T: x"},
+              "c5_shard_of_4": {"yhalf_ms": 0.18, "yhalf_frac_of_8000": 0.55, "kernels": "A: tiled, piece form; A^T: x"},
+              "c5_shard_of_8": {"error": "out of memory"}}
+    p = bench.predicted_scaling(1.30, ladder)
+    assert abs(p["P2"]["iteration_ms_model"] - (2 * 0.36 * 1.05 + 0.01)) < 1e-12 and abs(p["P2"]["speedup_model"] - 1.30 / (0.756 + 0.01)) < 1e-9
+    assert abs(p["P4"]["speedup_kernels_only"] - 1.30 / 0.36) < 1e-9 and p["P4"]["shard_kernel"].startswith("A: tiled, piece form")
+    assert p["P8"] == {"error": "out of memory"} and p["P1_iteration_ms"] == 1.30
+    # the real shard of a middle rank: rows [rank m / P, ...) of the SAME matrix, global columns
+    lp = None
+    bench.WORKLOADS["_t"] = (40_000, 40_000, 6, 300)
+    try:
+        lp = bench.shard_rows_lp("_t", 4)
+        full = bench.gen_banded(40_000, 40_000, 6, 300)
+    finally:
+        bench.WORKLOADS.pop("_t")
+    assert (lp["m"], lp["n"]) == (10_000, 40_000)
+    k0 = full[0][20_000]
+    assert np.array_equal(lp["colind"], full[1][k0:k0 + len(lp["colind"])]) and np.array_equal(lp["values"], full[2][k0:k0 + len(lp["values"])])
