@@ -246,6 +246,7 @@ constexpr double kStreamLineDensity = 0.25;  // build_tiled_copy: at most this m
 constexpr double kStreamL2LineDensity = 0.6;  // ... and only while neighbouring rows still share lines: with a line per entry the L2 holds the window but every gather
                                               // misses the L1 (1.5M x 1.5M, band 75 000, 0.93 lines per entry: stream 0.177 ms per half-step, pieces 0.128; the
                                               // multicommodity-flow LP the rule was made for: 0.35 / 0.15)
+constexpr double kPiecesMinRowEntries = 16.0;  // ... or while rows are thin (build_tiled_copy)
 constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of the gathered vector that one 4 MiB L2 keeps beside the matrix stream
 
 // HPRLP_TIMING=1: wall time of the set-up phases on stderr
@@ -448,7 +449,9 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         //    consecutive products (two dependent LDS reads each): five rows of 3000 entries took that launch from 31 to 203
         //    us.  Such matrices keep the stream kernel, which spreads a long row over a wave or several.
         const char *mc = env_get("HPRLP_TILED_MIN_COLS");
-        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (short_form ? (1 << 19) : 800000));  // (800 k: as kPbMinCols, a vector beyond one L2)
+        // (2^19 columns = 4 MiB = one L2.  Until round 5 the full-height form waited for 800 k columns: a 600k x 600k band of 40 000
+        // columns, 40 per row, kept the stream kernel at 0.25 of 8 TB/s where the piece form runs 0.33 and the lowered fused form 0.36)
+        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (1 << 19));
         const int longest = longest_row;  // (describe_when)
         declined_shape = cols < min_cols || longest > kTileMaxRow;
         // Round 4, late.  A matrix of fewer full-height super-blocks than workgroup slots whose height could not be lowered (its
@@ -464,6 +467,9 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // 8 entries per row, span 2.4e5 columns: pieces 0.086 ms per half-step, stream kernel 0.068)
         const double span_est = xcd_gather_bytes > 0.0 ? std::max(0.0, xcd_gather_bytes / 8.0 - cols / 8.0) : 0.0;
         const double tile_share_full = rows > 0 && nnz > 0 ? (span_est + static_cast<double>(kTileRows) * cols / rows) * 8.0 / (static_cast<double>(nnz) / rows * kTileRows * 11.0) : 0.0;
+        // ... and thin rows: a piece's cost goes with the tiles it stages, the stream kernel's with the entries (1M x 1M band of 16 000
+        // columns, 6 per row: pieces 0.060 ms per half-step, stream 0.041; 12 per row + dense borders: 0.102 / 0.088; 20 per row: 0.128 / 0.177)
+        const double entries_per_row = rows > 0 ? static_cast<double>(nnz) / rows : 0.0;
         line_density = (rows > 100000 && nnz > 1000000) ? launch_line_density(rowptr.p, col.p, rows, nullptr) : 1.0;
         if (pt.on) std::cerr << "[timing]   gathered 64-byte lines per entry (sampled 64-row windows): " << line_density << std::endl;
         // Rows whose neighbours gather from the same 64-byte lines (stencil rows, incidence matrices, bands a few hundred columns
@@ -476,7 +482,8 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         if (!declined_shape && line_density <= kStreamLineDensity && !mr && min_dense_override < 0.0 && env_get("HPRLP_TILED_ANYWAY") == nullptr)
             declined_shape = declined_coalesced = true;
         if (!declined_shape && rb == kTileRows && (rows + rb - 1) / rb < workgroup_slots() && xcd_gather_bytes > 0.0 &&
-            xcd_gather_bytes <= kStreamL2Bytes && (line_density <= kStreamL2LineDensity || tile_share_full > 1.0) && env_get("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
+            xcd_gather_bytes <= kStreamL2Bytes && (line_density <= kStreamL2LineDensity || tile_share_full > 1.0 || entries_per_row < kPiecesMinRowEntries) &&
+            env_get("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
             declined_shape = declined_l2 = true;
         }
         const char *ht = env_get("HPRLP_HOST_TILING");

@@ -228,7 +228,9 @@ def short(desc):
     d = desc.split("; switches:")[0]
     out = []
     for part in d.split("; ")[:2]:
-        if "piece form" in part: out.append("pieces" + ("+side" if "long rows aside" in part else ""))
+        part = part.split(": ", 1)[-1]
+        if part.startswith("stream kernel"): out.append("stream")   # (its note may name the form that was not attempted)
+        elif "piece form" in part: out.append("pieces" + ("+side" if "long rows aside" in part else ""))
         elif "all-remainder" in part: out.append("all-rem")
         elif "tiled, fused" in part:
             import re
