@@ -494,11 +494,17 @@ def ladder_point(key, steps=100, warmup=20, timed=True):
         lp = banded_lp(rows_, rows_, per_row_, band_)
     else:
         lp = (LADDER_POINTS.get(key) or FAMILY_POINTS[key])()
-    # A rank's two matrices are both shard-shaped and both run the tiled piece form, the x-half handing the y-half's remainder
-    # products over.  The stand-alone LP of a shard point has the (m / P) x n matrix as A only -- its A^T (n rows, most of them
-    # nearly empty) is declined by the row-block balance rule and would leave the y-half its own pre-pass: the point forces the
-    # tiled form on both (test hook), which is what a rank runs.
-    hooks = {"HPRLP_TEST_HOOKS": "1", "HPRLP_TILED_ANYWAY": "1"} if key in SHARD_POINTS.values() else {}
+    # A rank's two matrices are both shard-shaped.  The stand-alone LP of a shard point has the (m / P) x n matrix as A only -- its A^T
+    # (n rows, most of them nearly empty) is not what a rank holds, and whether A's remainder products come by hand-off depends on it.
+    # At 2 ranks both of a rank's matrices run the fused tiled kernel, whose epilogue hands the other half's products over: the
+    # point forces the tiled form on A^T too (test hook).  At 4 and 8 ranks both run the PIECE form, which does not hand over: every
+    # half-step runs its own remainder pre-pass, and the point measures it that way (HPRLP_NO_FAR_PUSH=1).
+    if key == SHARD_POINTS[2]:
+        hooks = {"HPRLP_TEST_HOOKS": "1", "HPRLP_TILED_ANYWAY": "1"}
+    elif key in SHARD_POINTS.values():
+        hooks = {"HPRLP_TEST_HOOKS": "1", "HPRLP_NO_FAR_PUSH": "1"}
+    else:
+        hooks = {}
     saved = {k: os.environ.get(k) for k in hooks}
     os.environ.update(hooks)
     try:
