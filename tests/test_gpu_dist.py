@@ -404,3 +404,32 @@ def test_process_ranks_over_shared_memory_equal_single_gpu(gpu, tmp_path, kind, 
         assert o["info"]["n_sparse"] == (1 if kind == "banded" else 0)
     check_against_single(ref, ranks, lp["m"], lp["n"], lp["obj_star"])
     model.free()
+
+
+def test_bench_supervisor_cascade_ends_with_a_line_on_the_one_gpu_box(gpu):
+    """`python bench.py --gpus 2` end to end on hardware, as far as a one-GPU box allows (HPRLP_BENCH_ONE_DEVICE=1: both ranks on
+    device 0).  RCCL refuses two ranks on one device, so transport tiers 0-2 end at communicator creation -- real failures, each in
+    fresh processes -- and tier 3 (host-staged shared memory between the rank PROCESSES) must produce the line: n_gpus 2, the tier
+    and the earlier tiers' ends recorded, marked as a one-device rehearsal, the sharded solve to 1e-4 OPTIMAL on the planted
+    objective.  (The supervisor's watchdog and the launcher form are covered on CPU: tests/test_dist_cpu.py.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "HPRLP_TEST_HOOKS")}
+    env.update(HPRLP_BENCH_ONE_DEVICE="1", HPRLP_BENCH_STALL_S="120")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c5_tiny", "--steps", "20", "--warmup", "5"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["finite"]
+    tr = d["transport"]
+    assert tr["tier"] == 3 and "shared memory" in tr["name"]
+    assert [a["tier"] for a in tr["attempts"]] == [0, 1, 2, 3] and tr["attempts"][3]["ended"] == "ok"
+    assert all("exited with code" in a["ended"] for a in tr["attempts"][:3]), tr["attempts"]
+    assert "rehearsal" in d["config"]["rccl"] and d["config"]["rccl"]["transport"].startswith("shared memory")
+    t = d["time_to_tol"]
+    assert t["status"] == "OPTIMAL" and t["rel_obj_err"] < 1e-3, t
