@@ -498,13 +498,9 @@ def ladder_point(key, steps=100, warmup=20, timed=True):
     # (n rows, most of them nearly empty) is not what a rank holds, and whether A's remainder products come by hand-off depends on it.
     # At 2 ranks both of a rank's matrices run the fused tiled kernel, whose epilogue hands the other half's products over: the
     # point forces the tiled form on A^T too (test hook).  At 4 and 8 ranks both run the PIECE form, which does not hand over: every
-    # half-step runs its own remainder pre-pass, and the point measures it that way (HPRLP_NO_FAR_PUSH=1).
-    if key == SHARD_POINTS[2]:
-        hooks = {"HPRLP_TEST_HOOKS": "1", "HPRLP_TILED_ANYWAY": "1"}
-    elif key in SHARD_POINTS.values():
-        hooks = {"HPRLP_TEST_HOOKS": "1", "HPRLP_NO_FAR_PUSH": "1"}
-    else:
-        hooks = {}
+    # half-step runs its own remainder pre-pass -- which is what the point measures as it stands (its A^T keeps the stream kernel:
+    # the row-block balance rule declines it, and a stream kernel hands nothing over).
+    hooks = {"HPRLP_TEST_HOOKS": "1", "HPRLP_TILED_ANYWAY": "1"} if key == SHARD_POINTS[2] else {}
     saved = {k: os.environ.get(k) for k in hooks}
     os.environ.update(hooks)
     try:
