@@ -590,7 +590,7 @@ TIERS = [
     ("rccl: two communicators, neighbour exchange overlapped with the local part of the half-steps", {}),
     ("rccl: one communicator, exchange in line (HPRLP_NO_OVERLAP=1)", {"HPRLP_NO_OVERLAP": "1", "HPRLP_BENCH_SINGLE_COMM": "1"}),
     ("rccl: one communicator, in-place all-gather (HPRLP_DIST_EXCHANGE=allgather)",
-     {"HPRLP_NO_OVERLAP": "1", "HPRLP_BENCH_SINGLE_COMM": "1", "HPRLP_DIST_EXCHANGE": "allgather"}),
+     {"HPRLP_NO_OVERLAP": "1", "HPRLP_BENCH_SINGLE_COMM": "1", "HPRLP_DIST_EXCHANGE": "allgather", "HPRLP_TEST_HOOKS": "1"}),  # (the exchange form is a test hook)
     ("host-staged shared memory between the processes, no RCCL (HPRLP_DIST_TRANSPORT=shm)", {"HPRLP_DIST_TRANSPORT": "shm"}),
 ]
 TIER_WEIGHTS = [4.0, 2.5, 2.0, 2.5]

@@ -130,6 +130,7 @@ extern "C" int hprlp_warmup(int device) {
 // background-thread form of round 4 stays rejected (a context first touched by another thread cost the solver more).
 namespace hprlp {
 void warm_for_first_solve() {
+    if (env_on("HPRLP_NO_WARM_MODEL")) return;  // (a process that forks after building its models: INTEGRATION.md)
     static std::once_flag once;
     std::call_once(once, []() {
         const auto t0 = time_now();

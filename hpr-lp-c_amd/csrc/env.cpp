@@ -15,7 +15,8 @@ static const EnvEntry kTable[] = {
     {"HPRLP_NO_REORDER", EnvKind::Integrator, "no set-up time locality ordering of a large matrix"},
     {"HPRLP_NO_ALLOC_CACHE", EnvKind::Integrator, "do not keep freed device blocks for the next solver of the process"},
     {"HPRLP_DIST_TRANSPORT", EnvKind::Integrator, "shm: hprlp_dist_unique_id names a shared-memory segment (host-staged group of processes on one node) instead of RCCL ids"},
-    {"HPRLP_DIST_EXCHANGE", EnvKind::Integrator, "sparse | allgather: force the multi-GPU exchange form (same value on every rank)"},
+    {"HPRLP_NO_WARM_MODEL", EnvKind::Integrator, "the model constructors do NOT start the HIP runtime / device context / code objects (for a process that forks workers after building its models: a HIP context does not survive fork); the first solve pays for them as in the reference"},
+    {"HPRLP_DIST_EXCHANGE", EnvKind::Hook, "sparse | allgather: force the multi-GPU exchange form (same value on every rank)"},
     {"HPRLP_NO_OVERLAP", EnvKind::Integrator, "multi-GPU: shards unsplit, exchange in line on the solver stream"},
     {"HPRLP_DIST_TIMEOUT_S", EnvKind::Integrator, "seconds a rank of the shared-memory transport waits for its peers before it fails (default 120)"},
     {"HPRLP_BATCH_CHUNK", EnvKind::Hook, "solve_batched with 64 or more problems: chunk width of the panels (default 64; narrower chunks map one chunk to each XCD -- measured slower, profiles/r03_tiled_decomposition.md section 6b)"},
