@@ -374,3 +374,21 @@ def test_row_length_rules_keep_skewed_and_unbalanced_patterns_on_the_stream_kern
     A = sparse.csr_matrix((np.ones(len(r) + len(rh)), (np.concatenate([r, rh]), np.concatenate([c, ch]))), shape=(m, n))
     d2, _ = describe(lp_of(A))
     assert d2.startswith("A: stream kernel") and "too many entries in long rows" in d2.split("; A^T:")[0], d2
+
+
+def test_form_regret_tool_on_a_kronecker_graph(gpu, tmp_path):
+    """tools/form_regret.py stays runnable, and the pattern with round 4's worst regret stays fixed: a Kronecker (R-MAT) graph of
+    2^20 nodes, 7.5e6 entries, 40 % of them in rows of more than 256 -- chosen form = the stream kernel on both matrices, within
+    30 % of the best forced form (round 4's rules chose the piece form: 6.5 x the stream kernel's time)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "regret.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "form_regret.py"), "--only", "kronecker_20_8", "--steps", "20", "--json", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    rec = json.load(open(out))["kronecker_20_8"]
+    assert rec["forms"]["chosen"]["form"] == "stream/stream", rec["forms"]["chosen"]
+    assert rec["regret"] <= 1.3, rec["regret"]
+    assert rec["forms"]["tiled_8192"]["it_ms"] > 2.0 * rec["forms"]["chosen"]["it_ms"]      # what the rule avoids
