@@ -81,54 +81,64 @@ void build_range(int rows, int cols, const int *rp, const int *ci, int sb0, int 
             const Ent *b = ents.data() + b_begin[slot[tl]];
             const size_t bn = static_cast<size_t>(b_begin[slot[tl] + 1] - b_begin[slot[tl]]);
             const size_t tile_begin = L->tidx.size();
-            // segments of 1..4 entries are laid down by the bin-packed layout their counts define (tiled.h: PackLayout); longer
-            // ones go to the remainder list whole
-            int cnt[5] = {0, 0, 0, 0, 0};
+            // a row's segment is cut into pieces of at most K entries, piece q goes to layer q of the tile's list (tiled.h: kTileLayers);
+            // every layer is laid down by the bin-packed layout its piece counts define (PackLayout)
+            int cnt[kTileLayers][5] = {};
             for (size_t i = 0; i < bn;) {
                 size_t j = i;
                 while (j < bn && b[j].row == b[i].row) ++j;
                 const int len = static_cast<int>(j - i);
-                if (len > K) {
-                    for (size_t q = i; q < j; ++q) rem_long.emplace_back(b[q].row, b[q].k);
-                } else {
-                    ++cnt[len];
-                    L->dense += len;
-                }
+                for (int q = 0; q < kTileLayers && q * K < len; ++q) ++cnt[q][std::min(K, len - q * K)];
                 i = j;
             }
-            PackLayout lay;
-            lay.set(cnt[1], cnt[2], cnt[3], cnt[4]);
-            const int total = lay.entries();
-            L->pad += total - (cnt[1] + 2 * cnt[2] + 3 * cnt[3] + 4 * cnt[4]);
-            L->tidx.resize(tile_begin + static_cast<size_t>(total), 0u);
-            L->tperm.resize(tile_begin + static_cast<size_t>(total), -1);
-            int rank[5] = {0, 0, 0, 0, 0};
+            int nl = 1;
+            auto layer_entries = [&](int q) { return cnt[q][1] + 2 * cnt[q][2] + 3 * cnt[q][3] + 4 * cnt[q][4]; };
+            while (nl < kTileLayers && layer_entries(nl) >= kTileLayerMin) ++nl;
+            PackLayout lay[kTileLayers];
+            size_t layer_at[kTileLayers + 1];
+            layer_at[0] = tile_begin;
+            for (int q = 0; q < nl; ++q) {
+                lay[q].set(cnt[q][1], cnt[q][2], cnt[q][3], cnt[q][4]);
+                layer_at[q + 1] = layer_at[q] + static_cast<size_t>(lay[q].entries());
+                L->dense += layer_entries(q);
+                L->pad += lay[q].entries() - layer_entries(q);
+            }
+            L->tidx.resize(layer_at[nl], 0u);
+            L->tperm.resize(layer_at[nl], -1);
+            int rank[kTileLayers][5] = {};
             for (size_t i = 0; i < bn;) {
                 size_t j = i;
                 while (j < bn && b[j].row == b[i].row) ++j;
                 const int len = static_cast<int>(j - i);
-                if (len <= K) {
-                    const int rk = rank[len]++;
-                    const size_t at = tile_begin + static_cast<size_t>(lay.pos(len, rk));
-                    for (size_t q = i; q < j; ++q) {
-                        L->tidx[at + (q - i)] = tile_code(b[q].lcol, b[q].row);
-                        L->tperm[at + (q - i)] = b[q].k;
+                for (int q = 0; q * K < len; ++q) {
+                    const size_t p0 = i + static_cast<size_t>(q) * K;
+                    if (q >= nl) {  // pieces beyond the kept layers: remainder
+                        for (size_t e = p0; e < j; ++e) rem_long.emplace_back(b[e].row, b[e].k);
+                        break;
                     }
-                    const int np = lay.pads_after(len, rk);
-                    for (int q = 0; q < np; ++q) {
-                        L->tidx[at + static_cast<size_t>(len + q)] = static_cast<uint32_t>(b[i].row);
-                        L->tperm[at + static_cast<size_t>(len + q)] = -1;
+                    const int pl = std::min(K, len - q * K);
+                    const int rk = rank[q][pl]++;
+                    const size_t at = layer_at[q] + static_cast<size_t>(lay[q].pos(pl, rk));
+                    for (int e = 0; e < pl; ++e) {
+                        L->tidx[at + static_cast<size_t>(e)] = tile_code(b[p0 + e].lcol, b[p0 + e].row);
+                        L->tperm[at + static_cast<size_t>(e)] = b[p0 + e].k;
+                    }
+                    const int np = lay[q].pads_after(pl, rk);
+                    for (int e = 0; e < np; ++e) {
+                        L->tidx[at + static_cast<size_t>(pl + e)] = static_cast<uint32_t>(b[i].row);
+                        L->tperm[at + static_cast<size_t>(pl + e)] = -1;
                     }
                 }
                 i = j;
             }
-            size_t p = tile_begin;
-            const size_t end = L->tidx.size();
-            while (p < end) {
-                const size_t c = std::min<size_t>(end - p, kTileStepCap);
-                L->steps.push_back(TileStep{tl * T, static_cast<int>(p), static_cast<int>(p + c), 0});
-                L->step_is_rem.push_back(0);
-                p += c;
+            for (int q = 0; q < nl; ++q) {   // every layer has its own steps
+                size_t p = layer_at[q];
+                while (p < layer_at[q + 1]) {
+                    const size_t c = std::min<size_t>(layer_at[q + 1] - p, kTileStepCap);
+                    L->steps.push_back(TileStep{tl * T, static_cast<int>(p), static_cast<int>(p + c), 0});
+                    L->step_is_rem.push_back(0);
+                    p += c;
+                }
             }
         }
         L->sb_mid.push_back(static_cast<int>(L->steps.size() - first_step));

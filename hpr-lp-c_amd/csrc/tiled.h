@@ -112,6 +112,18 @@ struct PackLayout {
     }
 };
 
+// Layers of a tile's list (round 5).  A row's entries in ONE tile beyond the first kTileChunk used to send the row's whole segment
+// to the remainder lists (34 bytes of traffic per entry against 11): a band of 4 000 columns with 20 entries per row puts five
+// entries of a row into a 1024-column tile, and two thirds of such a matrix ended up there.  Now the segment is cut into pieces of
+// at most kTileChunk entries; piece q of every row goes to LAYER q of the tile's list.  A layer is laid down like the whole list
+// used to be (PackLayout), the layers follow each other, and every layer has its own steps -- a row has at most one piece per
+// layer, so inside a step still exactly one lane touches a given accumulator.  At most kTileLayers layers (entries beyond go to
+// the remainder), and a layer above the first is kept only while it holds kTileLayerMin entries (half a step's worth: a step
+// costs the same whatever it holds); the layers kept are contiguous from the first.  Per-row summation order inside a tile:
+// layer by layer.
+constexpr int kTileLayers = 4;
+constexpr int kTileLayerMin = 1024;
+
 constexpr int kTileResidentPerCu = 2;  // 80 KiB of LDS per workgroup, 160 KiB per CU
 constexpr int kFarGroup = kTileRows;   // most source columns per workgroup of the remainder pre-pass (64 KiB of LDS); TiledDev::G
 constexpr int kFarThreads = 512;

@@ -77,18 +77,32 @@ struct WalkWindow {
     int *perm, *col;          // pass 2 only
 };
 
+// PASS 1: count the pieces per layer (tiled.h: kTileLayers) -> *nl_out layers kept, counts[q] their piece counts, returns the
+//         padded length of the run's list, *steps_out its steps, *dense / *pad its entries and padding.
+// PASS 3: flag what goes to the remainder (pieces beyond the kept layers), given nl.
+// PASS 2: write the packed entries, given nl and counts.
 template <int PASS>
 __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long long *__restrict__ skey,
                                         const int *__restrict__ sperm, const int *__restrict__ col, int col0,
                                         char *__restrict__ flag_sorted, uint32_t *__restrict__ tidx, int *__restrict__ tperm,
-                                        int out0, int *dense, int *pad, const WalkWindow &w, int4 *counts) {
-    constexpr int W = kWalkWin, NTH = kWalkThreads;
+                                        int out0, int *dense, int *pad, const WalkWindow &w, int4 *counts, int nl, int *nl_out, int *steps_out) {
+    constexpr int W = kWalkWin, NTH = kWalkThreads, NL = kTileLayers;
     constexpr int RM = (1 << kRowBits) - 1;
-    // PASS 1 counts the segments by length (and flags the long ones for the remainder); PASS 2 lays them down by the
-    // bin-packed layout those counts define (tiled.h: PackLayout)
-    int cnt[5] = {0, 0, 0, 0, 0};   // PASS 1: segments of length 1..4; PASS 2: rank of the next segment of each length
-    PackLayout lay;
-    if (PASS == 2) lay.set(counts->x, counts->y, counts->z, counts->w);
+    int cnt[NL][5];   // PASS 1: pieces of length 1..4 per layer; PASS 2: rank of the next piece of each length and layer
+#pragma unroll
+    for (int q = 0; q < NL; ++q)
+#pragma unroll
+        for (int l = 0; l < 5; ++l) cnt[q][l] = 0;
+    PackLayout lay[NL];
+    int layer_at[NL + 1];
+    layer_at[0] = out0;
+    if (PASS == 2) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            if (q < nl) lay[q].set(counts[q].x, counts[q].y, counts[q].z, counts[q].w);
+            layer_at[q + 1] = layer_at[q] + (q < nl ? lay[q].entries() : 0);
+        }
+    }
     int i = begin;
     int wb = begin - W;  // window base: the window holds entries [wb, wb + W) of this lane's run
     auto key_at = [&](int idx) { return idx < wb + W ? w.key[(idx - wb) * NTH] : skey[idx]; };  // (beyond the window: a long segment's scan)
@@ -120,44 +134,82 @@ __device__ __forceinline__ int walk_run(int begin, int end, const unsigned long 
         int j = i + 1;
         while (j < end && key_at(j) == rkey) ++j;
         const int len = j - i, row = static_cast<int>(rkey & RM);
-        if (len > K) {  // long segment: remainder
-            if (PASS == 1)
-                for (int q = i; q < j; ++q) flag_sorted[q] = 1;
-            i = j;
-            continue;
-        }
         if (PASS == 1) {
-            ++cnt[len];
-            *dense += len;
-        } else {
-            const int rank = cnt[len]++;
-            const int at = out0 + lay.pos(len, rank);
-            for (int q = i; q < j; ++q) {  // (i + K <= wb + W: inside the window)
-                tperm[at + (q - i)] = w.perm[(q - wb) * NTH];
-                tidx[at + (q - i)] = (static_cast<uint32_t>(w.col[(q - wb) * NTH] - col0) << kRowBits) | static_cast<uint32_t>(row);
+            for (int q = 0; q < NL && q * K < len; ++q) {
+                const int pl = min(K, len - q * K);
+#pragma unroll
+                for (int qq = 0; qq < NL; ++qq)   // (static indexing: the counters stay in registers)
+#pragma unroll
+                    for (int l = 1; l <= K; ++l)
+                        if (qq == q && l == pl) ++cnt[qq][l];
             }
-            const int np = lay.pads_after(len, rank);
-            for (int q = 0; q < np; ++q) {
-                tidx[at + len + q] = static_cast<uint32_t>(row);
-                tperm[at + len + q] = -1;
+        } else if (PASS == 3) {
+            for (int e = i + nl * K; e < j; ++e) flag_sorted[e] = 1;   // pieces beyond the kept layers
+        } else {
+            for (int q = 0; q < nl && q * K < len; ++q) {
+                const int pl = min(K, len - q * K), p0 = i + q * K;
+                int rank = 0, at = 0, np = 0;
+#pragma unroll
+                for (int qq = 0; qq < NL; ++qq)
+#pragma unroll
+                    for (int l = 1; l <= K; ++l)
+                        if (qq == q && l == pl) {
+                            rank = cnt[qq][l]++;
+                            at = layer_at[qq] + lay[qq].pos(l, rank);
+                            np = lay[qq].pads_after(l, rank);
+                        }
+                for (int e = 0; e < pl; ++e) {
+                    const int idx = p0 + e;
+                    int pm, cc;
+                    if (idx < wb + W) {
+                        pm = w.perm[(idx - wb) * NTH];
+                        cc = w.col[(idx - wb) * NTH];
+                    } else {  // (a segment longer than the window's lookahead)
+                        pm = sperm[idx];
+                        cc = col[pm];
+                    }
+                    tperm[at + e] = pm;
+                    tidx[at + e] = (static_cast<uint32_t>(cc - col0) << kRowBits) | static_cast<uint32_t>(row);
+                }
+                for (int e = 0; e < np; ++e) {
+                    tidx[at + pl + e] = static_cast<uint32_t>(row);
+                    tperm[at + pl + e] = -1;
+                }
             }
         }
         i = j;
     }
     if (PASS == 1) {
-        lay.set(cnt[1], cnt[2], cnt[3], cnt[4]);
-        *counts = make_int4(cnt[1], cnt[2], cnt[3], cnt[4]);
-        const int total = lay.entries();
-        *pad += total - *dense;
+        auto layer_entries = [&](int q) { return cnt[q][1] + 2 * cnt[q][2] + 3 * cnt[q][3] + 4 * cnt[q][4]; };
+        int keep = 1;
+#pragma unroll
+        for (int q = 1; q < NL; ++q)
+            if (keep == q && layer_entries(q) >= kTileLayerMin) keep = q + 1;
+        int total = 0, nst = 0;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            counts[q] = make_int4(cnt[q][1], cnt[q][2], cnt[q][3], cnt[q][4]);
+            if (q < keep) {
+                lay[q].set(cnt[q][1], cnt[q][2], cnt[q][3], cnt[q][4]);
+                const int le = lay[q].entries();
+                *dense += layer_entries(q);
+                *pad += le - layer_entries(q);
+                total += le;
+                nst += (le + kTileStepCap - 1) / kTileStepCap;
+            }
+        }
+        *nl_out = keep;
+        *steps_out = nst;
         return total;
     }
-    return lay.entries();
+    return 0;
 }
 
 __global__ void __launch_bounds__(kWalkThreads) k_run_pass1(int nruns, bool all_rem, const int *__restrict__ run_start,
                                                            const unsigned long long *__restrict__ skey, char *__restrict__ flag_sorted,
                                                            int *__restrict__ padded_len, int *__restrict__ nsteps,
-                                                           unsigned long long *__restrict__ totals, int4 *__restrict__ seg_counts) {
+                                                           unsigned long long *__restrict__ totals, int4 *__restrict__ seg_counts,
+                                                           int *__restrict__ run_layers) {
     __shared__ unsigned long long wkey[kWalkWin * kWalkThreads];
     const int r = blockIdx.x * kWalkThreads + threadIdx.x;
     if (r >= nruns) return;
@@ -166,17 +218,31 @@ __global__ void __launch_bounds__(kWalkThreads) k_run_pass1(int nruns, bool all_
         for (int q = begin; q < end; ++q) flag_sorted[q] = 1;
         padded_len[r] = 0;
         nsteps[r] = 0;
+        run_layers[r] = 0;
         return;
     }
-    int dense = 0, pad = 0;
+    int dense = 0, pad = 0, nl = 1, nst = 0;
     const WalkWindow w{wkey + threadIdx.x, nullptr, nullptr};
-    int4 c4;
-    const int len = walk_run<1>(begin, end, skey, nullptr, nullptr, 0, flag_sorted, nullptr, nullptr, 0, &dense, &pad, w, &c4);
-    seg_counts[r] = c4;
+    int4 c4[kTileLayers];
+    const int len = walk_run<1>(begin, end, skey, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, &dense, &pad, w, c4, 0, &nl, &nst);
+    for (int q = 0; q < kTileLayers; ++q) seg_counts[static_cast<size_t>(r) * kTileLayers + q] = c4[q];
     padded_len[r] = len;
-    nsteps[r] = (len + kTileStepCap - 1) / kTileStepCap;
+    nsteps[r] = nst;
+    run_layers[r] = nl;
     atomicAdd(&totals[0], static_cast<unsigned long long>(dense));
     atomicAdd(&totals[1], static_cast<unsigned long long>(pad));
+}
+
+// the remainder flags of the staged runs: what their kept layers do not hold (a walk over the keys alone)
+__global__ void __launch_bounds__(kWalkThreads) k_run_flags(int nruns, const int *__restrict__ run_start, const unsigned long long *__restrict__ skey,
+                                                           const int *__restrict__ run_layers, char *__restrict__ flag_sorted) {
+    __shared__ unsigned long long wkey[kWalkWin * kWalkThreads];
+    const int r = blockIdx.x * kWalkThreads + threadIdx.x;
+    if (r >= nruns) return;
+    const int nl = run_layers[r];
+    if (nl == 0) return;  // (flagged whole by pass 1)
+    const WalkWindow w{wkey + threadIdx.x, nullptr, nullptr};
+    walk_run<3>(run_start[r], run_start[r + 1], skey, nullptr, nullptr, 0, flag_sorted, nullptr, nullptr, 0, nullptr, nullptr, w, nullptr, nl, nullptr, nullptr);
 }
 
 // first run whose super-block is >= sb, for sb = 0..nsb  (runs are sorted by (super-block, tile))
@@ -200,7 +266,7 @@ __global__ void __launch_bounds__(kWalkThreads) k_run_pass2(int nruns, int tile_
                                                        const int *__restrict__ run_step_off, const int *__restrict__ first_run,
                                                        const int *__restrict__ sb_ptr, const int *__restrict__ col,
                                                        uint32_t *__restrict__ tidx, int *__restrict__ tperm, TileStep *__restrict__ steps,
-                                                       const int4 *__restrict__ seg_counts) {
+                                                       const int4 *__restrict__ seg_counts, const int *__restrict__ run_layers) {
     __shared__ unsigned long long wkey[kWalkWin * kWalkThreads];
     __shared__ int wperm[kWalkWin * kWalkThreads], wcol[kWalkWin * kWalkThreads];
     const int r = blockIdx.x * kWalkThreads + threadIdx.x;
@@ -211,12 +277,20 @@ __global__ void __launch_bounds__(kWalkThreads) k_run_pass2(int nruns, int tile_
     const unsigned long long k0 = skey[begin];
     const int tl = static_cast<int>((k0 >> kRowBits) & ((1ULL << tile_bits) - 1));
     const WalkWindow w{wkey + threadIdx.x, wperm + threadIdx.x, wcol + threadIdx.x};
-    int4 c4 = seg_counts[r];
-    walk_run<2>(begin, end, skey, sperm, col, tl * T, nullptr, tidx, tperm, out0, nullptr, nullptr, w, &c4);
+    const int nl = run_layers[r];
+    int4 c4[kTileLayers];
+    for (int q = 0; q < kTileLayers; ++q) c4[q] = seg_counts[static_cast<size_t>(r) * kTileLayers + q];
+    walk_run<2>(begin, end, skey, sperm, col, tl * T, nullptr, tidx, tperm, out0, nullptr, nullptr, w, c4, nl, nullptr, nullptr);
     const int sb = static_cast<int>(k0 >> (tile_bits + kRowBits));
-    const int s0 = sb_ptr[sb] + (run_step_off[r] - run_step_off[first_run[sb]]);
-    for (int p = 0, j = 0; p < len; p += kTileStepCap, ++j)
-        steps[s0 + j] = TileStep{tl * T, out0 + p, out0 + min(len, p + kTileStepCap), 0};
+    int sj = sb_ptr[sb] + (run_step_off[r] - run_step_off[first_run[sb]]);
+    int at = out0;
+    for (int q = 0; q < nl; ++q) {   // every layer has its own steps
+        PackLayout lay;
+        lay.set(c4[q].x, c4[q].y, c4[q].z, c4[q].w);
+        const int le = lay.entries();
+        for (int p = 0; p < le; p += kTileStepCap) steps[sj++] = TileStep{tl * T, at + p, at + min(le, p + kTileStepCap), 0};
+        at += le;
+    }
 }
 
 __global__ void __launch_bounds__(kThreads) k_gather_int(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ dst) {
@@ -487,13 +561,15 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     DBuf<char> flag_sorted;
     flag_sorted.alloc_zero(static_cast<size_t>(nnz));
     DBuf<int> padded_len(static_cast<size_t>(nruns) + 1), nsteps(static_cast<size_t>(nruns) + 1);
-    DBuf<int4> seg_counts(static_cast<size_t>(nruns) + 1);  // per run: its segments of length 1..4 (tiled.h: PackLayout)
+    DBuf<int4> seg_counts((static_cast<size_t>(nruns) + 1) * kTileLayers);  // per run and layer: its pieces of length 1..4 (tiled.h: PackLayout, kTileLayers)
+    DBuf<int> run_layers(static_cast<size_t>(nruns) + 1);
     DBuf<unsigned long long> totals;
     totals.alloc_zero(2);
     HIP_CHECK(hipMemsetAsync(padded_len.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
     HIP_CHECK(hipMemsetAsync(nsteps.p, 0, sizeof(int) * (static_cast<size_t>(nruns) + 1), s));
     hipLaunchKernelGGL(k_run_pass1, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, rem_cap == kPbRemCap, run_start.p, skey.p, flag_sorted.p, padded_len.p,
-                       nsteps.p, totals.p, seg_counts.p);
+                       nsteps.p, totals.p, seg_counts.p, run_layers.p);
+    hipLaunchKernelGGL(k_run_flags, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, run_start.p, skey.p, run_layers.p, flag_sorted.p);
     unsigned long long tot[2] = {0, 0};
     HIP_CHECK(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -555,7 +631,7 @@ bool DeviceTiled::build_on_device(int rows, int cols, long nnz, const int *rowpt
     tperm.alloc(static_cast<size_t>(n_tile) + 8);
     tval.alloc_zero(static_cast<size_t>(n_tile) + 8);
     hipLaunchKernelGGL(k_run_pass2, dim3((nruns + kWalkThreads - 1) / kWalkThreads), dim3(kWalkThreads), 0, s, nruns, tile_bits, T, run_start.p, skey.p, sperm.p, padded_len.p,
-                       run_off.p, run_step_off.p, first_run.p, sb_ptr.p, col, tidx.p, tperm.p, steps.p, seg_counts.p);
+                       run_off.p, run_step_off.p, first_run.p, sb_ptr.p, col, tidx.p, tperm.p, steps.p, seg_counts.p, run_layers.p);
     rcol.alloc_zero(static_cast<size_t>(n_rem) + 8);
     rperm.alloc(static_cast<size_t>(n_rem) + 8);
     rrow.alloc_zero(static_cast<size_t>(n_rem) + 8);
