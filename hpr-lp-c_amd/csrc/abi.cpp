@@ -948,7 +948,7 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
             if (M.declined_skew) d += " [tiled form not attempted: too many entries in long rows]";
             else if (M.declined_imbalance) d += " [tiled form not attempted: unbalanced row blocks]";
             else if (M.declined_coalesced) d += " [tiled form not attempted: neighbouring rows gather from the same lines]";
-            else if (M.declined_l2) d += " [tiled piece form not attempted: the stream kernel's gathers stay in one L2]";
+            else if (M.declined_l2) d += " [tiled form not attempted: the stream kernel's gathers stay in one L2]";
             else if (M.declined_shape) d += " [tiled form not attempted: shape]";
             else if (M.declined_sparse) d += " [tiled form declined: too few entries in dense tiles]";
             return d;

@@ -246,6 +246,8 @@ constexpr double kStreamLineDensity = 0.25;  // build_tiled_copy: at most this m
 constexpr double kStreamL2LineDensity = 0.6;  // ... and only while neighbouring rows still share lines: with a line per entry the L2 holds the window but every gather
                                               // misses the L1 (1.5M x 1.5M, band 75 000, 0.93 lines per entry: stream 0.177 ms per half-step, pieces 0.128; the
                                               // multicommodity-flow LP the rule was made for: 0.35 / 0.15)
+constexpr double kCoalescedMaxRowEntries = 32.0;   // build_tiled_copy: the coalesced-rows preference for the stream kernel holds up to this many entries per row
+constexpr double kStreamL2LineDensityFused = 0.5;  // ... the same against a FUSED tiled form that needs its longest rows kept aside (build_tiled_copy)
 constexpr double kPiecesMinRowEntries = 16.0;  // ... or while rows are thin (build_tiled_copy)
 constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of the gathered vector that one 4 MiB L2 keeps beside the matrix stream
 
@@ -478,13 +480,30 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // half-step, band 2000 (0.2) 0.107 -- the tiled build declines such bands (more than four entries of a row per tile) and the
         // all-remainder form that used to follow took 0.138 / 0.149; grid PDE-control LP (0.11 / 0.20): stream 0.0245 against
         // 0.0361 ms in the lowered fused form.  From 0.37 lines per entry on (band 4000) the fused tiled form wins (0.089 / 0.124).
+        // (these two hold for a matrix whose longest rows would be kept aside as well: evaluated whatever the longest row is -- with the
+        // layered tile lists of round 5 the copy of a block-angular LP WITHOUT its 400 linking rows passes the dense-tile test, and ran
+        // 0.48 / 0.42 of 8 TB/s where the stream kernel, whose rows share their lines, runs 0.58 / 0.47)
         declined_coalesced = false;
-        if (!declined_shape && line_density <= kStreamLineDensity && !mr && min_dense_override < 0.0 && env_get("HPRLP_TILED_ANYWAY") == nullptr)
+        const bool long_only = declined_shape && cols >= min_cols;  // declined so far for its longest row alone
+        // (rows of more than kCoalescedMaxRowEntries entries excepted: the stream kernel packs 512 entries per wave, so 60-entry rows leave
+        // it 8 busy lanes in its row-sum phase -- 600k x 600k, 60 per row in 6 000 columns, 0.2 lines per entry: stream 0.24 / 0.35 of
+        // 8 TB/s, lowered tiled form with three layers per tile 0.42 / 0.50)
+        if ((!declined_shape || long_only) && line_density <= kStreamLineDensity && entries_per_row <= kCoalescedMaxRowEntries && !mr && min_dense_override < 0.0 &&
+            env_get("HPRLP_TILED_ANYWAY") == nullptr)
             declined_shape = declined_coalesced = true;
-        if (!declined_shape && rb == kTileRows && (rows + rb - 1) / rb < workgroup_slots() && xcd_gather_bytes > 0.0 &&
-            xcd_gather_bytes <= kStreamL2Bytes && (line_density <= kStreamL2LineDensity || tile_share_full > 1.0 || entries_per_row < kPiecesMinRowEntries) &&
-            env_get("HPRLP_PIECES_ANYWAY") == nullptr && !mr) {
-            declined_shape = declined_l2 = true;
+        {
+            const bool pieces_expected = rb == kTileRows && (rows + rb - 1) / rb < workgroup_slots();
+            const bool in_one_l2 = xcd_gather_bytes > 0.0 && xcd_gather_bytes <= kStreamL2Bytes;
+            // pieces: round 4's rule with round 5's conditions.  A FUSED tiled form only where the copy would need its longest rows kept
+            // aside (two more launches per half-step for them) and the stream kernel's rows share their lines inside one L2:
+            // block-angular LP without its 400 linking rows (0.39 lines per entry, 2 MB per XCD): fused 1984-row form + side 0.48 / 0.42
+            // of 8 TB/s, stream kernel 0.58 / 0.47.  (A band of 4 000 columns has the same line density and window and no long rows:
+            // fused form 0.51, stream kernel 0.36.)
+            const bool stream_wins = pieces_expected ? (line_density <= kStreamL2LineDensity || tile_share_full > 1.0 || entries_per_row < kPiecesMinRowEntries)
+                                                     : (long_only && line_density <= kStreamL2LineDensityFused);
+            if ((!declined_shape || (long_only && !declined_coalesced)) && in_one_l2 && stream_wins && env_get("HPRLP_PIECES_ANYWAY") == nullptr &&
+                env_get("HPRLP_TILED_ANYWAY") == nullptr && !mr && min_dense_override < 0.0)
+                declined_shape = declined_l2 = true;
         }
         const char *ht = env_get("HPRLP_HOST_TILING");
         const bool host_tiling = ht && ht[0] == '1';
@@ -516,7 +535,8 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // tiled copy and summed by the stream kernel's vector / split-row mode into a base vector that every tiled launch
         // adds (tiled.h: TiledDev::side_*).  At most 0.1 % of the rows (and 64) and a fifth of the nonzeros.
         const char *nside = env_get("HPRLP_NO_LONG_SIDE");
-        if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && !host_tiling && !(nside && nside[0] == '1') && !declined_skew) {
+        if (cols >= min_cols && longest > kTileMaxRow && rows >= min_rows && nnz > 0 && !host_tiling && !(nside && nside[0] == '1') && !declined_skew &&
+            !declined_coalesced && !declined_l2) {
             const int *rp = host_rp();
             std::vector<int> long_rows;
             long long_nnz = 0;

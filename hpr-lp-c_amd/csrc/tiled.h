@@ -8,8 +8,9 @@
 // (row, column) and packed in chunks of 4; a row segment never straddles a chunk (zero-valued
 // padding continues the previous row), so exactly one lane touches a given accumulator in a step:
 // no atomics, deterministic; the per-row summation order is fixed by the matrix (tiles in the order of
-// the super-block's rotated sweep -- finish_schedule() in tiled_build.hip -- then the remainder).
-// Segments longer than 4 and entries of sparse tiles (the far columns) go to a remainder list.  A random 8-byte gather
+// the super-block's rotated sweep -- finish_schedule() in tiled_build.hip -- layer by layer inside a tile, then the remainder).
+// A row's entries beyond four in one tile go to further LAYERS of the tile's list (kTileLayers below; round 5), what the layers
+// do not hold and the entries of sparse tiles (the far columns) go to a remainder list.  A random 8-byte gather
 // costs a whole 128-byte line of fabric traffic whatever the load flavour (tools/gather_probe.hip), so the remainder is
 // not gathered by the row side at all: a pre-pass kernel (k_far_products) walks the list in SOURCE order -- one workgroup
 // per group of kFarGroup columns, that slice of the vector staged in LDS with coalesced loads -- and writes every product
