@@ -122,8 +122,14 @@ struct PackLayout {
 // the remainder), and a layer above the first is kept only while it holds kTileLayerMin entries (half a step's worth: a step
 // costs the same whatever it holds); the layers kept are contiguous from the first.  Per-row summation order inside a tile:
 // layer by layer.
-constexpr int kTileLayers = 4;
-constexpr int kTileLayerMin = 1024;
+#ifndef HPRLP_TILE_LAYERS
+#define HPRLP_TILE_LAYERS 4       // (developer variants: make variant NAME=l8 DEFS=-DHPRLP_TILE_LAYERS=8)
+#endif
+#ifndef HPRLP_TILE_LAYER_MIN
+#define HPRLP_TILE_LAYER_MIN 1024
+#endif
+constexpr int kTileLayers = HPRLP_TILE_LAYERS;
+constexpr int kTileLayerMin = HPRLP_TILE_LAYER_MIN;
 
 constexpr int kTileResidentPerCu = 2;  // 80 KiB of LDS per workgroup, 160 KiB per CU
 constexpr int kFarGroup = kTileRows;   // most source columns per workgroup of the remainder pre-pass (64 KiB of LDS); TiledDev::G
