@@ -974,6 +974,20 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
     GUARD_END(-1)
 }
 
+// Host only: the column-tiled structure of a CSR pattern (host builder, tiled.cpp) with super-blocks of R rows and tiles of T
+// columns, verified entry by entry (every entry once, codes name their entries, one chunk per accumulator inside a step, layers).
+// out = {tile entries incl. padding, remainder entries, steps, padding, most consecutive steps of one tile, staged share x 1e6}.
+extern "C" int hprlp_tiled_host_check(int m, int n, const int *rowptr, const int *col, int R, int T, double min_dense, long out[6]) {
+    try {
+        if (m <= 0 || n <= 0 || !rowptr || !col || !out) throw std::runtime_error("bad arguments");
+        tiled_host_check(m, n, rowptr, col, R, T, min_dense, out);
+        return 0;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return -1;
+    }
+}
+
 // The table of environment switches (env.h) as text, one per line: "<name>\t<integrator|hook>\t<what>"; returns the length.
 extern "C" int hprlp_env_switches(char *buf, int cap) {
     int count = 0;

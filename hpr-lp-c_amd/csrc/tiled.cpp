@@ -245,6 +245,77 @@ bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHos
     return true;
 }
 
+// Host only: build the tiled structure of a pattern and verify what the kernels rely on -- every CSR entry exactly once (in a
+// tile list or in the remainder), codes consistent with the entries they stand for, inside a step one chunk per accumulator at
+// most (a row appears in ONE chunk of a step: padding slots carry the row of the slot before them), steps within their capacity
+// and tile, at most kTileLayers steps-runs per (super-block, tile).  out = {tile entries incl. padding, remainder entries, steps,
+// padding, most consecutive steps of one tile in a super-block (its layers' steps), share of entries staged x 1e6}.
+void tiled_host_check(int rows, int cols, const int *rp, const int *ci, int R, int T, double min_dense, long out[6]) {
+    TiledHost h;
+    if (!build_tiled(rows, cols, rp, ci, &h, 1, min_dense, R, T, kTileRemCap)) throw std::runtime_error("tiled check: the build declined the pattern");
+    const long nnz = rp[rows];
+    std::vector<uint32_t> tidx;
+    std::vector<int> tperm, rperm;
+    std::vector<uint16_t> rrow;
+    for (const TiledHost::Piece &pc : h.pieces) {
+        tidx.insert(tidx.end(), pc.tidx.begin(), pc.tidx.end());
+        tperm.insert(tperm.end(), pc.tperm.begin(), pc.tperm.end());
+        rperm.insert(rperm.end(), pc.rperm.begin(), pc.rperm.end());
+        rrow.insert(rrow.end(), pc.rrow.begin(), pc.rrow.end());
+    }
+    std::vector<char> seen(static_cast<size_t>(nnz), 0);
+    auto row_of = [&](int k) { return static_cast<int>(std::upper_bound(rp, rp + rows + 1, k) - rp) - 1; };
+    const int nsb = static_cast<int>(h.sb_mid.size());
+    long pads = 0, most_run = 0;
+    std::vector<int> stamp(static_cast<size_t>(R), -1);
+    for (int sb = 0; sb < nsb; ++sb) {
+        long run = 0;
+        for (int s = h.sb_ptr[sb]; s < h.sb_mid[sb]; ++s) {
+            const TileStep &st = h.steps[s];
+            if (st.e_end - st.e_begin > kTileStepCap || st.e_begin % kTileChunk != 0 || st.col0 % T != 0) throw std::runtime_error("tiled check: bad tile step");
+            run = (s > h.sb_ptr[sb] && h.steps[s - 1].col0 == st.col0) ? run + 1 : 1;
+            most_run = std::max(most_run, run);
+            for (int e = st.e_begin; e < st.e_end; ++e) {
+                const int lrow = static_cast<int>(tidx[e] & (kTileRows - 1)), lcol = static_cast<int>(tidx[e] >> kTileRowBits);
+                if (lrow >= R) throw std::runtime_error("tiled check: local row beyond the super-block");
+                const int k = tperm[e];
+                if (k < 0) {
+                    ++pads;
+                    if (e % kTileChunk == 0 || static_cast<int>(tidx[e - 1] & (kTileRows - 1)) != lrow) throw std::runtime_error("tiled check: padding does not continue its row");
+                    continue;
+                }
+                if (k >= nnz || seen[k]++) throw std::runtime_error("tiled check: an entry twice (or out of range)");
+                if (row_of(k) != sb * R + lrow || ci[k] != st.col0 + lcol) throw std::runtime_error("tiled check: a code does not name its entry");
+            }
+            // one chunk per accumulator inside the step
+            for (int e = st.e_begin; e < st.e_end; ++e) {
+                const int lrow = static_cast<int>(tidx[e] & (kTileRows - 1)), chunk = e / kTileChunk;
+                if (stamp[lrow] == -1) stamp[lrow] = chunk;
+                else if (stamp[lrow] != chunk) throw std::runtime_error("tiled check: a row in two chunks of one step");
+            }
+            for (int e = st.e_begin; e < st.e_end; ++e) stamp[tidx[e] & (kTileRows - 1)] = -1;
+        }
+        for (int s = h.sb_mid[sb]; s < h.sb_ptr[sb + 1]; ++s) {
+            const TileStep &st = h.steps[s];
+            if (st.e_end - st.e_begin > kTileRemCap) throw std::runtime_error("tiled check: remainder step too long");
+            for (int e = st.e_begin; e < st.e_end; ++e) {
+                const int k = rperm[e];
+                if (k < 0 || k >= nnz || seen[k]++) throw std::runtime_error("tiled check: a remainder entry twice (or out of range)");
+                if (row_of(k) != sb * R + rrow[e]) throw std::runtime_error("tiled check: a remainder entry in the wrong super-block / row");
+            }
+        }
+    }
+    for (long k = 0; k < nnz; ++k)
+        if (!seen[k]) throw std::runtime_error("tiled check: an entry is missing");
+    if (most_run > kTileLayers * ((static_cast<long>(R) * kTileChunk + kTileStepCap - 1) / kTileStepCap + 1)) throw std::runtime_error("tiled check: too many steps for one tile");
+    out[0] = static_cast<long>(h.n_tile);
+    out[1] = static_cast<long>(h.n_rem);
+    out[2] = static_cast<long>(h.steps.size());
+    out[3] = pads;
+    out[4] = most_run;
+    out[5] = static_cast<long>(1e6 * static_cast<double>(h.dense_entries) / static_cast<double>(nnz));
+}
+
 void DeviceTiled::upload(const TiledHost &h, int R, int T, int rem_cap) {
     n_tile = static_cast<long>(h.n_tile);
     n_rem = static_cast<long>(h.n_rem);

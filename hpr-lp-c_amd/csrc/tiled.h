@@ -225,6 +225,9 @@ struct TiledHost {
 bool build_tiled(int rows, int cols, const int *rowptr, const int *col, TiledHost *out, int min_rows,
                  double min_dense_fraction, int R = kTileRows, int T = kTileCols, int rem_cap = kTileRemCap);
 
+// host only: build_tiled on the pattern + the invariants the kernels rely on (tiled.cpp); throws on the first violation
+void tiled_host_check(int rows, int cols, const int *rp, const int *ci, int R, int T, double min_dense, long out[6]);
+
 // col_c / map_c (device, compact nnz entries): the CSR pattern without the rows whose compact length is zero (tiled_build.hip)
 void compact_without_rows(long nnz, int rows, const int *rp_dev, const int *rp_c_dev, const int *col_dev, int *col_c, int *map_c, hipStream_t s);
 

@@ -222,6 +222,12 @@ int hprlp_locality_ordering(int m, int n, const int *rowptr, const int *col, int
  * column eighths when with_cuts != 0); out = {blocks, split rows, chunk slots, rows cut, longest chunk, entries covered};
  * -1 + hprlp_last_error() when the block list would be refused. */
 int hprlp_row_block_plan(int m, int n, const int *rowptr, const int *col, int with_cuts, long out[6]);
+/* host only: the column-tiled copy of a CSR pattern as the host builder lays it out (super-blocks of R rows: a multiple of 64 up to
+ * 8192; tiles of T = 2048 or 1024 columns; min_dense: least share of the entries in staged tiles), verified entry by entry -- every
+ * entry exactly once, codes name their entries, one chunk per accumulator inside a step, at most four layers per tile.
+ * out = {tile entries incl. padding, remainder entries, steps, padding, most consecutive steps of one tile, staged share x 1e6};
+ * -1 + hprlp_last_error() on the first violation or when the build declines the pattern. */
+int hprlp_tiled_host_check(int m, int n, const int *rowptr, const int *col, int R, int T, double min_dense, long out[6]);
 
 #ifdef __cplusplus
 }

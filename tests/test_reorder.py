@@ -98,3 +98,61 @@ def test_row_blocks_of_dense_rows_cut_by_column_eighths_stay_within_a_chunk():
     # without cuts the same rows fall to kSplitRow chunks
     rc, out = block_plan(m, n, rp, ci, cuts=False)
     assert rc == 0 and out[3] == 0 and out[4] <= 4096 and out[5] == rp[-1]
+
+
+def tiled_check(m, n, rp, ci, R, T, min_dense=0.0):
+    import ctypes as C
+    L = hprlp.lib()
+    out = np.zeros(6, np.int64)
+    L.hprlp_tiled_host_check.argtypes = [C.c_int, C.c_int, hprlp.c_int_p, hprlp.c_int_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_long)]
+    rc = L.hprlp_tiled_host_check(m, n, rp.ctypes.data_as(hprlp.c_int_p), ci.ctypes.data_as(hprlp.c_int_p), R, T, min_dense,
+                                  out.ctypes.data_as(C.POINTER(C.c_long)))
+    return rc, out
+
+
+def test_layered_tile_lists_keep_the_kernels_invariants():
+    """tiled.h: kTileLayers (round 5).  A row's entries beyond four in one tile go to further LAYERS of the tile's list instead of
+    sending the row's segment to the remainder.  The host builder's structure on narrow bands (5, 10 and 24 entries of a row per
+    tile: two, three and four layers + an overflow to the remainder), on a pattern with far entries and ragged rows, is verified
+    entry by entry (hprlp_tiled_host_check): every CSR entry exactly once, codes name their entries, inside a step one chunk per
+    accumulator, steps within capacity; the layers show as consecutive steps of one tile and as the staged share."""
+    rng = np.random.default_rng(5)
+
+    def band(m, per_row, half, far=0.0):
+        r = np.repeat(np.arange(m), per_row)
+        c = np.abs(r + rng.integers(-half, half + 1, size=len(r)))
+        c = np.where(c > m - 1, 2 * (m - 1) - c, c)
+        if far:
+            isfar = rng.random(len(r)) < far
+            c = np.where(isfar, rng.integers(0, m, size=len(r)), c)
+        A = sparse.csr_matrix((np.ones(len(r)), (r, c)), shape=(m, m)); A.sum_duplicates(); A.sort_indices()
+        return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.nnz
+
+    m = 40_000
+    # 20 per row in 4 000 columns: ~5 per 1024-column tile -> two layers; before the layers two thirds of it went to the remainder
+    rp, ci, nnz = band(m, 20, 2000)
+    rc, o = tiled_check(m, m, rp, ci, 2048, 1024)
+    assert rc == 0, hprlp.last_error()
+    assert o[5] >= 850_000 and o[1] <= 0.15 * nnz, o          # >= 85 % staged
+    assert o[0] - o[3] + o[1] == nnz                            # tile entries without padding + remainder = all entries
+    assert o[4] >= 2                                            # a tile's layers: consecutive steps of one tile
+    # 40 per row in 4 000 columns: ~10 per tile -> three layers
+    rp, ci, nnz = band(m, 40, 2000)
+    rc, o = tiled_check(m, m, rp, ci, 1024, 1024)
+    assert rc == 0 and o[5] >= 850_000 and o[0] - o[3] + o[1] == nnz, (o, hprlp.last_error())
+    # 60 per row in 2 400 columns: ~24 per tile -> four layers and the rest to the remainder; 10 % far entries; wide tiles
+    rp, ci, nnz = band(m, 60, 1200, far=0.1)
+    for T in (1024, 2048):
+        rc, o = tiled_check(m, m, rp, ci, 1024, T)
+        assert rc == 0 and o[0] - o[3] + o[1] == nnz, (T, o, hprlp.last_error())
+        assert 400_000 <= o[5] <= 900_000, o                    # 16 of ~24-48 per row and tile staged, the far entries not
+    # ragged: empty rows, rows of 1..200 entries, everything in ONE tile column range (up to 50 layers' worth: overflow)
+    lens = rng.integers(0, 200, size=5000); lens[::7] = 0
+    r = np.repeat(np.arange(5000), lens)
+    c = rng.integers(0, 900, size=len(r))
+    A = sparse.csr_matrix((np.ones(len(r)), (r, c)), shape=(5000, 4096)); A.sum_duplicates(); A.sort_indices()
+    rc, o = tiled_check(5000, 4096, A.indptr.astype(np.int32), A.indices.astype(np.int32), 1024, 1024)
+    assert rc == 0 and o[0] - o[3] + o[1] == A.nnz and o[1] > 0, (o, hprlp.last_error())
+    # the check itself notices a broken pattern description: the builder refuses nothing here, but a declined build is an error
+    rc, _ = tiled_check(m, m, rp, ci, 1024, 1024, min_dense=1.01)
+    assert rc == -1 and "declined" in hprlp.last_error()
