@@ -951,6 +951,7 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
             else if (M.declined_l2) d += " [tiled form not attempted: the stream kernel's gathers stay in one L2]";
             else if (M.declined_shape) d += " [tiled form not attempted: shape]";
             else if (M.declined_sparse) d += " [tiled form declined: too few entries in dense tiles]";
+            else if (M.declined_few_rows) d += " [tiled form not attempted: too few rows]";
             return d;
         }
         d += t.n_pieces > 0 ? "tiled, piece form (k_tiled_part + k_tiled_finish, " + std::to_string(t.n_pieces) + " pieces)"
@@ -960,6 +961,8 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
         if (t.R != kTileRows || t.T != kTileCols) d += " (" + std::to_string(t.R) + " rows, tiles of " + std::to_string(t.T) + " columns)";
         const double all = static_cast<double>(M.tiled.dense_entries) + static_cast<double>(M.tiled.n_rem);
         if (all > 0) d += ", " + std::to_string(static_cast<int>(100.0 * M.tiled.dense_entries / all + 0.5)) + " % of the entries in staged tiles";
+        if (t.f_rk) d += ", source-side run tables";
+        if (t.f_work) d += ", pre-pass work list of " + std::to_string(t.n_work) + " workgroups for " + std::to_string(t.n_groups) + " source groups";
         if (t.side_nblk > 0) d += ", long rows aside (" + std::to_string(t.side_nblk) + " blocks through the stream kernel)";
         return d;
     };

@@ -14,6 +14,8 @@
 // :91-157 (scaling), src/scaling.cu:5-38, src/power_iteration.cu:60-100.
 #include "kernels.h"
 
+#include <algorithm>
+#include <vector>
 #include <cmath>
 #include <type_traits>
 
@@ -1011,6 +1013,24 @@ void launch_tiled_refresh_log(const DeviceTiled &t, const double *csr_val, doubl
                            t.n_rem, t.f_perm.p, csr_val, fval_log);
 }
 
+// What a workgroup of the pre-pass works on: source group g, entries [b, e) of its list -- the whole group, or one chunk of a
+// heavy group (tiled.h: f_work).  Workgroups are dealt round-robin over the 8 XCDs: every XCD gets a contiguous range of groups
+// (work items), so that the runs its workgroups write side by side in P (layout [super-block][group]) meet in ONE L2 and leave
+// it as whole lines.
+__device__ __forceinline__ bool far_work_item(const TiledDev &t, int &g, int &b, int &e) {
+    const int items = t.f_work ? t.n_work : t.n_groups;
+    const int per = (items + 7) / 8;
+    const int w = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (w >= items) return false;
+    if (t.f_work) {
+        const int4 d = t.f_work[w];
+        g = d.x; b = d.y; e = d.z;
+    } else {
+        g = w; b = t.f_gptr[w]; e = t.f_gptr[w + 1];
+    }
+    return b < e;
+}
+
 // Pre-pass of a tiled launch (tiled.h): one workgroup per group of kFarGroup columns of the gathered vector.  The
 // group's slice is staged in LDS with coalesced loads; the workgroup streams its remainder entries (value, local
 // column, position in P -- ascending, so the stores of one (group, super-block) run are contiguous) and writes the
@@ -1018,14 +1038,10 @@ void launch_tiled_refresh_log(const DeviceTiled &t, const double *csr_val, doubl
 template <bool LOGTERM = false>
 __global__ void __launch_bounds__(kFarThreads) k_far_products(TiledDev t, const double *__restrict__ vec, int ncols) {
     __shared__ double v[kFarGroup];
-    // workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of groups, so that the runs its
-    // workgroups write side by side in P (layout [super-block][group]) meet in ONE L2 and leave it as whole lines
-    const int per = (t.n_groups + 7) / 8;
     const int G = t.G;  // columns per source group (at most kFarGroup)
-    const int g = (blockIdx.x % 8) * per + blockIdx.x / 8, c0 = g * G, tid = threadIdx.x;
-    if (g >= t.n_groups) return;
-    const int b = t.f_gptr[g], e = t.f_gptr[g + 1];
-    if (b >= e) return;
+    int g, b, e;
+    if (!far_work_item(t, g, b, e)) return;
+    const int c0 = g * G, tid = threadIdx.x;
     const int w = min(G, ncols - c0);
     // the first batch of entries does not depend on the staged slice: its loads go out before the slice's
     constexpr int U = 4;
@@ -1076,12 +1092,10 @@ template <bool LOGTERM = false>
 __global__ void __launch_bounds__(kFarThreads) k_far_products_runs(TiledDev t, const double *__restrict__ vec, int ncols) {
     __shared__ double v[kPbRowsMax];
     __shared__ int tab[2 * kPbRunTabCap];
-    const int per = (t.n_groups + 7) / 8;
     const int G = t.G;
-    const int g = (blockIdx.x % 8) * per + blockIdx.x / 8, c0 = g * G, tid = threadIdx.x;
-    if (g >= t.n_groups) return;
-    const int b = t.f_gptr[g], e = t.f_gptr[g + 1];
-    if (b >= e) return;
+    int g, b, e;
+    if (!far_work_item(t, g, b, e)) return;
+    const int c0 = g * G, tid = threadIdx.x;
     const int w = min(G, ncols - c0);
     const int r0 = t.f_rptr[g], nr = t.f_rptr[g + 1] - r0;
     int *tab_k = tab, *tab_p = tab + kPbRunTabCap;
@@ -1129,7 +1143,7 @@ __global__ void __launch_bounds__(kFarThreads) k_far_products_runs(TiledDev t, c
 
 template <bool LOGTERM>
 static void launch_far_products(const TiledDev &t, const double *vec, int ncols, hipStream_t s) {
-    const dim3 grid((t.n_groups + 7) / 8 * 8);
+    const dim3 grid(((t.f_work ? t.n_work : t.n_groups) + 7) / 8 * 8);
     if (t.f_rk && t.G <= kPbRowsMax) hipLaunchKernelGGL(k_far_products_runs<LOGTERM>, grid, dim3(kFarThreads), 0, s, t, vec, ncols);
     else hipLaunchKernelGGL(k_far_products<LOGTERM>, grid, dim3(kFarThreads), 0, s, t, vec, ncols);
 }
@@ -1974,8 +1988,8 @@ __global__ void __launch_bounds__(kWave) k_line_density(const int *__restrict__ 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (lane == 0) {
-        atomicAdd(out, cnt);
-        atomicAdd(out + 1, static_cast<unsigned long long>(k1 - k0));
+        out[2 * blockIdx.x] = cnt;
+        out[2 * blockIdx.x + 1] = static_cast<unsigned long long>(k1 - k0);
     }
 }
 
@@ -1983,13 +1997,28 @@ double launch_line_density(const int *rowptr, const int *col, int rows, hipStrea
     if (rows < 4 * kDensityWindowRows) return 1.0;
     const int nwin = std::min(1024, rows / kDensityWindowRows);
     DBuf<unsigned long long> out;
-    out.alloc(2);
-    HIP_CHECK(hipMemsetAsync(out.p, 0, 2 * sizeof(unsigned long long), s));
+    out.alloc(static_cast<size_t>(2) * nwin);
     hipLaunchKernelGGL(k_line_density, dim3(nwin), dim3(kWave), 0, s, rowptr, col, rows, nwin, out.p);
-    unsigned long long h[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    std::vector<unsigned long long> h(static_cast<size_t>(2) * nwin);
+    HIP_CHECK(hipMemcpyAsync(h.data(), out.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    return h[1] ? static_cast<double>(h[0]) / static_cast<double>(h[1]) : 1.0;
+    // entry-weighted mean over the windows, a window's weight capped at four times the median window's entries: the windows
+    // are a 1-in-50 sample of the rows, and ONE window of heavy rows (forty budget rows of 900 random entries behind a
+    // 3M-row bidiagonal matrix: 0.6 % of the entries, a fifth of the sample's) used to lift 0.13 lines per entry over the
+    // stream kernel's threshold (held-out corpus of tools/form_regret.py, round 5)
+    std::vector<unsigned long long> ent(static_cast<size_t>(nwin));
+    for (int w = 0; w < nwin; ++w) ent[w] = h[2 * w + 1];
+    std::nth_element(ent.begin(), ent.begin() + nwin / 2, ent.end());
+    const double cap = 4.0 * static_cast<double>(std::max<unsigned long long>(ent[nwin / 2], 1));
+    double num = 0.0, den = 0.0;
+    for (int w = 0; w < nwin; ++w) {
+        const double e = static_cast<double>(h[2 * w + 1]);
+        if (e <= 0.0) continue;
+        const double wt = std::min(e, cap);
+        num += wt * static_cast<double>(h[2 * w]) / e;
+        den += wt;
+    }
+    return den > 0.0 ? num / den : 1.0;
 }
 
 __global__ void __launch_bounds__(kThreads) k_longest_row(const int *__restrict__ rowptr, int rows, int limit, int *out, unsigned long long *in_long) {

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <limits>
@@ -440,9 +441,12 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         const int rb = sb_rows, gb = far_group;  // (heights, not bit counts)
         const bool short_form = rb < kTileRows;
         // (lowered height: chosen by Solver::choose_sb_rows so that there is a super-block per workgroup slot)
-        const int min_rows = mr ? std::atoi(mr) : (short_form ? 256 * rb : 32 * kTileRows);
+        // (a copy asked for WITHOUT a dense-tile requirement -- the all-remainder form, Solver::pb_fallback_wanted -- stages no tile:
+        // the row count that makes staging pay does not apply to it)
+        const int min_rows = mr ? std::atoi(mr) : min_dense_override >= 0.0 ? 1 : (short_form ? 256 * rb : 32 * kTileRows);
         const double min_dense = min_dense_override >= 0.0 ? min_dense_override : (md ? std::atof(md) : 0.5);
         declined_sparse = false;
+        declined_few_rows = false;
         // Two more conditions on the shape (measured late in round 2, tools/longrow_ab.py):
         //  * the gathered vector must be big enough for staging it to pay: a 300k x 100k matrix passes the dense-tile test but
         //    its 0.8 MB vector lives in every L2 anyway -- stream kernel 11.5 us, tiled 30.7 us per launch.  Tiled from 2^20
@@ -472,7 +476,7 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // ... and thin rows: a piece's cost goes with the tiles it stages, the stream kernel's with the entries (1M x 1M band of 16 000
         // columns, 6 per row: pieces 0.060 ms per half-step, stream 0.041; 12 per row + dense borders: 0.102 / 0.088; 20 per row: 0.128 / 0.177)
         const double entries_per_row = rows > 0 ? static_cast<double>(nnz) / rows : 0.0;
-        line_density = (rows > 100000 && nnz > 1000000) ? launch_line_density(rowptr.p, col.p, rows, nullptr) : 1.0;
+        line_density = (rows >= 8192 && nnz > 1000000) ? launch_line_density(rowptr.p, col.p, rows, nullptr) : 1.0;
         if (pt.on) std::cerr << "[timing]   gathered 64-byte lines per entry (sampled 64-row windows): " << line_density << std::endl;
         // Rows whose neighbours gather from the same 64-byte lines (stencil rows, incidence matrices, bands a few hundred columns
         // wide) are what the stream kernel is good at: its gathers coalesce and hit the L1 / L2, and there is nothing for staged
@@ -583,6 +587,9 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         }
         if (declined_shape) {
             if (pt.on) std::cerr << "[timing]   tiled copy not attempted: " << cols << " columns, longest row " << longest << std::endl;
+        } else if (rows < min_rows) {
+            declined_few_rows = rows > 0 && nnz > 0;  // (Solver::pb_fallback_wanted)
+            if (pt.on) std::cerr << "[timing]   tiled copy not attempted: " << rows << " rows (staged tiles from " << min_rows << " on)" << std::endl;
         } else if (rows >= min_rows && rows > 0 && nnz > 0 && !host_tiling) {
             // built on the device from the device CSR arrays (tiled_build.hip); HPRLP_TILING_CHECK=1 also runs the
             // host builder and compares every array
@@ -703,6 +710,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
     const auto t0 = time_now();
     prm = *param;
     env_at_setup = env_in_effect(&env_ignored_at_setup);
+    read_hooks();
     HIP_CHECK(hipSetDevice(prm.device_number));
     HIP_CHECK(hipStreamCreate(&stream));
     m = m_loc = model->m;
@@ -778,7 +786,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             if (try_reorder(model)) {  // A now holds P A Q: transpose that
                 device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
                 pt.tick("locality ordering + device transpose of the permuted matrix");
-            } else if (pb_fallback_wanted(A)) {
+            } else if (pb_fallback_wanted(A, AT.rowptr.p, n)) {
                 choose_pb_rows(A, AT, m, n);
                 // no column locality to be had (or the ordering is disabled): every random 8-byte gather of the stream kernel
                 // would cost a 128-byte line from the Infinity Cache / HBM.  Accept the tiled form with NO dense-tile
@@ -816,7 +824,7 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             if (overlap_setup) vec_job = std::async(std::launch::async, upload_vectors, true);  // (the numbering is final here)
             AT.describe_when(n, m, nnz, trp_ready, need_tci ? tci.data() : nullptr, ht, -1.0, nullptr);
             trp_ready.wait();
-            if (pb_fallback_wanted(AT)) {
+            if (pb_fallback_wanted(AT, A.rowptr.p, m)) {
                 choose_pb_rows(AT, A, n, m);
                 AT.describe(n, m, trp.data(), nullptr, nullptr, 0.0);
             }
@@ -881,20 +889,62 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
 constexpr double kMaxTileShare = 0.6;  // choose_sb_rows: most tile bytes per entry byte a lowered super-block may stage (one round)
 constexpr double kMaxTileShareRounds = 0.9;  // ... when the height only trims a partial last round of a larger matrix
 constexpr long kPbMinCols = 800000;  // (round 4, tools/unstructured_ab.py with k_pb_fused, 10 per row: 0.5M columns 0.065 vs 0.041 ms stream, 1.0M 0.080 vs 0.123, 1.5M 0.119 vs 0.214: from where the vector outgrows a 4 MiB L2)
+constexpr int kPbFewRowsMin = 32768;   // pb_fallback_wanted: fewest rows of a matrix that takes the all-remainder form without having been through the tiled build
+constexpr long kPopularLines = 32768;      // pb_fallback_wanted: 2 MB of the gathered vector ...
+constexpr double kPopularShareMax = 0.3;   // ... that may not take more than this share of a few-row matrix' gathers
+constexpr int kPbFewRowsLow = 80000;    // ... half that height below this many rows
+constexpr int kPbFewRowsHeight = 512;  // choose_pb_rows: super-block height for such a matrix (below 32 full-height super-blocks' worth of rows)
 constexpr double kNarrowTilesFrom = 1.2;  // choose_sb_rows: entries of a row per 2048-column tile from which the copy gets 1024-column tiles
 
-bool Solver::pb_fallback_wanted(const DeviceMatrix &M) const {
+// Share of a matrix' entries whose gathers go to the `lines` most popular 64-byte lines of the gathered vector (columns 8 l .. 8 l + 7;
+// `other` is the transpose: its row lengths are the column counts).  What the stream kernel's gathers find in an L2 however far apart
+// the rows reach.
+static double popular_lines_share(const int *d_rowptr, int cols, long nnz, long lines) {
+    if (cols <= 0 || nnz <= 0 || !d_rowptr) return 0.0;
+    std::vector<int> rp(static_cast<size_t>(cols) + 1);
+    HIP_CHECK(hipMemcpy(rp.data(), d_rowptr, rp.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const long nl = (static_cast<long>(cols) + 7) / 8;
+    if (nl <= lines) return 1.0;
+    std::vector<int> deg(static_cast<size_t>(nl));
+    for (long l = 0; l < nl; ++l) deg[l] = rp[std::min<long>(8 * (l + 1), cols)] - rp[8 * l];
+    std::nth_element(deg.begin(), deg.begin() + lines, deg.end(), std::greater<int>());
+    long top = 0;
+    for (long l = 0; l < lines; ++l) top += deg[l];
+    return static_cast<double>(top) / static_cast<double>(nnz);
+}
+
+bool Solver::pb_fallback_wanted(const DeviceMatrix &M, const int *other_rowptr, int other_rows) const {
     const char *no = env_get("HPRLP_NO_PB_FALLBACK");
     if (no && no[0] == '1') return false;
     const char *nt = env_get("HPRLP_NO_TILED");
     if (nt && nt[0] == '1') return false;
-    static const long min_cols = env_get("HPRLP_PB_MIN_COLS") ? std::atol(env_get("HPRLP_PB_MIN_COLS")) : kPbMinCols;
-    static const long min_nnz = env_get("HPRLP_PB_MIN_NNZ") ? std::atol(env_get("HPRLP_PB_MIN_NNZ")) : 4000000L;  // (tests lower it)
+    const long min_cols = env_get("HPRLP_PB_MIN_COLS") ? std::atol(env_get("HPRLP_PB_MIN_COLS")) : kPbMinCols;
+    const long min_nnz = env_get("HPRLP_PB_MIN_NNZ") ? std::atol(env_get("HPRLP_PB_MIN_NNZ")) : 4000000L;  // (tests lower it)
     // a pattern whose rows stay near a diagonal keeps the stream kernel: each XCD's eighth of the rows gathers from a window of the
     // vector that its L2 holds (Solver::choose_sb_rows: xcd_gather_bytes; 0 = not estimated).  1M x 1M, band 2000, 20 per row (the
     // tiled build declines it: too many entries of a row per tile): stream 0.107 ms per half-step, all-remainder form 0.149.
     const bool in_l2 = M.xcd_gather_bytes > 0.0 && M.xcd_gather_bytes <= kStreamL2Bytes && env_get("HPRLP_PB_MIN_COLS") == nullptr;
-    return !comm && !M.view.tiled.valid && M.declined_sparse && !in_l2 && M.view.cols >= min_cols && M.view.nnz >= min_nnz;
+    // Round 5, held-out corpus (tools/form_regret.py --corpus held_out): a matrix with FEWER rows than the staged forms ask for
+    // (a super-block per CU) never reached the tiled build, so it never got here either -- and kept the stream kernel at 0.11 of
+    // 8 TB/s where its rows gather at random from millions of columns: 200k x 5M with 75 per row (the transpose of a 3-per-row
+    // matrix), x-half 0.262 ms against 0.125 here (pre-pass 0.073 + k_pb_fused 0.049, super-blocks of 512 rows); 100k x 5M with
+    // 150 per row: 0.262 against 0.140.  Taken where the rows do NOT share their lines (launch_line_density).
+    // ... and where a ROW's own column window is beyond an L2 (xcd_gather_bytes less the drift of the eighth along the diagonal =
+    // the median row span): 150k x 3M with 60 per row inside a window of 150 000 columns has every entry on a line of its own and
+    // still gathers out of 1.2 MB -- stream kernel 0.063 ms, all-remainder form 0.081.
+    const double row_window_bytes = M.xcd_gather_bytes > 0.0 ? M.xcd_gather_bytes - static_cast<double>(M.view.cols) : 0.0;
+    bool few_rows = M.declined_few_rows && M.view.rows >= kPbFewRowsMin && M.line_density >= kStreamL2LineDensity &&
+                    (M.xcd_gather_bytes <= 0.0 || row_window_bytes > kStreamL2Bytes);
+    const bool size_ok = !comm && !M.view.tiled.valid && !in_l2 && M.view.cols >= min_cols && M.view.nnz >= min_nnz;
+    if (few_rows && size_ok && !M.declined_sparse) {
+        // ... and where no small set of popular columns takes a large share of the gathers (they stay in the L2s whatever the rows'
+        // reach): set-covering pattern 200k x 2M, 50 per row, column popularity ~ c^-0.6 -- 44 % of the entries on the 32 768 most
+        // popular lines (2 MB): stream kernel 0.123 ms, all-remainder form 0.144 (uniform columns: 5 %).
+        const double share = popular_lines_share(other_rowptr, other_rows, M.view.nnz, kPopularLines);
+        if (env_get("HPRLP_TIMING")) std::cerr << "[timing] few rows: share of the entries on the " << kPopularLines << " most popular lines " << share << std::endl;
+        if (share > kPopularShareMax) few_rows = false;
+    }
+    return size_ok && (M.declined_sparse || few_rows);
 }
 
 // Super-block heights of this LP's tiled copies (tiled.h).  A matrix with fewer than 512 full-height super-blocks cannot give
@@ -928,6 +978,10 @@ void Solver::choose_pb_rows(DeviceMatrix &M, DeviceMatrix &other, int rows, int 
         const int slots = workgroup_slots();
         // at most kPbRowsMax rows (the all-remainder kernel's accumulators, kernels.hip: k_pb_fused): larger matrices take more rounds
         auto height = [&](int nrows) {
+            // (few rows: 512-row super-blocks measured best -- 200k rows: 256 / 384 / 512 / 1024 rows 0.166 / 0.148 / 0.125 / 0.142 ms,
+            // 100k rows: 0.160 / 0.153 / 0.140 / 0.193)
+            // (50k rows: 256 / 512 rows 0.170 / 0.182; 33k rows: 0.155 / 0.190)
+            if (nrows < 32 * kTileRows) return nrows < kPbFewRowsLow ? kPbFewRowsHeight / 2 : kPbFewRowsHeight;
             int r = std::max(kTileRowsMin, whole_rounds_height(nrows, slots));
             for (int k = 2; r > kPbRowsMax; ++k) r = std::max(kTileRowsMin, ((nrows + k * slots - 1) / (k * slots) + 63) / 64 * 64);
             return r;
@@ -1116,6 +1170,7 @@ void Solver::setup_shard(int m_glob, int n_glob, int row_off_, int m_loc_, int c
     prm = *param;
     comm = comm_;
     env_at_setup = env_in_effect(&env_ignored_at_setup);
+    read_hooks();
     HIP_CHECK(hipSetDevice(prm.device_number));
     HIP_CHECK(hipStreamCreate(&stream));
     m = m_glob; n = n_glob;
@@ -1583,9 +1638,15 @@ void Solver::set_sigma_lambda(double sigma_, double lambda_, bool reset_k) {
     launch_set_ctrl(ctrl.p, sigma, lambda_max, reset_k ? 1 : 0, stream);
 }
 
+// hooks that the iteration path consults: read when the solver is set up (a later change of the environment does not reach it)
+void Solver::read_hooks() {
+    hook_no_far_push = env_get("HPRLP_NO_FAR_PUSH") && env_get("HPRLP_NO_FAR_PUSH")[0] == '1';
+    hook_no_bound_codes = env_get("HPRLP_NO_BOUND_CODES") != nullptr;  // A/B runs: always read l and u
+    hook_store_x = env_get("HPRLP_STORE_X") != nullptr;                // A/B runs: every x-half reads and stores x
+}
+
 void Solver::refresh_bound_codes() {
-    static const bool off = env_get("HPRLP_NO_BOUND_CODES") != nullptr;  // A/B runs: always read l and u
-    if (off) return;
+    if (hook_no_bound_codes) return;
     if (n_loc > 0) {
         if (lu_code.n != static_cast<size_t>(n_loc)) lu_code.alloc(static_cast<size_t>(n_loc));
         launch_bound_codes(n_loc, l.p, u.p, lu_code.p, stream);
@@ -1670,16 +1731,14 @@ void Solver::prepare_overlap() {
 // The hand-off needs the PRODUCER to run the fused tiled kernel on one GPU (a super-block's rows = one source group of
 // the consumer's remainder) and the consumer to have remainder lists; HPRLP_NO_FAR_PUSH=1 keeps the pre-pass (A/B runs).
 FarPush Solver::push_into(const DeviceMatrix &consumer, const DeviceMatrix &producer) const {
-    static const bool off = env_get("HPRLP_NO_FAR_PUSH") && env_get("HPRLP_NO_FAR_PUSH")[0] == '1';
     const TiledDev &pt = producer.view.tiled;
-    if (off || comm || !pt.valid || pt.n_pieces > 0) return FarPush{};
+    if (hook_no_far_push || comm || !pt.valid || pt.n_pieces > 0) return FarPush{};
     if (consumer.view.tiled.valid && consumer.view.tiled.G != pt.R) return FarPush{};  // a source group must be ONE super-block of the producer
     return far_push_of(consumer.view);
 }
 
 int Solver::x_mode_of(int i, int count) const {
-    static const bool off = env_get("HPRLP_STORE_X") != nullptr;  // A/B runs: every x-half reads and stores x
-    if (off || overlap_enabled || !AT.view.tiled.valid) return 0;
+    if (hook_store_x || overlap_enabled || !AT.view.tiled.valid) return 0;
     return (i > 0 ? kXRebuild : 0) | (i + 1 < count ? kXNoStore : 0);
 }
 

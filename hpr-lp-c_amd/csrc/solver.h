@@ -72,6 +72,7 @@ struct DeviceMatrix {
     bool declined_coalesced = false;  // ... not attempted (a case of declined_shape): neighbouring rows gather from the same lines
     bool declined_skew = false;       // ... not attempted (a case of declined_shape): too many of the entries in long rows
     bool declined_imbalance = false;  // ... not attempted (a case of declined_shape): one block of sb_rows rows holds several times the mean
+    bool declined_few_rows = false;   // ... not attempted for the number of rows alone (fewer than a super-block per CU); Solver::pb_fallback_wanted
     double long_row_share = 0.0;      // share of the entries in rows of more than kSkewRow entries (describe_when; 0 for small matrices)
     double line_density = 1.0;     // distinct 64-byte lines of the gathered vector per entry (kernels.hip: launch_line_density)
     double xcd_gather_bytes = 0.0; // estimate by Solver::choose_sb_rows: bytes of the gathered vector an XCD's eighth of the rows reads (0: unknown)
@@ -126,7 +127,8 @@ struct Solver {
     bool try_reorder(const LP_info_cpu *model);
     void choose_sb_rows(const LP_info_cpu *model);  // super-block heights of this LP's tiled copies (tiled.h), before the matrices are described
     void choose_pb_rows(DeviceMatrix &M, DeviceMatrix &other, int rows, int other_rows);  // ... of a matrix without column locality (all-remainder form, tiled.h)
-    bool pb_fallback_wanted(const DeviceMatrix &M) const;  // unstructured large matrix: tiled form without dense-tile requirement
+    // (other_rowptr: the device row pointers of M's transpose, other_rows + 1 of them -- its view need not be described yet)
+    bool pb_fallback_wanted(const DeviceMatrix &M, const int *other_rowptr, int other_rows) const;  // unstructured large matrix: tiled form without dense-tile requirement
     // Hand-off of the remainder products between the two kernels of an iteration (kernels.h: FarPush).  far_A_ready: A's
     // remainder buffer holds the products of the current x_hat (written by the x-half's epilogue); far_AT_ready likewise
     // for y.  Every other launch on a tiled matrix refills its buffer for another vector: invalidate_far().
@@ -210,6 +212,8 @@ struct Solver {
     hipEvent_t ev_ready = nullptr, ev_done_x = nullptr, ev_done_y = nullptr;
     // the environment switches in effect when this solver was set up (env.h), and the test hooks found set but ignored
     std::string env_at_setup, env_ignored_at_setup;
+    bool hook_no_far_push = false, hook_no_bound_codes = false, hook_store_x = false;  // test hooks read once per solver (read_hooks), used every iteration
+    void read_hooks();
     bool overlap_enabled = false, overlap_ready = false, y_exchange_pending = false;
     bool overlap_spmv_first = false;  // launch order of the local SpMV and the exchange (launch_normal_pair)
     void prepare_overlap();

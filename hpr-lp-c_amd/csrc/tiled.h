@@ -134,6 +134,8 @@ constexpr int kTileLayerMin = HPRLP_TILE_LAYER_MIN;
 constexpr int kTileResidentPerCu = 2;  // 80 KiB of LDS per workgroup, 160 KiB per CU
 constexpr int kFarGroup = kTileRows;   // most source columns per workgroup of the remainder pre-pass (64 KiB of LDS); TiledDev::G
 constexpr int kFarThreads = 512;
+constexpr long kFarWorkMin = 32768;     // pre-pass work list (TiledDev::f_work): a source group is cut up from this many entries ...
+constexpr long kFarWorkOverMean = 4;    // ... and this many times the mean group on
 
 struct TileStep {
     int col0;     // first column of the tile
@@ -199,6 +201,11 @@ struct TiledDev {
     const int *f_rk = nullptr;        // first entry (index into the f lists) of a run
     const int *f_rp = nullptr;        // its position in P
     int f_maxruns = 0;                // most runs in one group (0: no tables)
+    // Work list of the pre-pass (null: one workgroup per source group).  Where one group holds several times the mean -- popular
+    // columns of a set-covering LP: 8 % of the entries in the first of 490 groups -- its list is cut into chunks of f_work_cap
+    // entries, a workgroup each: {group, first entry, one past the last, 0}, ordered by group.
+    const int4 *f_work = nullptr;
+    int n_work = 0;
 };
 
 // Host-side result of the analysis; perm arrays give, for every stored entry, its index in the CSR
@@ -243,6 +250,7 @@ struct DeviceTiled {
     DBuf<uint32_t> rq;
     DBuf<int> f_gptr, f_pos, f_perm;
     DBuf<int> f_rptr, f_rk, f_rp;
+    DBuf<int4> f_work;
     DBuf<uint16_t> f_lcol;
     TiledDev view;
     long n_tile = 0, n_rem = 0;

@@ -866,6 +866,33 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
     hipLaunchKernelGGL(k_far_gptr, dim3(grid_for(ngroups + 1)), dim3(kThreads), 0, s, ngroups, n, kout.p, f_gptr.p);
     P.alloc_zero(static_cast<size_t>(n) + 8);
     HIP_CHECK(hipStreamSynchronize(s));
+    {   // pre-pass work list: only where a source group is several times the mean (tiled.h: f_work)
+        std::vector<int> gp(static_cast<size_t>(ngroups) + 1);
+        f_gptr.download(gp.data(), gp.size());
+        const long cap = std::max<long>(kFarWorkMin, kFarWorkOverMean * static_cast<long>(n) / std::max(ngroups, 1));
+        int heaviest = 0;
+        for (int g = 0; g < ngroups; ++g) heaviest = std::max(heaviest, gp[g + 1] - gp[g]);
+        view.f_work = nullptr;
+        view.n_work = 0;
+        f_work.release();
+        if (heaviest > cap && !env_get("HPRLP_NO_FAR_WORK")) {
+            std::vector<int4> wl;
+            wl.reserve(static_cast<size_t>(ngroups) + 64);
+            for (int g = 0; g < ngroups; ++g) {
+                const long b = gp[g], e = gp[g + 1];
+                if (e <= b) continue;
+                const long parts = (e - b + cap - 1) / cap, per = (e - b + parts - 1) / parts;
+                for (long q = b; q < e; q += per) wl.push_back(make_int4(g, static_cast<int>(q), static_cast<int>(std::min(e, q + per)), 0));
+            }
+            f_work.alloc(wl.size());
+            f_work.upload(wl.data(), wl.size());
+            view.f_work = f_work.p;
+            view.n_work = static_cast<int>(wl.size());
+            if (env_get("HPRLP_TIMING"))
+                std::fprintf(stderr, "[timing]   pre-pass work list: %d workgroups for %d source groups (heaviest group %d entries, chunks of at most %ld)\n",
+                             view.n_work, ngroups, heaviest, cap);
+        }
+    }
     view.f_rptr = view.f_rk = view.f_rp = nullptr;
     view.f_maxruns = 0;
     if (view.rem_cap == kPbRemCap) {

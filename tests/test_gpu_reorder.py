@@ -392,3 +392,95 @@ def test_form_regret_tool_on_a_kronecker_graph(gpu, tmp_path):
     assert rec["forms"]["chosen"]["form"] == "stream/stream", rec["forms"]["chosen"]
     assert rec["regret"] <= 1.3, rec["regret"]
     assert rec["forms"]["tiled_8192"]["it_ms"] > 2.0 * rec["forms"]["chosen"]["it_ms"]      # what the rule avoids
+
+
+def _popular_columns_lp(m, n, per_row, power, seed):
+    """Rows of per_row entries whose columns follow a popularity law c ~ n u^power (set-covering pattern; power 1: uniform)."""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(m), per_row)
+    c = np.minimum((n * rng.random(len(r)) ** power).astype(np.int64), n - 1)
+    A = sparse.csr_matrix((np.ones(len(r)), (r, c)), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    A.data = rng.normal(size=A.nnz)
+    x0 = rng.uniform(0, 1, size=n)
+    b = A @ x0
+    return A, (m, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy(), b - 1.0, b + 1.0, np.zeros(n), np.full(n, 2.0), rng.normal(size=n))
+
+
+def _iterates(model, steps=12):
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+    d = s.describe()
+    s.scale()
+    lam, _ = s.power_iteration(max_iter=30)
+    s.init(0.7, 1.3 * lam)
+    s.iterate(steps, True)
+    out = (d, lam, {k: s.get(k) for k in ("x", "y", "x_bar", "y_bar", "z_bar")}, s.residuals(steps + 1, True)["kkt"])
+    s.close()
+    return out
+
+
+def test_prepass_work_list_cuts_heavy_source_groups(gpu):
+    """Remainder pre-pass (k_far_products / k_far_products_runs, kernels.hip) with the work list of tiled.h f_work: columns with a
+    popularity law put a third of the entries into the first source group; its list is cut into chunks, a workgroup each.  Same
+    iterates as the stream kernel (reference src/cuda_kernels/HPR_cuda_kernels.cu:203-295) to 1e-10, through the all-remainder
+    form with short runs (positions read per entry) and with long runs (run tables); without the list (HPRLP_NO_FAR_WORK) the same again."""
+    A, lp = _popular_columns_lp(60_000, 300_000, 24, 3.0, 91)
+    model = hprlp.Model.from_csr(*lp)
+    pb = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "1.01", "HPRLP_PB_MIN_COLS": "1", "HPRLP_PB_MIN_NNZ": "1", "HPRLP_DEVICE_TRANSPOSE_MIN": "1",
+          "HPRLP_NO_FAR_PUSH": "1"}
+    forms = {"short runs (k_far_products)": dict(pb, HPRLP_TILE_ROWS="256"), "long runs (k_far_products_runs)": dict(pb, HPRLP_TILE_ROWS="4096")}
+
+    def under(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return _iterates(model)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+    d0, lam0, st0, kkt0 = under({"HPRLP_NO_TILED": "1"})
+    assert d0.count("stream kernel") == 2, d0
+    for name, env in forms.items():
+        d, lam, st, kkt = under(env)
+        a_part = d.split("; A^T: ")[0]
+        assert "pre-pass work list of" in a_part and "all-remainder form" in a_part, (name, d)       # A's columns are the skewed ones
+        assert ("source-side run tables" in a_part) == name.startswith("long"), (name, d)
+        assert abs(lam - lam0) <= 1e-11 * abs(lam0), name
+        for k in st:
+            np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=f"{name}: {k}")
+        assert abs(kkt - kkt0) <= 1e-9 * (1 + abs(kkt0)), name
+        d1, lam1, st1, kkt1 = under(dict(env, HPRLP_NO_FAR_WORK="1"))
+        assert "pre-pass work list" not in d1, d1
+        for k in st:
+            np.testing.assert_allclose(st1[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=f"{name}, no work list: {k}")
+    model.free()
+
+
+def test_few_rows_and_random_columns_take_the_all_remainder_form(gpu):
+    """Selection (Solver::pb_fallback_wanted, held-out corpus of tools/form_regret.py): a matrix with fewer rows than the staged
+    forms ask for whose rows gather at random from millions of columns runs k_pb_fused on 512-row super-blocks, its 3-per-row
+    transpose the stream kernel; with popular columns (44 % of the gathers on 2 MB of the vector) it keeps the stream kernel.
+    Iterates against the stream kernel's on both."""
+    A, lp = _popular_columns_lp(100_000, 2_000_000, 50, 1.0, 92)
+    model = hprlp.Model.from_csr(*lp)
+    d, lam, st, kkt = _iterates(model, steps=6)
+    a_part, at_part = d.split("; A^T: ")[0], d.split("; A^T: ")[1]
+    assert "all-remainder form (k_pb_fused" in a_part and "(512 rows" in a_part, d
+    assert at_part.startswith("stream kernel"), d
+    os.environ["HPRLP_NO_PB_FALLBACK"] = "1"
+    try:
+        d0, lam0, st0, kkt0 = _iterates(model, steps=6)
+    finally:
+        os.environ.pop("HPRLP_NO_PB_FALLBACK", None)
+    assert "too few rows" in d0.split("; A^T: ")[0], d0
+    for k in st:
+        np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    model.free()
+    A, lp = _popular_columns_lp(100_000, 2_000_000, 50, 2.5, 93)
+    model = hprlp.Model.from_csr(*lp)
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    d = s.describe()
+    s.close(); model.free()
+    assert d.split("; A^T: ")[0].startswith("A: stream kernel") and "too few rows" in d.split("; A^T: ")[0], d

@@ -198,6 +198,114 @@ CORPUS = {
 }
 
 
+# ---- held-out patterns: LP-shaped structures generated AFTER the rules were fixed (no constant was tuned on them) --------------
+def network_incidence(nodes, arcs, reach, seed=51):
+    """Node-arc incidence matrix of a graph whose arcs join nodes at most `reach` apart: every column has two entries."""
+    rng = np.random.default_rng(seed)
+    tail = rng.integers(0, nodes, size=arcs)
+    head = (tail + rng.integers(1, reach + 1, size=arcs)) % nodes
+    a = np.arange(arcs)
+    return _csr(np.concatenate([tail, head]), np.concatenate([a, a]), nodes, arcs)
+
+
+def with_slacks(A):
+    """[A | I]: one slack column per row, as an LP in equality form carries."""
+    m = A.shape[0]
+    return sparse.hstack([A, sparse.identity(m, format="csr")]).tocsr()
+
+
+def assignment_like(N):
+    """Rows of an assignment polytope on N x N variables: row sums and column sums (2N rows, N^2 columns, strides 1 and N)."""
+    idx = np.arange(N * N)
+    return _csr(np.concatenate([idx // N, N + idx % N]), np.concatenate([idx, idx]), 2 * N, N * N)
+
+
+def set_cover(m, n, lo, hi, seed=52):
+    """Rows of lo..hi entries; column popularity follows a power law."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(lo, hi + 1, size=m)
+    r = np.repeat(np.arange(m), lens)
+    c = np.minimum((n * rng.random(len(r)) ** 2.5).astype(np.int64), n - 1)
+    return _csr(r, c, m, n)
+
+
+def multi_period(periods, rows, cols, per_row, seed=53):
+    """Time-staged LP: a period's rows read their own columns (60 %), those of t-1 (30 %) and of t-2 (10 %)."""
+    rng = np.random.default_rng(seed)
+    m, n = periods * rows, periods * cols
+    r = np.repeat(np.arange(m), per_row)
+    q = rng.random(len(r))
+    back = np.where(q < 0.6, 0, np.where(q < 0.9, 1, 2))
+    c = np.maximum(r // rows - back, 0) * cols + rng.integers(0, cols, size=len(r))
+    return _csr(r, c, m, n)
+
+
+def dense_block_tridiagonal(blocks, b):
+    i = np.arange(blocks * b)
+    rs, cs = [], []
+    for d in (-1, 0, 1):
+        for k in range(b):
+            cblk = i // b + d
+            ok = (cblk >= 0) & (cblk < blocks)
+            rs.append(i[ok]); cs.append(cblk[ok] * b + k)
+    return _csr(np.concatenate(rs), np.concatenate(cs), blocks * b, blocks * b)
+
+
+def chirp_band(m, per_row, lo, hi, seed=54):
+    """Band whose half-width grows linearly along the rows from lo to hi (fractions of the width)."""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(m), per_row)
+    half = ((lo + (hi - lo) * r / m) * m / 2).astype(np.int64) + 1
+    c = np.abs(r + (rng.random(len(r)) * 2 - 1) * half).astype(np.int64)
+    c = np.where(c > m - 1, 2 * (m - 1) - c, c)
+    return _csr(r, c, m, m)
+
+
+def two_diagonals(m, per_row, half, seed=55):
+    """A band around the diagonal and a second one half the matrix away (periodic coupling)."""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(m), per_row)
+    centre = np.where(rng.random(len(r)) < 0.5, r, (r + m // 2) % m)
+    c = (centre + rng.integers(-half, half + 1, size=len(r))) % m
+    return _csr(r, c, m, m)
+
+
+def diagonal_with_budget_rows(n, budgets, length, seed=56):
+    rng = np.random.default_rng(seed)
+    i = np.arange(n)
+    rb = np.repeat(np.arange(n, n + budgets), length)
+    cb = rng.integers(0, n, size=len(rb))
+    return _csr(np.concatenate([i, i, rb]), np.concatenate([i, (i + 1) % n, cb]), n + budgets, n)
+
+
+def fixed_column_degree(m, n, deg, seed=57):
+    rng = np.random.default_rng(seed)
+    c = np.repeat(np.arange(n), deg)
+    return _csr(rng.integers(0, m, size=len(c)), c, m, n)
+
+
+HELD_OUT = {
+    "net_incidence_local": lambda: network_incidence(1_000_000, 4_000_000, 3_000),
+    "net_incidence_global": lambda: network_incidence(800_000, 3_000_000, 799_999),
+    "net_incidence_slacks": lambda: with_slacks(network_incidence(600_000, 2_500_000, 10_000).T.tocsr()),
+    "assignment_1500": lambda: assignment_like(1500),
+    "set_cover_1Mx300k": lambda: set_cover(1_000_000, 300_000, 3, 30),
+    "set_cover_200kx2M": lambda: set_cover(200_000, 2_000_000, 20, 80),
+    "multi_period_48": lambda: multi_period(48, 20_000, 30_000, 9),
+    "multi_period_365": lambda: multi_period(365, 2_500, 4_000, 14),
+    "dense_blocks_tridiag_64": lambda: dense_block_tridiagonal(3_000, 64),
+    "chirp_band_0.05_5pct": lambda: chirp_band(1_200_000, 16, 0.0005, 0.05),
+    "two_diagonals_2000": lambda: two_diagonals(1_000_000, 18, 2_000),
+    "diag_budget_rows": lambda: diagonal_with_budget_rows(3_000_000, 40, 900),
+    "column_degree_3_wide": lambda: fixed_column_degree(100_000, 5_000_000, 3),
+    "row_degree_3_tall": lambda: fixed_column_degree(200_000, 5_000_000, 3).T.tocsr(),
+    "band_1pct_10_slacks": lambda: with_slacks(band(800_000, 1_200_000, 10, 0.01, seed=58)),
+    "band_small_300k": lambda: band(300_000, 300_000, 10, 0.01, seed=59),
+    "stencil2d_slacks_cont": lambda: with_slacks(stencil2d(1000)),
+    "powerlaw_cols_local": lambda: power_law(800_000, 800_000, 10, seed=60, local=True).T.tocsr(),
+}
+
+
 def _lp_matrix(lp):
     return sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(lp["m"], lp["n"]))
 
@@ -271,7 +379,11 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--json", default=None, help="also write the raw records here")
+    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out"),
+                    help="tuning: the 43 patterns the rules were adjusted on; held_out: LP-shaped patterns generated after the rules were fixed")
     args = ap.parse_args()
+    if args.corpus == "held_out":
+        CORPUS.clear(); CORPUS.update(HELD_OUT)
     names = list(CORPUS) if not args.only else args.only.split(",")
     if args.list:
         print("\n".join(names)); return
