@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""A/B of super-block heights for the all-remainder form (k_pb_fused) against the chosen form and the stream kernel on patterns
+of tools/form_regret.py (tuning, held-out or the few-row extras below): half-step windows, KKT error after the run (the forms must
+agree), describe line.
+
+    python tools/ab_pb_rows.py PATTERN[,PATTERN..] HEIGHT[,HEIGHT..] [FORM[,FORM..]]      (GPU box; forms: chosen, stream, pb_H, pieces0_H)
+"""
 import os, sys
 os.environ.setdefault("HPRLP_TEST_HOOKS", "1")
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")

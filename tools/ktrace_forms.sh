@@ -1,10 +1,10 @@
 #!/bin/bash
-# kernel statistics of one pattern under one forced form
+# rocprofv3 kernel statistics of one pattern of tools/ab_pb_rows.py under forced forms:  tools/ktrace_forms.sh PATTERN HEIGHTS FORM [FORM..]
 export TMPDIR=/tmp
 pat=$1; rows=$2; shift 2
 for f in "$@"; do
   out=$PWD/gpurun_out/prof_$f
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 tools/scratch/pb_rows.py $pat $rows $f > gpurun_out/prof_$f.txt 2> /dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 tools/ab_pb_rows.py $pat $rows $f > gpurun_out/prof_$f.txt 2> /dev/null
   cp "$out"/*/*kernel_stats.csv gpurun_out/prof_$f.csv; rm -rf "$out"
   echo "== $f"; cat gpurun_out/prof_$f.txt
   python3 - gpurun_out/prof_$f.csv <<'P'
