@@ -249,6 +249,7 @@ constexpr double kStreamL2LineDensity = 0.6;  // ... and only while neighbouring
                                               // multicommodity-flow LP the rule was made for: 0.35 / 0.15)
 constexpr double kCoalescedMaxRowEntries = 32.0;   // build_tiled_copy: the coalesced-rows preference for the stream kernel holds up to this many entries per row
 constexpr double kStreamL2LineDensityFused = 0.5;  // ... the same against a FUSED tiled form that needs its longest rows kept aside (build_tiled_copy)
+constexpr double kPiecesThinRows = 10.0;     // build_tiled_copy: below this many entries per row a PIECE-form copy is dropped for the stream kernel
 constexpr double kPiecesMinRowEntries = 16.0;  // ... or while rows are thin (build_tiled_copy)
 constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of the gathered vector that one 4 MiB L2 keeps beside the matrix stream
 
@@ -446,6 +447,7 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         const int min_rows = mr ? std::atoi(mr) : min_dense_override >= 0.0 ? 1 : (short_form ? 256 * rb : 32 * kTileRows);
         const double min_dense = min_dense_override >= 0.0 ? min_dense_override : (md ? std::atof(md) : 0.5);
         declined_sparse = false;
+        declined_thin = false;
         declined_few_rows = false;
         // Two more conditions on the shape (measured late in round 2, tools/longrow_ab.py):
         //  * the gathered vector must be big enough for staging it to pay: a 300k x 100k matrix passes the dense-tile test but
@@ -611,12 +613,23 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
             // 1.2M x 1.2M, 16 per row (51 % in tiles): 0.55 ms per iteration against 0.27 in the all-remainder form; band + 30 % far
             // entries (53 %): 0.39 against 0.28.  Such a copy is handed back as "too few entries in dense tiles": the
             // all-remainder form follows where the matrix is large enough for it (Solver::pb_fallback_wanted), else the stream kernel.
+            declined_thin = false;
             if (ok && tiled.view.n_pieces > 0 && !mr && !md && min_dense_override < 0.0 && env_get("HPRLP_PIECES_ANYWAY") == nullptr) {
                 const double staged = static_cast<double>(tiled.dense_entries) / std::max(1.0, static_cast<double>(tiled.dense_entries) + static_cast<double>(tiled.n_rem));
                 if (staged < kPiecesMinDense) {
                     if (pt.on) std::cerr << "[timing]   piece form with " << staged << " of the entries in staged tiles: declined" << std::endl;
                     tiled = DeviceTiled();
                     declined_sparse = true;
+                } else if (entries_per_row < kPiecesThinRows) {
+                    // Held-out corpus, round 5: a copy that passes the dense-tile test has its rows' columns close together -- and
+                    // with fewer than ten entries per row the stream kernel then beats the PIECE form whether or not an XCD's window
+                    // fits its L2 (a piece's cost goes with the tiles it stages): node-arc incidence 1M x 4M after the locality
+                    // ordering, 8 / 2 per row: 0.070 / 0.093 ms per half-step in pieces, 0.055 / 0.085 on the stream kernel; 5-, 7-
+                    // and 9-point stencils in random order (after the ordering) 5-13 % per iteration; 3M x 3M band of 300 000 columns,
+                    // 8 per row: 0.357 -> 0.327 ms (12 per row: pieces stay ahead, 0.275 against 0.293).
+                    if (pt.on) std::cerr << "[timing]   piece form with " << entries_per_row << " entries per row: the stream kernel instead" << std::endl;
+                    tiled = DeviceTiled();
+                    declined_thin = true;
                 }
             }
             const bool kept = ok && tiled.view.valid;

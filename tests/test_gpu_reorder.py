@@ -218,15 +218,25 @@ def test_permuted_grid_is_reordered_on_the_device(gpu):
     AL, AU, l, u, c = b - 1.0, b + 1.0, np.zeros(n), np.full(n, 2.0), rng.normal(size=n)
     rp, ci, v = B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.copy()
     model = hprlp.Model.from_csr(m, n, rp, ci, v, AL, AU, l, u, c)
-    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
-    info = s.info()
-    assert info["reordered"] and info["tiled"] == 3, info
-    ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, c, O.Params.default(use_CR_scaling=0))
-    s.scale()
-    st = run_steps(s, ref, 0.6, 1.4, [(7, True), (4, False)])
-    for name in NAMES_N + NAMES_M:
-        np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-12, err_msg=name)
-    s.close(); model.free()
+    # by default the reordered matrix -- tileable, but five entries per row -- runs the stream kernel (round 5: thin rows); with
+    # HPRLP_PIECES_ANYWAY the piece form of the tiled kernel, as until then
+    for env, tiled in (({}, 0), ({"HPRLP_PIECES_ANYWAY": "1"}, 3)):
+        os.environ.update(env)
+        try:
+            s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False, use_CR_scaling=False))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        info = s.info()
+        assert info["reordered"] and info["tiled"] == tiled, info
+        assert (s.describe().count("[tiled piece form declined: thin rows]") == 2) == (tiled == 0), s.describe()
+        ref = O.ScaledLP(m, n, rp, ci, v, AL, AU, l, u, c, O.Params.default(use_CR_scaling=0))
+        s.scale()
+        st = run_steps(s, ref, 0.6, 1.4, [(7, True), (4, False)])
+        for name in NAMES_N + NAMES_M:
+            np.testing.assert_allclose(s.get(name), st[name], rtol=1e-11, atol=1e-12, err_msg=name)
+        s.close()
+    model.free()
 
 
 def test_solve_batched_on_a_matrix_the_single_solver_would_reorder(gpu, lp):

@@ -16,13 +16,16 @@ real = os.dup(1); os.dup2(2, 1)
 out = lambda s: os.write(real, (s + "\n").encode())
 PB = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "1.01", "HPRLP_PB_MIN_COLS": "1", "HPRLP_PB_MIN_NNZ": "1"}
 TL = {"HPRLP_TILED_MIN_ROWS": "1", "HPRLP_TILED_MIN_DENSE": "0.0", "HPRLP_TILED_ANYWAY": "1", "HPRLP_PIECES_ANYWAY": "1"}
-envs = {"chosen": {}, "stream": {"HPRLP_NO_TILED": "1"}}
+envs = {"chosen": {}, "stream": {"HPRLP_NO_TILED": "1"},
+        "stream_reordered": {"HPRLP_TILED_MIN_DENSE": "1.01", "HPRLP_NO_PB_FALLBACK": "1"}}   # locality ordering, then both matrices on the stream kernel
 for r in sys.argv[2].split(","):
     envs["pb_%s" % r] = dict(PB, HPRLP_TILE_ROWS=r)
     envs["pieces0_%s" % r] = dict(TL, HPRLP_TILE_ROWS=r)
 if len(sys.argv) > 3:
     envs = {k: v for k, v in envs.items() if k in sys.argv[3].split(",")}
-EXTRA = {"cd3_50k": lambda: fr.fixed_column_degree(50_000, 5_000_000, 3, seed=61), "cd3_33k": lambda: fr.fixed_column_degree(33_000, 4_000_000, 3, seed=62),
+EXTRA = {"band_20pct_6": lambda: fr.band(2_000_000, 2_000_000, 6, 0.2, seed=66), "band_10pct_8": lambda: fr.band(3_000_000, 3_000_000, 8, 0.1, seed=67),
+         "band_10pct_12": lambda: fr.band(2_000_000, 2_000_000, 12, 0.1, seed=68),
+         "cd3_50k": lambda: fr.fixed_column_degree(50_000, 5_000_000, 3, seed=61), "cd3_33k": lambda: fr.fixed_column_degree(33_000, 4_000_000, 3, seed=62),
          "cd4_250k": lambda: fr.fixed_column_degree(250_000, 3_000_000, 4, seed=63), "cd3_50k_local": lambda: fr.band(50_000, 5_000_000, 300, 0.002, seed=64),
          "wide_band_150k": lambda: fr.band(150_000, 3_000_000, 60, 0.05, seed=65)}
 for name in sys.argv[1].split(","):
