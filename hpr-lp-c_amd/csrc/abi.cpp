@@ -952,6 +952,7 @@ extern "C" int hprlp_solver_describe(hprlp_solver *h, char *buf, int cap) {
             else if (M.declined_shape) d += " [tiled form not attempted: shape]";
             else if (M.declined_sparse) d += " [tiled form declined: too few entries in dense tiles]";
             else if (M.declined_thin) d += " [tiled piece form declined: thin rows]";
+            else if (M.declined_popular) d += " [tiled form declined: its remainder gathers from a few popular columns]";
             else if (M.declined_few_rows) d += " [tiled form not attempted: too few rows]";
             return d;
         }

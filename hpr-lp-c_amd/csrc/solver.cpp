@@ -249,6 +249,9 @@ constexpr double kStreamL2LineDensity = 0.6;  // ... and only while neighbouring
                                               // multicommodity-flow LP the rule was made for: 0.35 / 0.15)
 constexpr double kCoalescedMaxRowEntries = 32.0;   // build_tiled_copy: the coalesced-rows preference for the stream kernel holds up to this many entries per row
 constexpr double kStreamL2LineDensityFused = 0.5;  // ... the same against a FUSED tiled form that needs its longest rows kept aside (build_tiled_copy)
+constexpr double kFewRowsTileShare = 0.6;    // build_tiled_copy: most tile bytes per entry byte at which a matrix of few rows is still tried in the piece form
+constexpr double kPopularFarShare = 0.8;     // build_tiled_copy: share of the remainder that 2 MB of the gathered vector serve, from which ...
+constexpr double kPopularFarMinRem = 0.1;    // ... a copy with at least this share of its entries in the remainder is dropped for the stream kernel (one-L2 window)
 constexpr double kPiecesThinRows = 10.0;     // build_tiled_copy: below this many entries per row a PIECE-form copy is dropped for the stream kernel
 constexpr double kPiecesMinRowEntries = 16.0;  // ... or while rows are thin (build_tiled_copy)
 constexpr double kStreamL2Bytes = 3.0e6;  // build_tiled_copy: an XCD's share of the gathered vector that one 4 MiB L2 keeps beside the matrix stream
@@ -444,10 +447,10 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // (lowered height: chosen by Solver::choose_sb_rows so that there is a super-block per workgroup slot)
         // (a copy asked for WITHOUT a dense-tile requirement -- the all-remainder form, Solver::pb_fallback_wanted -- stages no tile:
         // the row count that makes staging pay does not apply to it)
-        const int min_rows = mr ? std::atoi(mr) : min_dense_override >= 0.0 ? 1 : (short_form ? 256 * rb : 32 * kTileRows);
+        int min_rows = mr ? std::atoi(mr) : min_dense_override >= 0.0 ? 1 : (short_form ? 256 * rb : 32 * kTileRows);
         const double min_dense = min_dense_override >= 0.0 ? min_dense_override : (md ? std::atof(md) : 0.5);
         declined_sparse = false;
-        declined_thin = false;
+        declined_thin = declined_popular = false;
         declined_few_rows = false;
         // Two more conditions on the shape (measured late in round 2, tools/longrow_ab.py):
         //  * the gathered vector must be big enough for staging it to pay: a 300k x 100k matrix passes the dense-tile test but
@@ -475,6 +478,14 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // 8 entries per row, span 2.4e5 columns: pieces 0.086 ms per half-step, stream kernel 0.068)
         const double span_est = xcd_gather_bytes > 0.0 ? std::max(0.0, xcd_gather_bytes / 8.0 - cols / 8.0) : 0.0;
         const double tile_share_full = rows > 0 && nnz > 0 ? (span_est + static_cast<double>(kTileRows) * cols / rows) * 8.0 / (static_cast<double>(nnz) / rows * kTileRows * 11.0) : 0.0;
+        // Second held-out set, round 5: FEW rows (under a super-block per CU) whose full-height tiles would still be dense -- the vector
+        // bytes a super-block stages stay under kFewRowsTileShare of its entries' bytes -- go through the tiled build after all and run the
+        // piece form: 50k x 2M with 400 random entries per row (the transpose of a 10-per-row matrix): 7 super-blocks in 512 pieces
+        // 0.101 ms per half-step, all-remainder form 0.162, stream kernel 0.291.  (100k x 5M with 150 per row: share 3.2 -- all-remainder
+        // form, Solver::pb_fallback_wanted.)
+        if (!mr && min_dense_override < 0.0 && rb == kTileRows && rows < min_rows && rows >= 4 * kTileRows && nnz >= 4000000 && xcd_gather_bytes > 0.0 &&
+            tile_share_full <= kFewRowsTileShare)
+            min_rows = rows;
         // ... and thin rows: a piece's cost goes with the tiles it stages, the stream kernel's with the entries (1M x 1M band of 16 000
         // columns, 6 per row: pieces 0.060 ms per half-step, stream 0.041; 12 per row + dense borders: 0.102 / 0.088; 20 per row: 0.128 / 0.177)
         const double entries_per_row = rows > 0 ? static_cast<double>(nnz) / rows : 0.0;
@@ -571,6 +582,10 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                     if (staged < kPiecesMinDense) {
                         tiled = DeviceTiled();
                         ok_kept = false;
+                    } else if (entries_per_row < kPiecesThinRows) {   // (as below: thin rows)
+                        tiled = DeviceTiled();
+                        ok_kept = false;
+                        declined_thin = true;
                     }
                 }
                 if (ok_kept) {
@@ -632,9 +647,25 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                     declined_thin = true;
                 }
             }
-            const bool kept = ok && tiled.view.valid;
+            bool kept = ok && tiled.view.valid;
             if (kept) {
                 tiled.build_far(cols, bs, gb);  // consumes the remainder lists the check above compares
+                // Second held-out set, round 5: what the tiles could not hold gathers from a FEW popular columns (the first-stage columns of
+                // a two-stage stochastic LP: 20 % of the entries, 160 KB of the vector) and the rest of a row from a window that an XCD's L2
+                // holds anyway: the stream kernel finds ALL of it in its L2, the tiled form sends the popular fifth through the remainder at
+                // 30 bytes per entry.  1M x 1.42M, 8 per row, 2 000 scenario blocks: lowered fused form 0.080 ms per half-step (28 % in
+                // the remainder), stream kernel 0.034.  (A band with 30 % uniformly far entries has the same share in the remainder and NO
+                // such concentration: the tiled form stays ahead, 0.237 against 0.288 ms per iteration.)
+                const bool in_one_l2 = xcd_gather_bytes > 0.0 && xcd_gather_bytes <= kStreamL2Bytes;
+                if (in_one_l2 && !mr && !md && min_dense_override < 0.0 && env_get("HPRLP_TILED_ANYWAY") == nullptr && env_get("HPRLP_PIECES_ANYWAY") == nullptr &&
+                    static_cast<double>(tiled.n_rem) >= kPopularFarMinRem * static_cast<double>(nnz) && tiled.rem_top_share >= kPopularFarShare) {
+                    if (pt.on) std::cerr << "[timing]   " << tiled.rem_top_share << " of the remainder on 2 MB of popular columns, window in one L2: the stream kernel instead" << std::endl;
+                    tiled = DeviceTiled();
+                    declined_popular = true;
+                    kept = false;
+                }
+            }
+            if (kept) {
                 view.tiled = tiled.view;
                 join_values();
                 launch_tiled_refresh(tiled, val.p, bs);

@@ -254,6 +254,7 @@ struct DeviceTiled {
     DBuf<uint16_t> f_lcol;
     TiledDev view;
     long n_tile = 0, n_rem = 0;
+    double rem_top_share = 0.0;  // build_far: share of the remainder entries in the heaviest source groups that together cover 2 MB of the gathered vector
     long dense_entries = 0, padding = 0;
     int n_steps = 0;
     void upload(const TiledHost &h, int R = kTileRows, int T = kTileCols, int rem_cap = kTileRemCap);

@@ -12,6 +12,7 @@
 // of the sizes, a second time to write tidx / tperm / the steps; remainder entries are the flagged entries in
 // original order [hipCUB select]; the per-super-block step tables (1221 entries on config 5) are finished on the host.
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
@@ -872,6 +873,15 @@ void DeviceTiled::build_far(int cols, hipStream_t s, int G) {
         const long cap = std::max<long>(kFarWorkMin, kFarWorkOverMean * static_cast<long>(n) / std::max(ngroups, 1));
         int heaviest = 0;
         for (int g = 0; g < ngroups; ++g) heaviest = std::max(heaviest, gp[g + 1] - gp[g]);
+        {   // how concentrated the remainder is (DeviceMatrix::build_tiled_copy): the heaviest groups covering 2 MB of the vector
+            std::vector<int> sz(static_cast<size_t>(ngroups));
+            for (int g = 0; g < ngroups; ++g) sz[g] = gp[g + 1] - gp[g];
+            const int k = std::max(1, std::min(ngroups, static_cast<int>((2L << 20) / (8L * G))));
+            std::nth_element(sz.begin(), sz.begin() + (k - 1), sz.end(), std::greater<int>());
+            long top = 0;
+            for (int g = 0; g < k; ++g) top += sz[g];
+            rem_top_share = static_cast<double>(top) / static_cast<double>(n);
+        }
         view.f_work = nullptr;
         view.n_work = 0;
         f_work.release();

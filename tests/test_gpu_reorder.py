@@ -494,3 +494,44 @@ def test_few_rows_and_random_columns_take_the_all_remainder_form(gpu):
     d = s.describe()
     s.close(); model.free()
     assert d.split("; A^T: ")[0].startswith("A: stream kernel") and "too few rows" in d.split("; A^T: ")[0], d
+
+
+def test_second_held_out_rules(gpu):
+    """DeviceMatrix::build_tiled_copy, second held-out set of tools/form_regret.py.  (a) Two-stage stochastic pattern: 85 % of a
+    row's entries in its scenario block, 15 % on 20 000 first-stage columns -- the lowered tiled copy would send the popular share
+    through the remainder; it is dropped for the stream kernel.  (b) 50k x 2M with 400 random entries per row (the transpose of a
+    10-per-row matrix): fewer rows than a super-block per CU, yet dense full-height tiles -- the piece form, iterates equal to the
+    stream kernel's (reference src/cuda_kernels/HPR_cuda_kernels.cu:203-295) to 1e-10."""
+    rng = np.random.default_rng(95)
+    m, rows, cols, first, per_row = 1_000_000, 500, 700, 20_000, 8
+    r = np.repeat(np.arange(m), per_row)
+    own = rng.random(len(r)) < 0.85
+    c = np.where(own, first + (r // rows) * cols + rng.integers(0, cols, size=len(r)), rng.integers(0, first, size=len(r)))
+    n = first + (m // rows) * cols
+    A = sparse.csr_matrix((np.ones(len(r)), (r, c)), shape=(m, n)); A.sum_duplicates(); A.sort_indices()
+    A.data = rng.normal(size=A.nnz)
+    b = A @ rng.uniform(0, 1, size=n)
+    model = hprlp.Model.from_csr(m, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy(), b - 1.0, b + 1.0, np.zeros(n), np.full(n, 2.0), rng.normal(size=n))
+    s = hprlp.Solver(model, hprlp.Parameters(use_presolve=False))
+    d = s.describe()
+    s.close(); model.free()
+    # (15 % on the first-stage columns: the median row's trimmed span stays inside its block, the height is lowered, the copy is built
+    # and then dropped; from about 20 % on half of the rows hold two first-stage entries, the height stays full and the one-L2 rule for
+    # the piece form says "stream kernel" before the build)
+    assert d.startswith("A: stream kernel") and "its remainder gathers from a few popular columns" in d.split("; A^T: ")[0], d
+
+    A, lp = _popular_columns_lp(2_000_000, 50_000, 10, 1.0, 96)
+    model = hprlp.Model.from_csr(*lp)
+    d, lam, st, kkt = _iterates(model, steps=6)
+    at_part = d.split("; A^T: ")[1]
+    assert d.startswith("A: stream kernel") and "piece form" in at_part and "7 super-blocks" in at_part, d
+    os.environ["HPRLP_NO_TILED"] = "1"
+    try:
+        d0, lam0, st0, kkt0 = _iterates(model, steps=6)
+    finally:
+        os.environ.pop("HPRLP_NO_TILED", None)
+    assert d0.count("stream kernel") == 2, d0
+    assert abs(lam - lam0) <= 1e-11 * abs(lam0)
+    for k in st:
+        np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    model.free()

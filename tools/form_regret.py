@@ -306,6 +306,128 @@ HELD_OUT = {
 }
 
 
+# ---- second held-out set (after rules 7-9): more LP formulations ----------------------------------------------------------------
+def transportation(S, D):
+    """Supply rows (D consecutive arcs each) and demand rows (S arcs at stride D) over S x D arc columns."""
+    a = np.arange(S * D)
+    return _csr(np.concatenate([a // D, S + a % D]), np.concatenate([a, a]), S + D, S * D)
+
+
+def multicommodity(K, nodes, arcs, reach, seed=71):
+    """K copies of a node-arc incidence matrix on the diagonal + one capacity row per arc linking its K copies."""
+    rng = np.random.default_rng(seed)
+    tail = rng.integers(0, nodes, size=arcs)
+    head = (tail + rng.integers(1, reach + 1, size=arcs)) % nodes
+    a = np.arange(arcs)
+    rs, cs = [], []
+    for k in range(K):
+        rs += [k * nodes + tail, k * nodes + head]; cs += [k * arcs + a, k * arcs + a]
+        rs.append(K * nodes + a); cs.append(k * arcs + a)
+    return _csr(np.concatenate(rs), np.concatenate(cs), K * nodes + arcs, K * arcs)
+
+
+def two_stage(scenarios, rows, cols, first, per_row, seed=72):
+    """Dual block-angular: every scenario block reads its own columns and a few of the `first` first-stage columns."""
+    rng = np.random.default_rng(seed)
+    m, n = scenarios * rows, first + scenarios * cols
+    r = np.repeat(np.arange(m), per_row)
+    own = rng.random(len(r)) < 0.8
+    c = np.where(own, first + (r // rows) * cols + rng.integers(0, cols, size=len(r)), rng.integers(0, first, size=len(r)))
+    return _csr(r, c, m, n)
+
+
+def time_expanded(nodes, T, out_deg, reach, seed=73):
+    """Arcs from (v, t) to (w, t + 1): incidence matrix, columns ordered by time."""
+    rng = np.random.default_rng(seed)
+    v = np.tile(np.repeat(np.arange(nodes), out_deg), T - 1)
+    t = np.repeat(np.arange(T - 1), nodes * out_deg)
+    w = (v + rng.integers(-reach, reach + 1, size=len(v))) % nodes
+    a = np.arange(len(v))
+    return _csr(np.concatenate([t * nodes + v, (t + 1) * nodes + w]), np.concatenate([a, a]), nodes * T, len(a))
+
+
+def lot_sizing(items, T):
+    """Three variable families (production, stock, set-up) per item and period; balance and set-up rows."""
+    i = np.arange(items * T)
+    n1 = items * T
+    prev = np.where(i % T > 0, i - 1, i)
+    rs = [i, i, i, n1 + i, n1 + i]
+    cs = [i, n1 + i, n1 + prev, i, 2 * n1 + i]
+    return _csr(np.concatenate(rs), np.concatenate(cs), 2 * n1, 3 * n1)
+
+
+def facility_location(I, J):
+    """x_ij <= y_j rows (two entries) and one assignment row per customer (J entries)."""
+    a = np.arange(I * J)
+    rs = [a, a, I * J + a // J]
+    cs = [a, I * J + a % J, a]
+    return _csr(np.concatenate(rs), np.concatenate(cs), I * J + I, I * J + J)
+
+
+def two_densities(m, n, seed=74):
+    """First half of the rows 3 entries, second half 40: blocks of very different weight."""
+    rng = np.random.default_rng(seed)
+    lens = np.where(np.arange(m) < m // 2, 3, 40)
+    r = np.repeat(np.arange(m), lens)
+    c = np.abs((r * (n / m)).astype(np.int64) + rng.integers(-5000, 5001, size=len(r)))
+    c = np.where(c > n - 1, 2 * (n - 1) - c, c)
+    return _csr(r, c, m, n)
+
+
+def path_with_chords(n, chord_share, seed=75):
+    rng = np.random.default_rng(seed)
+    i = np.arange(n)
+    k = int(n * chord_share)
+    rc = rng.integers(0, n, size=k)
+    return _csr(np.concatenate([i, i, rc]), np.concatenate([i, (i + 1) % n, rng.integers(0, n, size=k)]), n, n)
+
+
+def power_law_blocks(total, seed=76):
+    """Dense-ish diagonal blocks whose sizes follow a power law (8 entries per row inside the block)."""
+    rng = np.random.default_rng(seed)
+    sizes = []
+    while sum(sizes) < total:
+        sizes.append(int(min(200_000, 200 * (rng.pareto(1.1) + 1))))
+    start = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+    n = int(sum(sizes))
+    blk = np.repeat(np.arange(len(sizes)), sizes)
+    r = np.repeat(np.arange(n), 8)
+    c = start[blk[r]] + (rng.random(len(r)) * np.asarray(sizes)[blk[r]]).astype(np.int64)
+    return _csr(r, c, n, n)
+
+
+def hub_network(nodes, arcs, seed=77):
+    """Node-arc incidence with power-law node degrees (hubs of thousands of arcs, capped at 1000)."""
+    rng = np.random.default_rng(seed)
+    w = (rng.pareto(1.3, size=nodes) + 1.0)
+    w = np.minimum(w, np.sort(w)[-1] * 0 + 400.0)
+    p = w / w.sum()
+    tail = rng.choice(nodes, size=arcs, p=p)
+    head = rng.integers(0, nodes, size=arcs)
+    a = np.arange(arcs)
+    return _csr(np.concatenate([tail, head]), np.concatenate([a, a]), nodes, arcs)
+
+
+HELD_OUT_2 = {
+    "transportation_1000x3000": lambda: transportation(1000, 3000),
+    "multicommodity_12": lambda: multicommodity(12, 40_000, 160_000, 500),
+    "multicommodity_40_global": lambda: multicommodity(40, 10_000, 60_000, 9_999),
+    "two_stage_200": lambda: two_stage(200, 5_000, 8_000, 2_000, 10),
+    "two_stage_2000": lambda: two_stage(2000, 500, 700, 20_000, 8),
+    "time_expanded_48": lambda: time_expanded(40_000, 48, 3, 200),
+    "lot_sizing_20000x52": lambda: lot_sizing(20_000, 52),
+    "facility_location_2000x1000": lambda: facility_location(2000, 1000),
+    "two_densities": lambda: two_densities(1_200_000, 1_200_000),
+    "path_with_chords_6M": lambda: path_with_chords(6_000_000, 0.1),
+    "tall_2Mx50k_10": lambda: fixed_column_degree(50_000, 2_000_000, 10, seed=78).T.tocsr(),
+    "wide_30kx3M_200": lambda: fixed_column_degree(30_000, 3_000_000, 2, seed=79),
+    "power_law_blocks": lambda: power_law_blocks(1_500_000),
+    "hub_network": lambda: hub_network(500_000, 4_000_000),
+    "grid_pde_slacks_pm": lambda: sparse.hstack([stencil2d(1100), sparse.identity(1100 * 1100), sparse.identity(1100 * 1100)]).tocsr(),
+    "band_300kx4M_40": lambda: band(300_000, 4_000_000, 40, 0.3, seed=80),
+}
+
+
 def _lp_matrix(lp):
     return sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(lp["m"], lp["n"]))
 
@@ -381,11 +503,11 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--json", default=None, help="also write the raw records here")
-    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out"),
+    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out", "held_out_2"),
                     help="tuning: the 43 patterns the rules were adjusted on; held_out: LP-shaped patterns generated after the rules were fixed")
     args = ap.parse_args()
-    if args.corpus == "held_out":
-        CORPUS.clear(); CORPUS.update(HELD_OUT)
+    if args.corpus != "tuning":
+        CORPUS.clear(); CORPUS.update(HELD_OUT if args.corpus == "held_out" else HELD_OUT_2)
     names = list(CORPUS) if not args.only else args.only.split(",")
     if args.list:
         print("\n".join(names)); return
