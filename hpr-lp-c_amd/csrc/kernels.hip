@@ -158,11 +158,26 @@ __global__ void __launch_bounds__(kThreads) k_spmv_fused(CsrDev A, Epi epi) {
                     s[v] += term<Epi>(a3, g3);
                 }
             }
-            for (; j < nz; j += kWave) {
-                double a0 = val[j];
-                int c0 = col[j];
+            if (j < nz) {
+                // the tail: at most three more entries per lane (j + 3 * kWave >= nz here), in ONE clamped, masked step with all loads
+                // in flight.  It was a loop of one load + one dependent gather per trip: a row of 65..255 entries never enters the
+                // loops above and paid three serial round trips to memory (192-entry rows of a dense-block matrix: the whole launch
+                // 0.166 -> 0.129 ms; rows of 1000-3000: 3-4 %).  Same additions in the same order.  (Measured and not kept, same box:
+                // wave-uniform trips with a three- or four-wide tail: 0.139-0.148 ms on the 192-entry rows, 3-5 % ahead on rows of
+                // 1000-3000.)
+                const int last = nz - 1;
+                const int q1 = min(j + kWave, last), q2 = min(j + 2 * kWave, last);
+                const double a0 = val[j], a1 = val[q1], a2 = val[q2];
+                const int c0 = col[j], c1 = col[q1], c2 = col[q2];
+                const bool m1 = j + kWave < nz, m2 = j + 2 * kWave < nz;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) s[v] += term<Epi>(a0, epi.gv[v][c0]);
+                for (int v = 0; v < NV; ++v) {
+                    const double *__restrict__ g = epi.gv[v];
+                    const double g0 = g[c0], g1 = g[c1], g2 = g[c2];
+                    s[v] += term<Epi>(a0, g0);
+                    if (m1) s[v] += term<Epi>(a1, g1);
+                    if (m2) s[v] += term<Epi>(a2, g2);
+                }
             }
 #pragma unroll
             for (int v = 0; v < NV; ++v) s[v] = wave_sum(s[v]);
