@@ -548,6 +548,24 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
                 std::cerr << "[timing]   tiled forms declined for the row lengths: " << (declined_skew ? "skew" : "imbalance") << " (share of the entries in rows over "
                           << kSkewRow << ": " << long_row_share << ")" << std::endl;
         }
+        // Thin rows (rule below, after the build: a PIECE-form copy of a matrix with under kPiecesThinRows entries per row is dropped
+        // for the stream kernel) decided BEFORE the build where the cheap tiling test (a sort of the entries' tile keys, under a
+        // millisecond; the locality ordering's acceptance test) already says the copy would pass: the build and its drop were
+        // 20-65 ms per matrix of a 0.5 s solve (two-stage LP: 0.126 s of 0.57).
+        {
+            const bool pieces_expected = rb == kTileRows && (rows + rb - 1) / rb <= workgroup_slots();
+            if ((!declined_shape || long_only) && pieces_expected && rows >= min_rows && nnz > 0 && entries_per_row < kPiecesThinRows && !host_tiling && !mr && !md &&
+                min_dense_override < 0.0 && env_get("HPRLP_PIECES_ANYWAY") == nullptr && env_get("HPRLP_TILED_ANYWAY") == nullptr &&
+                env_get("HPRLP_TILING_CHECK") == nullptr) {
+                const double share = device_tiling_dense_fraction(rows, cols, nnz, rowptr.p, col.p, nullptr, nullptr, bs);
+                if (pt.on) std::cerr << "[timing]   thin rows (" << entries_per_row << " per row), tiling test: " << share << " of the entries in dense tiles" << std::endl;
+                if (share >= kPiecesMinDense) {
+                    declined_thin = true;
+                    pt.tick("  tiling test (thin rows: the stream kernel without a build)");
+                    return;
+                }
+            }
+        }
         // A FEW long rows (dense LP columns / rows) do not have to cost the matrix the tiled kernel: they are left out of the
         // tiled copy and summed by the stream kernel's vector / split-row mode into a base vector that every tiled launch
         // adds (tiled.h: TiledDev::side_*).  At most 0.1 % of the rows (and 64) and a fifth of the nonzeros.
