@@ -249,7 +249,9 @@ constexpr double kStreamL2LineDensity = 0.6;  // ... and only while neighbouring
                                               // multicommodity-flow LP the rule was made for: 0.35 / 0.15)
 constexpr double kCoalescedMaxRowEntries = 32.0;   // build_tiled_copy: the coalesced-rows preference for the stream kernel holds up to this many entries per row
 constexpr double kStreamL2LineDensityFused = 0.5;  // ... the same against a FUSED tiled form that needs its longest rows kept aside (build_tiled_copy)
-constexpr double kFewRowsTileShare = 0.6;    // build_tiled_copy: most tile bytes per entry byte at which a matrix of few rows is still tried in the piece form
+constexpr double kFewRowsTileShare = 1.8;    // build_tiled_copy: most tile bytes per entry byte at which a matrix of few rows is still tried in the piece form
+                                             // (threshold sweep, tools/form_regret.py --corpus boundaries: piece form ahead of the all-remainder form by 12-41 % at
+                                             // 0.8 / 1.2 / 1.5, level at 1.3, behind by 8-17 % at 2.2 / 2.8 and 2-3 x from 3.2 on)
 constexpr double kPopularFarShare = 0.8;     // build_tiled_copy: share of the remainder that 2 MB of the gathered vector serve, from which ...
 constexpr double kPopularFarMinRem = 0.1;    // ... a copy with at least this share of its entries in the remainder is dropped for the stream kernel (one-L2 window)
 constexpr double kPiecesThinRows = 10.0;     // build_tiled_copy: below this many entries per row a PIECE-form copy is dropped for the stream kernel
@@ -479,7 +481,7 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         const double span_est = xcd_gather_bytes > 0.0 ? std::max(0.0, xcd_gather_bytes / 8.0 - cols / 8.0) : 0.0;
         const double tile_share_full = rows > 0 && nnz > 0 ? (span_est + static_cast<double>(kTileRows) * cols / rows) * 8.0 / (static_cast<double>(nnz) / rows * kTileRows * 11.0) : 0.0;
         // Second held-out set, round 5: FEW rows (under a super-block per CU) whose full-height tiles would still be dense -- the vector
-        // bytes a super-block stages stay under kFewRowsTileShare of its entries' bytes -- go through the tiled build after all and run the
+        // bytes a super-block stages stay under kFewRowsTileShare times its entries' bytes -- go through the tiled build after all and run the
         // piece form: 50k x 2M with 400 random entries per row (the transpose of a 10-per-row matrix): 7 super-blocks in 512 pieces
         // 0.101 ms per half-step, all-remainder form 0.162, stream kernel 0.291.  (100k x 5M with 150 per row: share 3.2 -- all-remainder
         // form, Solver::pb_fallback_wanted.)

@@ -428,6 +428,18 @@ HELD_OUT_2 = {
 }
 
 
+# ---- threshold sweep: the few-row rules (7, 11) around their size limits -------------------------------------------------------
+BOUNDARIES = {}
+for _rows in (25_000, 40_000, 70_000, 90_000, 150_000, 250_000, 300_000):
+    BOUNDARIES["cd3_%dk_x3M" % (_rows // 1000)] = (lambda r=_rows: fixed_column_degree(r, 3_000_000, 3, seed=81))
+for _cols in (400_000, 700_000, 900_000, 1_500_000):
+    BOUNDARIES["cd8_100k_x%dk" % (_cols // 1000)] = (lambda c=_cols: fixed_column_degree(100_000, c, 8, seed=82))
+for _deg in (1, 2):
+    BOUNDARIES["cd%d_100k_x2M" % _deg] = (lambda d=_deg: fixed_column_degree(100_000, 2_000_000, d, seed=83))
+for _rows in (40_000, 100_000, 200_000):
+    BOUNDARIES["tallT_%dk_x2M_dense" % (_rows // 1000)] = (lambda r=_rows: fixed_column_degree(r, 2_000_000, 12, seed=84))
+
+
 def _lp_matrix(lp):
     return sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(lp["m"], lp["n"]))
 
@@ -503,11 +515,11 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--json", default=None, help="also write the raw records here")
-    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out", "held_out_2"),
+    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out", "held_out_2", "boundaries"),
                     help="tuning: the 43 patterns the rules were adjusted on; held_out: LP-shaped patterns generated after the rules were fixed")
     args = ap.parse_args()
     if args.corpus != "tuning":
-        CORPUS.clear(); CORPUS.update(HELD_OUT if args.corpus == "held_out" else HELD_OUT_2)
+        CORPUS.clear(); CORPUS.update({"held_out": HELD_OUT, "held_out_2": HELD_OUT_2, "boundaries": BOUNDARIES}[args.corpus])
     names = list(CORPUS) if not args.only else args.only.split(",")
     if args.list:
         print("\n".join(names)); return
