@@ -247,6 +247,8 @@ constexpr double kStreamLineDensity = 0.25;  // build_tiled_copy: at most this m
 constexpr double kStreamL2LineDensity = 0.6;  // ... and only while neighbouring rows still share lines: with a line per entry the L2 holds the window but every gather
                                               // misses the L1 (1.5M x 1.5M, band 75 000, 0.93 lines per entry: stream 0.177 ms per half-step, pieces 0.128; the
                                               // multicommodity-flow LP the rule was made for: 0.35 / 0.15)
+constexpr int kTiledMinCols = 7 << 16;        // build_tiled_copy: fewest columns of a matrix that is tried in a tiled form (458 752: 3.5 MiB of gathered vector)
+constexpr double kStreamLineDensityLong = 0.12;  // ... lines per entry up to which rows of ANY length keep the coalesced-rows preference
 constexpr double kCoalescedMaxRowEntries = 32.0;   // build_tiled_copy: the coalesced-rows preference for the stream kernel holds up to this many entries per row
 constexpr double kStreamL2LineDensityFused = 0.5;  // ... the same against a FUSED tiled form that needs its longest rows kept aside (build_tiled_copy)
 constexpr double kFewRowsTileShare = 1.8;    // build_tiled_copy: most tile bytes per entry byte at which a matrix of few rows is still tried in the piece form
@@ -464,7 +466,9 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         const char *mc = env_get("HPRLP_TILED_MIN_COLS");
         // (2^19 columns = 4 MiB = one L2.  Until round 5 the full-height form waited for 800 k columns: a 600k x 600k band of 40 000
         // columns, 40 per row, kept the stream kernel at 0.25 of 8 TB/s where the piece form runs 0.33 and the lowered fused form 0.36)
-        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : (1 << 19));
+        // (7 * 2^16 since the threshold sweep of round 5: 2 % band, 20 per row: 400 k columns stream 0.070 / lowered tiled 0.078 ms,
+        // 500 k columns 0.098 / 0.082 -- the vector shares its L2 with the matrix stream)
+        const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : kTiledMinCols);
         const int longest = longest_row;  // (describe_when)
         declined_shape = cols < min_cols || longest > kTileMaxRow;
         // Round 4, late.  A matrix of fewer full-height super-blocks than workgroup slots whose height could not be lowered (its
@@ -507,7 +511,10 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // (rows of more than kCoalescedMaxRowEntries entries excepted: the stream kernel packs 512 entries per wave, so 60-entry rows leave
         // it 8 busy lanes in its row-sum phase -- 600k x 600k, 60 per row in 6 000 columns, 0.2 lines per entry: stream 0.24 / 0.35 of
         // 8 TB/s, lowered tiled form with three layers per tile 0.42 / 0.50)
-        if ((!declined_shape || long_only) && line_density <= kStreamLineDensity && entries_per_row <= kCoalescedMaxRowEntries && !mr && min_dense_override < 0.0 &&
+        // (... unless the rows share their lines almost completely: 1M x 1M, 40 / 48 per row inside 1 500 columns, 0.08 lines per entry:
+        // stream 0.243 / 0.298 ms per iteration, lowered tiled form 0.274 / 0.359 -- threshold sweep, round 5)
+        if ((!declined_shape || long_only) && line_density <= kStreamLineDensity && (entries_per_row <= kCoalescedMaxRowEntries || line_density <= kStreamLineDensityLong) &&
+            !mr && min_dense_override < 0.0 &&
             env_get("HPRLP_TILED_ANYWAY") == nullptr)
             declined_shape = declined_coalesced = true;
         {

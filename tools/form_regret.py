@@ -438,6 +438,16 @@ for _deg in (1, 2):
     BOUNDARIES["cd%d_100k_x2M" % _deg] = (lambda d=_deg: fixed_column_degree(100_000, 2_000_000, d, seed=83))
 for _rows in (40_000, 100_000, 200_000):
     BOUNDARIES["tallT_%dk_x2M_dense" % (_rows // 1000)] = (lambda r=_rows: fixed_column_degree(r, 2_000_000, 12, seed=84))
+# ... the thin-rows limit of the piece form (rule 8), the all-remainder form's column limit, the tiled forms' column limit
+BOUNDARIES_2 = {}
+for _d in (7, 9, 10, 11, 13, 16):
+    BOUNDARIES_2["band_10pct_%d" % _d] = (lambda d=_d: band(2_500_000, 2_500_000, d, 0.1, seed=85))
+for _c in (500_000, 700_000, 900_000, 1_200_000):
+    BOUNDARIES_2["uniform_1Mx%dk_10" % (_c // 1000)] = (lambda c=_c: band(1_000_000, c, 10, 1.0, seed=86))
+for _c in (400_000, 500_000, 600_000, 800_000):
+    BOUNDARIES_2["band_2pct_%dk_20" % (_c // 1000)] = (lambda c=_c: band(c, c, 20, 0.02, seed=87))
+for _d in (24, 32, 40, 48):
+    BOUNDARIES_2["band_0.15pct_%d" % _d] = (lambda d=_d: band(1_000_000, 1_000_000, d, 0.0015, seed=88))
 
 
 def _lp_matrix(lp):
@@ -515,11 +525,11 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--json", default=None, help="also write the raw records here")
-    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out", "held_out_2", "boundaries"),
+    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out", "held_out_2", "boundaries", "boundaries_2"),
                     help="tuning: the 43 patterns the rules were adjusted on; held_out: LP-shaped patterns generated after the rules were fixed")
     args = ap.parse_args()
     if args.corpus != "tuning":
-        CORPUS.clear(); CORPUS.update({"held_out": HELD_OUT, "held_out_2": HELD_OUT_2, "boundaries": BOUNDARIES}[args.corpus])
+        CORPUS.clear(); CORPUS.update({"held_out": HELD_OUT, "held_out_2": HELD_OUT_2, "boundaries": BOUNDARIES, "boundaries_2": BOUNDARIES_2}[args.corpus])
     names = list(CORPUS) if not args.only else args.only.split(",")
     if args.list:
         print("\n".join(names)); return
