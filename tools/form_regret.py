@@ -450,6 +450,75 @@ for _d in (24, 32, 40, 48):
     BOUNDARIES_2["band_0.15pct_%d" % _d] = (lambda d=_d: band(1_000_000, 1_000_000, d, 0.0015, seed=88))
 
 
+# ---- third held-out set: measured ONCE at the end of round 5 and not tuned on (validation of rules 1-12) ------------------------
+def knapsack_rows(rows, n, share, seed=91):
+    rng = np.random.default_rng(seed)
+    per = int(n * share)
+    r = np.repeat(np.arange(rows), per)
+    c = np.concatenate([np.sort(rng.choice(n, per, replace=False)) for _ in range(rows)])
+    i = np.arange(n)
+    return _csr(np.concatenate([r, rows + i]), np.concatenate([c, i]), rows + n, n)
+
+
+def sliding_window_schedule(tasks, T, w):
+    """Row (task, t) reads the task's start variables of the last w periods; one capacity row per period over all tasks."""
+    tt = np.arange(tasks * T)
+    rs, cs = [], []
+    for d in range(w):
+        ok = (tt % T) >= d
+        rs.append(tt[ok]); cs.append(tt[ok] - d)
+    rs.append(tasks * T + tt % T); cs.append(tt)
+    return _csr(np.concatenate(rs), np.concatenate(cs), tasks * T + T, tasks * T)
+
+
+def network_design(nodes, arcs, reach, seed=92):
+    rng = np.random.default_rng(seed)
+    tail = rng.integers(0, nodes, size=arcs)
+    head = (tail + rng.integers(1, reach + 1, size=arcs)) % nodes
+    a = np.arange(arcs)
+    return _csr(np.concatenate([tail, head, nodes + a, nodes + a]), np.concatenate([a, a, a, arcs + a]), nodes + arcs, 2 * arcs)
+
+
+def anti_diagonal_band(m, per_row, half, seed=93):
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(m), per_row)
+    c = np.clip(m - 1 - r + rng.integers(-half, half + 1, size=len(r)), 0, m - 1)
+    return _csr(r, c, m, m)
+
+
+def b_matching(nodes, edges, seed=94):
+    rng = np.random.default_rng(seed)
+    w = rng.pareto(1.2, size=nodes) + 1.0
+    p = w / w.sum()
+    a = np.arange(edges)
+    return _csr(np.concatenate([rng.choice(nodes, size=edges, p=p), rng.integers(0, nodes, size=edges)]), np.concatenate([a, a]), nodes, edges)
+
+
+def small_dense_blocks(blocks, bm, bn):
+    r = np.repeat(np.arange(blocks * bm), bn)
+    c = (r // bm) * bn + np.tile(np.arange(bn), blocks * bm)
+    return _csr(r, c, blocks * bm, blocks * bn)
+
+
+def axial_transportation(N):
+    """x_ijk with the three families of two-index sums: 3 N^2 rows of N entries at strides 1, N and N^2."""
+    idx = np.arange(N ** 3)
+    i, j, k = idx // (N * N), (idx // N) % N, idx % N
+    return _csr(np.concatenate([i * N + j, N * N + j * N + k, 2 * N * N + i * N + k]), np.concatenate([idx, idx, idx]), 3 * N * N, N ** 3)
+
+
+HELD_OUT_3 = {
+    "knapsack_40_rows": lambda: knapsack_rows(40, 1_500_000, 0.1),
+    "sliding_window_12": lambda: sliding_window_schedule(20_000, 100, 12),
+    "cover_300kx3M_coldeg4": lambda: fixed_column_degree(300_000, 3_000_000, 4, seed=95),
+    "network_design": lambda: network_design(600_000, 2_000_000, 5_000),
+    "anti_diagonal_band": lambda: anti_diagonal_band(1_500_000, 14, 8_000),
+    "b_matching_hubs": lambda: b_matching(400_000, 5_000_000),
+    "small_dense_blocks_30x50": lambda: small_dense_blocks(30_000, 30, 50),
+    "axial_transportation_130": lambda: axial_transportation(130),
+}
+
+
 def _lp_matrix(lp):
     return sparse.csr_matrix((lp["values"], lp["colind"], lp["rowptr"]), shape=(lp["m"], lp["n"]))
 
@@ -525,11 +594,11 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--json", default=None, help="also write the raw records here")
-    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out", "held_out_2", "boundaries", "boundaries_2"),
+    ap.add_argument("--corpus", default="tuning", choices=("tuning", "held_out", "held_out_2", "boundaries", "boundaries_2", "held_out_3"),
                     help="tuning: the 43 patterns the rules were adjusted on; held_out: LP-shaped patterns generated after the rules were fixed")
     args = ap.parse_args()
     if args.corpus != "tuning":
-        CORPUS.clear(); CORPUS.update({"held_out": HELD_OUT, "held_out_2": HELD_OUT_2, "boundaries": BOUNDARIES, "boundaries_2": BOUNDARIES_2}[args.corpus])
+        CORPUS.clear(); CORPUS.update({"held_out": HELD_OUT, "held_out_2": HELD_OUT_2, "boundaries": BOUNDARIES, "boundaries_2": BOUNDARIES_2, "held_out_3": HELD_OUT_3}[args.corpus])
     names = list(CORPUS) if not args.only else args.only.split(",")
     if args.list:
         print("\n".join(names)); return
