@@ -34,6 +34,7 @@ static const EnvEntry kTable[] = {
     {"HPRLP_NO_BOUND_CODES", EnvKind::Hook, "the x-half always reads l[j] and u[j], the y-half AL[i] and AU[i] (default: one code byte per column / row says which of them is not a constant; an equality row reads one value)"},
     {"HPRLP_NO_FAR_PUSH", EnvKind::Hook, "always run the remainder pre-pass (k_far_products) instead of the hand-off from the producing half-step's epilogue"},
     {"HPRLP_NO_FAR_WORK", EnvKind::Hook, "the remainder pre-pass with one workgroup per source group also where one group holds several times the mean (default: a work list cuts heavy groups into chunks, tiled.h f_work)"},
+    {"HPRLP_NO_PB_LONG_ROWS", EnvKind::Hook, "a matrix kept off the tiled forms for its long rows keeps the stream kernel also where its columns are not popular (default: all-remainder form, Solver::pb_fallback_wanted)"},
     {"HPRLP_NO_FUSED_NORMS", EnvKind::Hook, "the Ruiz row norms by their own passes instead of as a by-product of the preceding scaling pass (same bits)"},
     {"HPRLP_NO_LONG_SIDE", EnvKind::Hook, "a matrix with rows over 1024 entries keeps the stream kernel instead of being tiled with those rows kept aside"},
     {"HPRLP_NO_PB_FALLBACK", EnvKind::Hook, "unstructured large matrices keep the stream kernel instead of the tiled form without dense-tile requirement"},

@@ -470,7 +470,10 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
         // 500 k columns 0.098 / 0.082 -- the vector shares its L2 with the matrix stream)
         const int min_cols = mc ? std::atoi(mc) : (mr ? 0 : kTiledMinCols);
         const int longest = longest_row;  // (describe_when)
-        declined_shape = cols < min_cols || longest > kTileMaxRow;
+        // (an all-remainder copy -- min_dense_override >= 0 -- takes rows of any length: its steps add a row's products by a segmented
+        // reduction over the lanes, Solver::pb_fallback_wanted)
+        declined_shape = cols < min_cols || (longest > kTileMaxRow && min_dense_override < 0.0);
+        declined_long_rows = false;
         // Round 4, late.  A matrix of fewer full-height super-blocks than workgroup slots whose height could not be lowered (its
         // rows' column windows are too wide for short super-blocks) would run the piece form: partial sums through memory and a
         // finish launch.  When the stream kernel's gathers stay inside one L2 anyway -- every XCD runs a contiguous eighth of the
@@ -630,6 +633,9 @@ void DeviceMatrix::build_tiled_copy(int rows, int cols, int nnz, const std::func
             }
         }
         if (declined_shape) {
+            // declined for its row lengths alone (longest row, or too many entries in long rows) -- not because its rows share lines or
+            // gather from one L2's window: a candidate for the all-remainder form where the COLUMNS are not popular (pb_fallback_wanted)
+            declined_long_rows = cols >= min_cols && longest > kTileMaxRow && !declined_coalesced && !declined_l2 && !declined_imbalance && rows > 0 && nnz > 0;
             if (pt.on) std::cerr << "[timing]   tiled copy not attempted: " << cols << " columns, longest row " << longest << std::endl;
         } else if (rows < min_rows) {
             declined_few_rows = rows > 0 && nnz > 0;  // (Solver::pb_fallback_wanted)
@@ -963,6 +969,7 @@ constexpr long kPbMinCols = 800000;  // (round 4, tools/unstructured_ab.py with 
 constexpr int kPbFewRowsMin = 32768;   // pb_fallback_wanted: fewest rows of a matrix that takes the all-remainder form without having been through the tiled build
 constexpr long kPopularLines = 32768;      // pb_fallback_wanted: 2 MB of the gathered vector ...
 constexpr double kPopularShareMax = 0.3;   // ... that may not take more than this share of a few-row matrix' gathers
+constexpr double kPbHeaviestBlockShare = 48.0;  // pb_fallback_wanted: a matrix with long rows takes the all-remainder form only if its heaviest 4096-row block holds at most 1 / 48 of the entries
 constexpr int kPbFewRowsLow = 80000;    // ... half that height below this many rows
 constexpr int kPbFewRowsHeight = 512;  // choose_pb_rows: super-block height for such a matrix (below 32 full-height super-blocks' worth of rows)
 constexpr double kNarrowTilesFrom = 1.2;  // choose_sb_rows: entries of a row per 2048-column tile from which the copy gets 1024-column tiles
@@ -1007,6 +1014,20 @@ bool Solver::pb_fallback_wanted(const DeviceMatrix &M, const int *other_rowptr, 
     bool few_rows = M.declined_few_rows && M.view.rows >= kPbFewRowsMin && M.line_density >= kStreamL2LineDensity &&
                     (M.xcd_gather_bytes <= 0.0 || row_window_bytes > kStreamL2Bytes);
     const bool size_ok = !comm && !M.view.tiled.valid && !in_l2 && M.view.cols >= min_cols && M.view.nnz >= min_nnz;
+    // Validation set, end of round 5: a matrix kept off the tiled forms for its LONG rows (hubs of a b-matching LP: rows of up to 77 000
+    // entries, a quarter of the entries in rows over 1 024) whose columns are NOT popular gathers at random like any unstructured
+    // matrix -- stream kernel 0.12 of 8 TB/s.  k_pb_fused adds rows of any length; what it cannot take is a super-block far heavier
+    // than the chip's share (the launch ends with it).  (A Kronecker graph has popular columns: it keeps the stream kernel, rule 1.)
+    bool long_rows = false;
+    if (M.declined_long_rows && size_ok && !M.declined_sparse && !few_rows && M.line_density >= kStreamL2LineDensity && env_get("HPRLP_NO_PB_LONG_ROWS") == nullptr) {
+        const double share = popular_lines_share(other_rowptr, other_rows, M.view.nnz, kPopularLines);
+        const int heaviest = launch_heaviest_block(M.rowptr.p, M.view.rows, kPbRowsMax, stream);
+        if (env_get("HPRLP_TIMING"))
+            std::cerr << "[timing] long rows: share of the entries on the " << kPopularLines << " most popular lines " << share << ", heaviest block of " << kPbRowsMax
+                      << " rows " << heaviest << " entries of " << M.view.nnz << std::endl;
+        long_rows = share <= kPopularShareMax && static_cast<double>(heaviest) * kPbHeaviestBlockShare <= static_cast<double>(M.view.nnz);
+    }
+    if (long_rows) return true;
     if (few_rows && size_ok && !M.declined_sparse) {
         // ... and where no small set of popular columns takes a large share of the gathers (they stay in the L2s whatever the rows'
         // reach): set-covering pattern 200k x 2M, 50 per row, column popularity ~ c^-0.6 -- 44 % of the entries on the 32 768 most

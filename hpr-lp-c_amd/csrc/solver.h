@@ -74,6 +74,7 @@ struct DeviceMatrix {
     bool declined_imbalance = false;  // ... not attempted (a case of declined_shape): one block of sb_rows rows holds several times the mean
     bool declined_thin = false;       // a PIECE-form copy was built and dropped: fewer than kPiecesThinRows entries per row (stream kernel instead)
     bool declined_popular = false;    // a copy was built and dropped: its remainder gathers from a few popular columns and the rest from one L2's window
+    bool declined_long_rows = false;  // ... not attempted for the length of its rows alone (Solver::pb_fallback_wanted)
     bool declined_few_rows = false;   // ... not attempted for the number of rows alone (fewer than a super-block per CU); Solver::pb_fallback_wanted
     double long_row_share = 0.0;      // share of the entries in rows of more than kSkewRow entries (describe_when; 0 for small matrices)
     double line_density = 1.0;     // distinct 64-byte lines of the gathered vector per entry (kernels.hip: launch_line_density)

@@ -535,3 +535,35 @@ def test_second_held_out_rules(gpu):
     for k in st:
         np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
     model.free()
+
+
+def test_long_rows_with_unpopular_columns_take_the_all_remainder_form(gpu):
+    """Solver::pb_fallback_wanted, rule 13: a b-matching pattern -- node rows with power-law degrees (hubs of tens of thousands of
+    entries, a quarter of the entries in rows over 1 024), edge columns of exactly two entries -- is kept off the tiled forms for its
+    long rows, yet gathers at random from 3M columns: the all-remainder form with the hubs aside (stream kernel's split rows), its
+    two-per-row transpose on the stream kernel.  Iterates against the stream kernel's (HPRLP_NO_PB_LONG_ROWS) to 1e-10; a
+    Kronecker graph (popular columns) keeps the stream kernel."""
+    rng = np.random.default_rng(97)
+    nodes, edges = 300_000, 3_000_000
+    w = np.minimum(rng.pareto(1.2, size=nodes) + 1.0, 4000.0)   # (capped: no 4096-row block with more than 1 / 48 of the entries)
+    a = np.arange(edges)
+    r = np.concatenate([rng.choice(nodes, size=edges, p=w / w.sum()), rng.integers(0, nodes, size=edges)])
+    A = sparse.csr_matrix((np.ones(2 * edges), (r, np.concatenate([a, a]))), shape=(nodes, edges)); A.sum_duplicates(); A.sort_indices()
+    A.data = rng.normal(size=A.nnz)
+    assert np.diff(A.indptr).max() > 4096
+    b = A @ rng.uniform(0, 1, size=edges)
+    model = hprlp.Model.from_csr(nodes, edges, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy(), b - 1.0, b + 1.0, np.zeros(edges), np.full(edges, 2.0),
+                                 rng.normal(size=edges))
+    d, lam, st, kkt = _iterates(model, steps=6)
+    a_part, at_part = d.split("; A^T: ")
+    assert "all-remainder form (k_pb_fused" in a_part and "long rows aside" in a_part and at_part.startswith("stream kernel"), d
+    os.environ["HPRLP_NO_PB_LONG_ROWS"] = "1"
+    try:
+        d0, lam0, st0, kkt0 = _iterates(model, steps=6)
+    finally:
+        os.environ.pop("HPRLP_NO_PB_LONG_ROWS", None)
+    assert d0.count("stream kernel (k_spmv_fused") == 2, d0
+    assert abs(lam - lam0) <= 1e-11 * abs(lam0)
+    for k in st:
+        np.testing.assert_allclose(st[k], st0[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    model.free()

@@ -29,7 +29,7 @@ EXTRA = {"band_20pct_6": lambda: fr.band(2_000_000, 2_000_000, 6, 0.2, seed=66),
          "cd4_250k": lambda: fr.fixed_column_degree(250_000, 3_000_000, 4, seed=63), "cd3_50k_local": lambda: fr.band(50_000, 5_000_000, 300, 0.002, seed=64),
          "wide_band_150k": lambda: fr.band(150_000, 3_000_000, 60, 0.05, seed=65)}
 for name in sys.argv[1].split(","):
-    A = (EXTRA.get(name) or fr.HELD_OUT.get(name) or fr.HELD_OUT_2.get(name) or fr.CORPUS[name])().tocsr(); A.sort_indices()
+    A = (EXTRA.get(name) or fr.HELD_OUT.get(name) or fr.HELD_OUT_2.get(name) or fr.HELD_OUT_3.get(name) or fr.CORPUS[name])().tocsr(); A.sort_indices()
     A.data = np.random.default_rng(7).normal(size=A.nnz)
     m, n = A.shape
     lp = bench.planted_on(m, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64))
