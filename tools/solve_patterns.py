@@ -23,7 +23,7 @@ bench, H = fr.bench, fr.H
 real = os.dup(1); os.dup2(2, 1)
 out = lambda s: os.write(real, (s + "\n").encode())
 for name in sys.argv[1].split(","):
-    gen = fr.HELD_OUT.get(name) or fr.HELD_OUT_2.get(name) or fr.CORPUS.get(name)
+    gen = fr.HELD_OUT.get(name) or fr.HELD_OUT_2.get(name) or fr.HELD_OUT_3.get(name) or fr.CORPUS.get(name)
     A = gen().tocsr(); A.sort_indices()
     A.data = np.random.default_rng(7).normal(size=A.nnz)
     m, n = A.shape
