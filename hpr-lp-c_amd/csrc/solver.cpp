@@ -860,17 +860,27 @@ void Solver::setup(const LP_info_cpu *model, const HPRLP_parameters *param) {
             AT.val.alloc(static_cast<size_t>(nnz));
             device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
             pt.tick("device transpose");
-            if (try_reorder(model)) {  // A now holds P A Q: transpose that
+            const bool reordered = try_reorder(model);
+            if (reordered) {  // A now holds P A Q: transpose that
                 device_transpose(m, n, nnz, A.rowptr.p, A.col.p, A.val.p, AT.rowptr.p, AT.col.p, AT.val.p, stream);
                 pt.tick("locality ordering + device transpose of the permuted matrix");
-            } else if (pb_fallback_wanted(A, AT.rowptr.p, n)) {
+            }
+            // (also behind an ordering whose copy the build then declined -- the cheap tiling test had accepted it: covering pattern
+            // 300k x 3M, four per column: stream kernel 0.188 ms on the y-half where the remainder path takes 0.133; end of round 5)
+            if (!A.view.tiled.valid && pb_fallback_wanted(A, AT.rowptr.p, n)) {
                 choose_pb_rows(A, AT, m, n);
                 // no column locality to be had (or the ordering is disabled): every random 8-byte gather of the stream kernel
                 // would cost a 128-byte line from the Infinity Cache / HBM.  Accept the tiled form with NO dense-tile
                 // requirement: whatever is not in dense tiles -- here almost everything -- goes through the propagation-
                 // blocking remainder (pre-pass in source order, streamed products in destination order): about 30 bytes per
                 // nonzero, all sequential.  Unstructured 2e8-nnz matrix: 3.85 -> 1.87 ms per half-step.
-                A.describe(m, n, As->rowPtr, nullptr, nullptr, 0.0);
+                if (reordered) {
+                    std::vector<int> hrp(static_cast<size_t>(m) + 1);
+                    A.rowptr.download(hrp.data(), hrp.size());
+                    A.describe(m, n, hrp.data(), nullptr, nullptr, 0.0);
+                } else {
+                    A.describe(m, n, As->rowPtr, nullptr, nullptr, 0.0);
+                }
                 pt.tick("tiled copy of A without a dense-tile requirement (propagation blocking for all entries)");
             }
             // the host copy of A^T's row pointers (row blocks, statistics) comes back on a copy stream of its own, driven by a
