@@ -23,7 +23,8 @@ for r in sys.argv[2].split(","):
     envs["pieces0_%s" % r] = dict(TL, HPRLP_TILE_ROWS=r)
 if len(sys.argv) > 3:
     envs = {k: v for k, v in envs.items() if k in sys.argv[3].split(",")}
-EXTRA = {"band_20pct_6": lambda: fr.band(2_000_000, 2_000_000, 6, 0.2, seed=66), "band_10pct_8": lambda: fr.band(3_000_000, 3_000_000, 8, 0.1, seed=67),
+EXTRA = {"cd3_25k_x3M": lambda: fr.fixed_column_degree(25_000, 3_000_000, 3, seed=81), "cd3_16k_x3M": lambda: fr.fixed_column_degree(16_000, 3_000_000, 2, seed=98),
+         "band_20pct_6": lambda: fr.band(2_000_000, 2_000_000, 6, 0.2, seed=66), "band_10pct_8": lambda: fr.band(3_000_000, 3_000_000, 8, 0.1, seed=67),
          "band_10pct_12": lambda: fr.band(2_000_000, 2_000_000, 12, 0.1, seed=68),
          "cd3_50k": lambda: fr.fixed_column_degree(50_000, 5_000_000, 3, seed=61), "cd3_33k": lambda: fr.fixed_column_degree(33_000, 4_000_000, 3, seed=62),
          "cd4_250k": lambda: fr.fixed_column_degree(250_000, 3_000_000, 4, seed=63), "cd3_50k_local": lambda: fr.band(50_000, 5_000_000, 300, 0.002, seed=64),
